@@ -1,0 +1,243 @@
+/*
+ * wayne_hip.h -- C ABI of libwayne_hip.so, the MI355X (gfx950) WFC3-IR
+ * exposure-synthesis path.  Plain pointers and sizes only; bound from Python
+ * with ctypes (wayne_amd/_lib.py) and from anything else that can call C.
+ *
+ * Each entry point names the reference interface it replaces
+ * (file:line under the ucl-exoplanets/wayne tree).
+ *
+ * Conventions
+ *   - every function returning int returns WAYNE_OK (0) or a negative
+ *     WAYNE_E_* code; wayne_last_error(ctx) gives the message;
+ *   - host pointers are borrowed for the duration of the call only;
+ *   - the library owns all device memory; one wayne_ctx per GPU / stream;
+ *     calls on distinct contexts are thread-safe, calls on one are not;
+ *   - frames are row-major, y-major: pixel (y, x) at [y * side + x], exactly
+ *     as the reference's `pixel_array[ypos*nc + xpos]` (pyparallel_menu.c:94).
+ *   - N = light-sensitive side (SUBARRAY, or 1014 for SUBARRAY 1024),
+ *     S = N + 10 = side with the 5-px reference border (detector.py:102-124).
+ */
+#ifndef WAYNE_HIP_H
+#define WAYNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAYNE_ABI_VERSION 1
+
+/* status codes */
+#define WAYNE_OK 0
+#define WAYNE_E_INVALID (-1)   /* bad argument / shape                       */
+#define WAYNE_E_NEGATIVE (-2)  /* negative electron count                     */
+#define WAYNE_E_OVERFLOW (-3)  /* sum(counts)*threads >= 2^31 in replay mode   */
+#define WAYNE_E_NOMEM (-4)     /* host or device allocation failed             */
+#define WAYNE_E_HIP (-5)       /* a HIP runtime call failed                    */
+#define WAYNE_E_NODEVICE (-6)  /* no usable gfx950 device                      */
+#define WAYNE_E_STATE (-7)     /* grism / calibration / upload missing         */
+
+/* rng_mode */
+#define WAYNE_RNG_REPLAY 0 /* glibc rand_r streams + OpenMP partition of the reference: bit-exact */
+#define WAYNE_RNG_PHILOX 1 /* Philox4x32-10 counters (production)             */
+
+/* wayne_exposure_desc.flags -- the keyword switches of
+ * ExposureGenerator.scanning_frame (exposure_generator.py:178-192) */
+#define WAYNE_F_ADD_FLAT (1u << 0)
+#define WAYNE_F_ADD_GAIN_VARIATIONS (1u << 1)
+#define WAYNE_F_ADD_NON_LINEAR (1u << 2)
+#define WAYNE_F_CLIP_DET_LIMITS (1u << 3)
+#define WAYNE_F_ADD_READ_NOISE (1u << 4)
+#define WAYNE_F_ADD_STELLAR_NOISE (1u << 5)
+#define WAYNE_F_ADD_DARK (1u << 6)
+#define WAYNE_F_ADD_INITIAL_BIAS (1u << 7)
+#define WAYNE_F_OUT_F64 (1u << 16) /* reads delivered as float64 (the reference's dtype) instead of float32 */
+
+typedef struct wayne_ctx wayne_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+
+int wayne_abi_version(void);
+const char *wayne_strerror(int status);
+
+/* Number of HIP devices visible (0 when there is none / no driver). */
+int wayne_device_count(void);
+
+/* Create a context on `device` with its own HIP stream.  NULL on failure
+ * (*status, if given, says why).  Fails -- never falls back to the CPU --
+ * when no gfx950 GPU is present. */
+wayne_ctx *wayne_ctx_create(int device, int *status);
+void wayne_ctx_destroy(wayne_ctx *ctx);
+const char *wayne_last_error(const wayne_ctx *ctx);
+int wayne_ctx_synchronize(wayne_ctx *ctx);
+/* The context's hipStream_t (as void*), for callers that interoperate. */
+void *wayne_ctx_stream(wayne_ctx *ctx);
+
+/* ---- inner boundary: the electron thrower ------------------------------ */
+
+/*
+ * Drop-in for  int *PSF(counts,size,x_pos,y_pos,psf_ratio,psf_sigmal,
+ *                       psf_sigmah,nr,nc,test,threads)
+ * (wayne/pyparallel_menu.h:1-3, pyparallel_menu.c:10-113) and therefore for
+ * wayne.pyparallel.apply_psf (wayne/pyparallel.pyx:14-38), called once per
+ * sub-sample at exposure_generator.py:636-639.
+ *
+ * Differences from the reference signature: the frame is written into the
+ * caller's `out` (nr*nc int32) instead of a malloc'd buffer the caller must
+ * free (pyparallel.pyx:36); `seed` is the reference's `test`;
+ * `threads_compat` selects the reference's OpenMP partition in replay mode
+ * (the result depends on it, pyparallel_menu.c:47-52) and never starts CPU
+ * threads; in Philox mode `exposure`/`subsample` extend the counter.
+ * WAYNE_RNG_REPLAY reproduces the reference frame bit for bit.
+ */
+int wayne_psf_apply(wayne_ctx *ctx, const int32_t *counts, int size,
+                    const double *x_pos, const double *y_pos,
+                    const double *psf_ratio, const double *psf_sigmal,
+                    const double *psf_sigmah, int nr, int nc, uint32_t seed,
+                    int threads_compat, int rng_mode, uint32_t exposure,
+                    uint32_t subsample, int32_t *out);
+
+/* ---- grism and calibration (uploaded once per context) ----------------- */
+
+/* What grism.G141 / grism.G102 hold (grism.py:24-118, 426-476, 756-776). */
+typedef struct wayne_grism_desc {
+  double trace_coeff[9];     /* aXe trace polynomial   (grism.py:756-764)   */
+  double wl_solution[9];     /* aXe dispersion solution (grism.py:768-776)  */
+  double psf_ratio_poly[4];  /* np.poly1d coefficients, highest power first */
+  double psf_sigmal_poly[4]; /*   (grism.py:85-90)                          */
+  double psf_sigmah_poly[4];
+  int n_sens;                /* sensitivity table (grism.py:97-106)         */
+  const double *sens_wl_um;  /* increasing, micron                          */
+  const double *sens_val;
+  double flat_wmin, flat_wmax; /* WMIN / WMAX of the flat cube (grism.py:71-72), angstrom */
+} wayne_grism_desc;
+
+int wayne_ctx_set_grism(wayne_ctx *ctx, const wayne_grism_desc *g);
+
+/*
+ * Calibration planes for one (SUBARRAY, SAMPSEQ, NSAMP) mode, already
+ * centre-cropped to the sub-array by the caller (tools.crop_central_box,
+ * tools.py:317-324; detector.py:328-333).  float32 as in the CALWF3 files.
+ * Any pointer may be NULL when the matching flag is never used.
+ */
+typedef struct wayne_calibration {
+  int subarray;          /* 64, 128, 256, 512 or 1024                          */
+  int n_reads;           /* R = NSAMP - 1 non-zero reads                       */
+  const float *flat[4];  /* N*N each: flat cube planes f0..f3 (grism.py:73-76) */
+  const float *pfl;      /* N*N: pixel flat; gain = 2.35 / pfl (detector.py:200-209) */
+  const float *sky;      /* N*N: master sky (grism.py:411-423)                 */
+  const float *lin[4];   /* S*S each: non-linearity c1..c4 (detector.py:58-67) */
+  const float *dark_sci; /* R*S*S: super-dark SCI of non-zero read r (detector.py:185-188) */
+  const float *dark_err; /* R*S*S: its ERR                                      */
+  const double *zero_read; /* S*S initial bias or NULL (exposure_generator.py:446-466) */
+} wayne_calibration;
+
+int wayne_ctx_set_calibration(wayne_ctx *ctx, const wayne_calibration *c);
+
+/* ---- outer boundary: one whole exposure -------------------------------- */
+
+/*
+ * Everything ExposureGenerator.scanning_frame / staring_frame
+ * (exposure_generator.py:146-405) consumes for one exposure, as plain arrays.
+ * The sample timing (A12), scan positions, jitter and SSV scaling are small
+ * K-vectors prepared by the host (wayne_amd/exposure_generator.py); the
+ * per-wavelength, per-electron and per-pixel work happens on the device:
+ *   trace + counts chain   exposure_generator.py:581-634, grism.py:491-669, 779-803
+ *   electron thrower       pyparallel_menu.c:10-113
+ *   flat                   grism.py:349-409, exposure_generator.py:641-645
+ *   per-read stage         exposure_generator.py:468-515, cosmic_rays.py:70-139
+ *   post-ramp stage        exposure_generator.py:407-444, exposure.py:49-131,
+ *                          detector.py:151-198, 318-350
+ */
+typedef struct wayne_exposure_desc {
+  uint32_t seed;           /* visit seed (run_visit.py:68-77)                  */
+  uint32_t exposure_index; /* extends every RNG counter                        */
+  int rng_mode;            /* thrower RNG: WAYNE_RNG_*                         */
+  int threads_compat;      /* replay mode only                                 */
+  uint32_t flags;          /* WAYNE_F_*                                        */
+  int sub_scale;           /* frame offset 507 - SUBARRAY/2 (exposure_generator.py:630) */
+
+  int n_wl;                /* W: bins already cropped to grism.wl_limits       */
+  const double *wl_um;     /* [W] increasing                                   */
+  const double *flux;      /* [W] stellar flux                                 */
+  const double *depth;     /* [K*W] transit depth per sub-sample, or NULL      */
+
+  int n_samples;              /* K                                             */
+  const double *x_ref;        /* [K] star x incl. jitter                       */
+  const double *y_ref;        /* [K] star y incl. scan + jitter                */
+  const double *dur_ms;       /* [K] sub-sample duration (after SSV)           */
+  const int32_t *replay_seed; /* [K] s_rand_seeds (exposure_generator.py:327) */
+  const int32_t *sample_read; /* [K] index 0..R-1 of the read that closes it   */
+
+  int n_reads;              /* R                                               */
+  const double *read_dt_s;  /* [R] interval since the previous read, seconds   */
+
+  double sky_ct_s;     /* sky background counts/s; <= 0 disables               */
+  double cosmic_rate;  /* hits/s per 1024^2; < 0 disables (None)               */
+  double scale_factor; /* visit-trend scale (1 when None)                      */
+  double noise_mean;   /* optional gaussian noise per second, both 0 disables  */
+  double noise_std;
+
+  int thrower_margin; /* LDS tile margin in px around the trace; 0 = default   */
+  int thrower_splits; /* workgroups per sub-sample; 0 = auto                   */
+} wayne_exposure_desc;
+
+/* Stage an exposure's inputs in HBM slot `slot` (0 <= slot < wayne_ctx_slots). */
+int wayne_ctx_slots(const wayne_ctx *ctx);
+int wayne_exposure_upload(wayne_ctx *ctx, int slot, const wayne_exposure_desc *d);
+/* Enqueue the whole synthesis of slot `slot` on the context stream
+ * (asynchronous; inputs and outputs stay in HBM). */
+int wayne_exposure_run(wayne_ctx *ctx, int slot);
+/* Copy the NSAMP reads (read 0 = zero read) of `slot` to the host:
+ * NSAMP*S*S float32, or float64 when WAYNE_F_OUT_F64 was set.  Synchronises. */
+int wayne_exposure_download(wayne_ctx *ctx, int slot, void *out_reads);
+/* Device pointer of that buffer (for zero-copy consumers). */
+void *wayne_exposure_device_reads(wayne_ctx *ctx, int slot);
+/* upload + run + download in one call: the batched drop-in for one
+ * ExposureGenerator.scanning_frame call. */
+int wayne_exposure_synthesize(wayne_ctx *ctx, const wayne_exposure_desc *d,
+                              void *out_reads);
+
+/* Intermediate products of the last run of `slot`, for parity tests
+ * (any pointer may be NULL):
+ *   counts  [K*W] int32  electrons per bin per sub-sample   (A9)
+ *   x_pos   [K*W] double frame x of each bin                (A7, A10)
+ *   y_pos   [K*W] double
+ *   acc_e   [R*S*S] double  flat-weighted electrons accumulated per read
+ *                    interval, before sky / gain (A11, A12); includes cosmic hits
+ * `acc_e` is only meaningful between wayne_exposure_run_front and
+ * wayne_exposure_run_back (the ramp kernel clears it). */
+int wayne_exposure_debug_fetch(wayne_ctx *ctx, int slot, int32_t *counts,
+                               double *x_pos, double *y_pos, double *acc_e);
+/* The two halves of wayne_exposure_run: front = prep + thrower + cosmic rays,
+ * back = the fused up-the-ramp kernel. */
+int wayne_exposure_run_front(wayne_ctx *ctx, int slot);
+int wayne_exposure_run_back(wayne_ctx *ctx, int slot);
+
+/* ---- measurement ------------------------------------------------------- */
+
+#define WAYNE_PROF_KERNELS 6
+typedef struct wayne_profile {
+  /* per kernel: launches and total milliseconds measured with HIP events on
+   * the context stream since wayne_profile_reset */
+  const char *name[WAYNE_PROF_KERNELS];
+  uint64_t launches[WAYNE_PROF_KERNELS];
+  double ms[WAYNE_PROF_KERNELS];
+  uint64_t electrons; /* electrons thrown */
+} wayne_profile;
+
+int wayne_profile_enable(wayne_ctx *ctx, int on);
+int wayne_profile_reset(wayne_ctx *ctx);
+int wayne_profile_get(wayne_ctx *ctx, wayne_profile *out); /* synchronises */
+
+/* ---- host helpers ------------------------------------------------------ */
+
+/* Philox4x32-10 block (Random123), used by the host for the per-exposure
+ * jitter / seed draws (exposure_generator.py:327-329). */
+void wayne_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAYNE_HIP_H */

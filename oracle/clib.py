@@ -1,0 +1,140 @@
+"""ctypes access to the oracle's C libraries.  TEST INFRASTRUCTURE ONLY.
+
+  libwayne_oracle.so        this repo's C restatement (oracle/psf_oracle.c, noise_oracle.c)
+  _ref/libwayne_ref_psf.so  the reference's own wayne/pyparallel_menu.c compiled
+                            unmodified by oracle/Makefile (present only where
+                            /root/reference was available at build time, or
+                            shipped prebuilt to the GPU box)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE = os.path.join(HERE, "libwayne_oracle.so")
+_REF = os.path.join(HERE, "_ref", "libwayne_ref_psf.so")
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """(Re)build the oracle libraries with oracle/Makefile."""
+    srcs = [os.path.join(HERE, f) for f in ("psf_oracle.c", "noise_oracle.c", "Makefile")]
+    stale = force or not os.path.exists(_ORACLE) or any(
+        os.path.getmtime(s) > os.path.getmtime(_ORACLE) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", HERE, "-B", "liboracle"])
+    if os.path.exists("/root/reference/wayne/pyparallel_menu.c") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_ORACLE)
+        L.wayne_oracle_psf.restype = C.c_int
+        L.wayne_oracle_psf.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, _i32p]
+        L.wayne_oracle_psf_philox.restype = C.c_int
+        L.wayne_oracle_psf_philox.argtypes = [_i32p, C.c_int, _f32p, _f32p, _f64p, _f32p, _f32p,
+                                              C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
+        L.wayne_oracle_philox4x32.restype = None
+        L.wayne_oracle_philox4x32.argtypes = [_u32p, _u32p, _u32p]
+        L.wayne_oracle_rand_r.restype = C.c_int
+        L.wayne_oracle_rand_r.argtypes = [C.POINTER(C.c_uint32)]
+        L.wayne_oracle_poisson_f64.restype = None
+        L.wayne_oracle_poisson_f64.argtypes = [_f64p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, _f64p]
+        L.wayne_oracle_poisson_sky.restype = None
+        L.wayne_oracle_poisson_sky.argtypes = [_f32p, _u32p, C.c_int64, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, _f64p]
+        L.wayne_oracle_normal_pairs.restype = None
+        L.wayne_oracle_normal_pairs.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, _f32p, _f32p]
+        L.wayne_oracle_philox_blocks.restype = None
+        L.wayne_oracle_philox_blocks.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32, _u32p]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(_REF)
+
+
+def ref():
+    """The reference's compiled PSF(); None when oracle/_ref was not built."""
+    global _ref
+    if _ref is None and have_ref():
+        L = C.CDLL(_REF)
+        L.PSF.restype = C.POINTER(C.c_int)
+        L.PSF.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p,
+                          C.c_int, C.c_int, C.c_int, C.c_int]
+        _ref = L
+    return _ref
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+_libc.free.restype = None
+
+
+def _prep(counts, x, y, ratio, sl, sh):
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, ratio, sl, sh)]
+    n = counts.size
+    assert all(a.size == n for a in arrs)
+    return (counts,) + tuple(arrs)
+
+
+def psf_oracle(counts, x, y, ratio, sl, sh, nr, nc, test, threads):
+    """The repo's restatement of PSF() -> int32[nr*nc] (raises on invalid input)."""
+    counts, x, y, ratio, sl, sh = _prep(counts, x, y, ratio, sl, sh)
+    out = np.empty(nr * nc, dtype=np.int32)
+    rc = lib().wayne_oracle_psf(counts, counts.size, x, y, ratio, sl, sh, nr, nc, int(test), int(threads), out)
+    if rc != 0:
+        raise ValueError("wayne_oracle_psf: status %d" % rc)
+    return out
+
+
+def psf_reference(counts, x, y, ratio, sl, sh, nr, nc, test, threads):
+    """The reference's own compiled PSF() (wayne/pyparallel_menu.c) -> int32[nr*nc]."""
+    L = ref()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libwayne_ref_psf.so not built")
+    counts, x, y, ratio, sl, sh = _prep(counts, x, y, ratio, sl, sh)
+    p = L.PSF(counts, counts.size, x, y, ratio, sl, sh, nr, nc, int(test), int(threads))
+    out = np.ctypeslib.as_array(p, shape=(nr * nc,)).astype(np.int32, copy=True)
+    _libc.free(C.cast(p, C.c_void_p))
+    return out
+
+
+def psf_philox_oracle(counts, x, y, ratio, sl, sh, nr, nc, seed, exposure, subsample):
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    x32, y32, sl32, sh32 = (np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+                            for a in (x, y, sl, sh))
+    ratio = np.ascontiguousarray(ratio, dtype=np.float64)
+    out = np.empty(nr * nc, dtype=np.int32)
+    rc = lib().wayne_oracle_psf_philox(counts, counts.size, x32, y32, ratio, sl32, sh32, nr, nc,
+                                       int(seed), int(exposure), int(subsample), out)
+    if rc != 0:
+        raise ValueError("wayne_oracle_psf_philox: status %d" % rc)
+    return out
+
+
+def philox4x32(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().wayne_oracle_philox4x32(ctr, key, out)
+    return out

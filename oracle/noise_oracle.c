@@ -1,0 +1,189 @@
+/*
+ * oracle/noise_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU statement of the Philox-keyed Poisson / normal / uniform-integer draws
+ * that stand in for numpy's legacy generator on the MI355X path
+ * (reference call sites: exposure_generator.py:327-329,495,626,725;
+ *  detector.py:191,198; cosmic_rays.py:80-81,127,134).
+ *
+ * Parity status: the reference's MT19937 stream cannot be reproduced by a
+ * sharded, counter-based generator, so these draws are "parity unpinned"
+ * against the reference; they are pinned instead by
+ *   (a) Random123's known-answer vectors for Philox4x32-10,
+ *   (b) distribution tests against scipy.stats (tests/test_samplers.py),
+ *   (c) agreement with the device under the same counters.
+ * The algorithms are the published ones numpy's legacy poisson uses:
+ * Knuth's product of uniforms for lam < 10 and Hoermann's PTRS transformed
+ * rejection (Insurance: Mathematics and Economics 12, 1993) for lam >= 10.
+ * Written separately from wayne_amd/csrc/samplers.h on purpose: two
+ * statements of one specification check each other.
+ */
+#include <math.h>
+#include <stdint.h>
+
+void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+typedef struct {
+  uint32_t ctr[4];
+  uint32_t key[2];
+  uint32_t buf[4];
+  int have;
+} wo_stream;
+
+static void wo_stream_init(wo_stream *s, uint32_t seed, uint32_t stage, uint32_t c0,
+                           uint32_t c2, uint32_t c3) {
+  s->ctr[0] = c0; s->ctr[1] = 0; s->ctr[2] = c2; s->ctr[3] = c3;
+  s->key[0] = seed; s->key[1] = stage;
+  s->have = 0;
+}
+
+static uint32_t wo_next(wo_stream *s) {
+  if (s->have == 0) {
+    wayne_oracle_philox4x32(s->ctr, s->key, s->buf);
+    s->ctr[1] += 1;
+    s->have = 4;
+  }
+  uint32_t v = s->buf[4 - s->have];
+  s->have -= 1;
+  return v;
+}
+
+static float wo_u01f(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
+static double wo_u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+
+/* ---- ln Gamma via shift + Stirling, double and float ------------------- */
+static double wo_loggam_d(double x) {
+  double prod = 1.0;
+  for (int i = 0; i < 6 && x < 7.0; ++i) { prod = prod * x; x = x + 1.0; }
+  const double xi = 1.0 / x, x2 = xi * xi;
+  double s = -691.0 / 360360.0;
+  s = s * x2 + 1.0 / 1188.0;
+  s = s * x2 + -1.0 / 1680.0;
+  s = s * x2 + 1.0 / 1260.0;
+  s = s * x2 + -1.0 / 360.0;
+  s = s * x2 + 1.0 / 12.0;
+  s = s * xi;
+  return (x - 0.5) * log(x) - x + 0.91893853320467274178 + s - log(prod);
+}
+static float wo_loggam_f(float x) {
+  float prod = 1.0f;
+  for (int i = 0; i < 6 && x < 7.0f; ++i) { prod = prod * x; x = x + 1.0f; }
+  const float xi = 1.0f / x, x2 = xi * xi;
+  float s = (float)(-691.0 / 360360.0);
+  s = s * x2 + (float)(1.0 / 1188.0);
+  s = s * x2 + (float)(-1.0 / 1680.0);
+  s = s * x2 + (float)(1.0 / 1260.0);
+  s = s * x2 + (float)(-1.0 / 360.0);
+  s = s * x2 + (float)(1.0 / 12.0);
+  s = s * xi;
+  return (x - 0.5f) * logf(x) - x + (float)0.91893853320467274178 + s - logf(prod);
+}
+
+/* ---- Poisson ------------------------------------------------------------ */
+static double wo_poisson_d(double lam, wo_stream *rng) {
+  if (!(lam > 0.0)) return 0.0;
+  if (lam < 10.0) {
+    const double enlam = exp(-lam);
+    double k = 0.0, prod = 1.0;
+    for (int it = 0; it < 4096; ++it) {
+      prod = prod * wo_u01d(wo_next(rng));
+      if (prod > enlam) k = k + 1.0; else break;
+    }
+    return k;
+  }
+  const double slam = sqrt(lam), loglam = log(lam);
+  const double b = 0.931 + 2.53 * slam;
+  const double a = -0.059 + 0.02483 * b;
+  const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+  const double vr = 0.9277 - 3.6224 / (b - 2.0);
+  for (int it = 0; it < 256; ++it) {
+    const double U = wo_u01d(wo_next(rng)) - 0.5;
+    const double V = wo_u01d(wo_next(rng));
+    const double us = 0.5 - fabs(U);
+    const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
+    if (us >= 0.07 && V <= vr) return k;
+    if (k < 0.0 || (us < 0.013 && V > us)) continue;
+    const double lhs = log(V) + log(invalpha) - log(a / (us * us) + b);
+    const double rhs = -lam + k * loglam - wo_loggam_d(k + 1.0);
+    if (lhs <= rhs) return k;
+  }
+  return floor(lam + 0.5);
+}
+
+static float wo_poisson_f(float lam, wo_stream *rng) {
+  if (!(lam > 0.0f)) return 0.0f;
+  if (lam < 10.0f) {
+    const float enlam = expf(-lam);
+    float k = 0.0f, prod = 1.0f;
+    for (int it = 0; it < 4096; ++it) {
+      prod = prod * wo_u01f(wo_next(rng));
+      if (prod > enlam) k = k + 1.0f; else break;
+    }
+    return k;
+  }
+  const float slam = sqrtf(lam), loglam = logf(lam);
+  const float b = 0.931f + 2.53f * slam;
+  const float a = -0.059f + 0.02483f * b;
+  const float invalpha = 1.1239f + 1.1328f / (b - 3.4f);
+  const float vr = 0.9277f - 3.6224f / (b - 2.0f);
+  for (int it = 0; it < 256; ++it) {
+    const float U = wo_u01f(wo_next(rng)) - 0.5f;
+    const float V = wo_u01f(wo_next(rng));
+    const float us = 0.5f - fabsf(U);
+    const float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
+    if (us >= 0.07f && V <= vr) return k;
+    if (k < 0.0f || (us < 0.013f && V > us)) continue;
+    const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
+    const float rhs = -lam + k * loglam - wo_loggam_f(k + 1.0f);
+    if (lhs <= rhs) return k;
+  }
+  return floorf(lam + 0.5f);
+}
+
+/* Vector entry points used by oracle/wayne_oracle.py.  Element i draws from
+ * the stream (c0[i] or c0_base + i, c2, c3) of stage `stage`. */
+void wayne_oracle_poisson_f64(const double *lam, int64_t n, uint32_t seed, uint32_t stage,
+                              uint32_t c0_base, uint32_t c2, uint32_t c3, double *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    wo_stream s;
+    wo_stream_init(&s, seed, stage, c0_base + (uint32_t)i, c2, c3);
+    out[i] = wo_poisson_d(lam[i], &s);
+  }
+}
+
+/* the sky draw of the ramp kernel: float32 sampler below lam = 256, float64
+ * above; element i uses counter c0 = idx[i] (the bordered pixel index) */
+void wayne_oracle_poisson_sky(const float *lam, const uint32_t *idx, int64_t n, uint32_t seed,
+                              uint32_t stage, uint32_t c2, uint32_t c3, double *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    wo_stream s;
+    wo_stream_init(&s, seed, stage, idx[i], c2, c3);
+    out[i] = (lam[i] < 256.0f) ? (double)wo_poisson_f(lam[i], &s) : wo_poisson_d((double)lam[i], &s);
+  }
+}
+
+/* Box-Muller pair from words 0,1 of block (idx[i], 0, c2, c3): fp32, libm. */
+void wayne_oracle_normal_pairs(const uint32_t *idx, int64_t n, uint32_t seed, uint32_t stage,
+                               uint32_t c2, uint32_t c3, float *z0, float *z1) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t ctr[4] = {idx[i], 0u, c2, c3};
+    const uint32_t key[2] = {seed, stage};
+    uint32_t w[4];
+    wayne_oracle_philox4x32(ctr, key, w);
+    const float ua = wo_u01f(w[0]), ub = wo_u01f(w[1]);
+    const float R = sqrtf(-2.0f * logf(ub));
+    const float ang = 6.283185307179586f * ua;
+    z0[i] = R * cosf(ang);
+    z1[i] = R * sinf(ang);
+  }
+}
+
+/* Raw blocks, for uniform-integer draws (cosmic rays) and host draws. */
+void wayne_oracle_philox_blocks(const uint32_t *c0, int64_t n, uint32_t c1, uint32_t c2, uint32_t c3,
+                                uint32_t seed, uint32_t stage, uint32_t *out /* n*4 */) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t ctr[4] = {c0[i], c1, c2, c3};
+    const uint32_t key[2] = {seed, stage};
+    wayne_oracle_philox4x32(ctr, key, out + 4 * i);
+  }
+}

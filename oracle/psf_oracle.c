@@ -1,0 +1,197 @@
+/*
+ * oracle/psf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference electron thrower `PSF()`
+ * (reference: wayne/pyparallel_menu.c:10-113) and of the production
+ * (Philox-keyed) thrower that wayne_amd's HIP kernel implements.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path never links or calls it.
+ *
+ * Pinning: `wayne_oracle_psf` is checked bit-for-bit against the reference's
+ * own C file compiled unmodified into oracle/_ref/libwayne_ref_psf.so
+ * (oracle/Makefile), and against the golden vectors under tests/golden/
+ * that were generated from that library (scripts/make_golden_psf.py).
+ *
+ * What the reference does (restated, not copied):
+ *   A1  ssum = sum(counts)                                   (:19-34)
+ *   A2  T "threads" each own electrons [t*ssum/T, (t+1)*ssum/T) (last one up
+ *       to ssum), seed_t = 25234 + 17*t + test, and per electron draw
+ *       theta = 2*pi*rand_r/RAND_MAX ; R = sqrt(-2 ln(rand_r/RAND_MAX));
+ *       A[i] = R cos(theta) ; A[i+ssum] = R sin(theta)          (:40-64)
+ *   A3  zero the frame                                        (:68-83)
+ *   A4  serial scatter, bin-major: the first (int)(counts*ratio) electrons of
+ *       a bin use sigma_h, the rest sigma_l; position truncates toward zero;
+ *       kept iff 0 < xpos < nr and 0 < ypos < nc; pixel[ypos*nc + xpos]++
+ *                                                              (:87-108)
+ * The OpenMP team is emulated by looping over thread ids, so the result is
+ * the one the reference produces when the runtime grants exactly `threads`
+ * threads (it depends on `threads`, as the reference's does).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WO_PI 3.14159265358979323846
+#define WO_RAND_MAX 2147483647
+
+/* glibc rand_r (stdlib/rand_r.c), restated: three steps of the LCG
+ * next = next*1103515245 + 12345, taking 11, 10 and 10 bits of (next>>16). */
+static inline int wo_rand_r(uint32_t *state) {
+  uint32_t s = *state;
+  uint32_t r;
+  s = s * 1103515245u + 12345u;
+  r = (s >> 16) & 2047u;
+  s = s * 1103515245u + 12345u;
+  r = (r << 10) ^ ((s >> 16) & 1023u);
+  s = s * 1103515245u + 12345u;
+  r = (r << 10) ^ ((s >> 16) & 1023u);
+  *state = s;
+  return (int)r;
+}
+
+int wayne_oracle_rand_r(uint32_t *state) { return wo_rand_r(state); }
+
+/* C's (int) conversion of an out-of-range / non-finite double is undefined;
+ * on x86-64 (cvttsd2si) it yields INT_MIN, which the bounds test rejects.
+ * Make that explicit so the oracle is well defined everywhere. */
+static inline int wo_trunc_int(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+  return (int)v;
+}
+
+/* Returns 0 on success, <0 on invalid input (the reference has no checks;
+ * these are the cases where it would overflow or write out of bounds). */
+int wayne_oracle_psf(const int32_t *counts, int size, const double *x_pos,
+                     const double *y_pos, const double *psf_ratio,
+                     const double *psf_sigmal, const double *psf_sigmah,
+                     int nr, int nc, int test, int threads, int32_t *out) {
+  if (size < 0 || nr <= 0 || nc <= 0 || threads <= 0) return -1;
+  int64_t total = 0;
+  for (int k = 0; k < size; ++k) {
+    if (counts[k] < 0) return -2;
+    total += counts[k];
+  }
+  /* reference: `int ssum`, and `myid*ssum` evaluated in int (:12, :48) */
+  if (total * (int64_t)threads > 2147483647LL) return -3;
+  const int ssum = (int)total;
+
+  double *A = (double *)malloc((size_t)(2 * (int64_t)ssum + 1) * sizeof(double));
+  if (!A) return -4;
+
+  for (int t = 0; t < threads; ++t) {
+    int istart = t * ssum / threads;
+    int iend = (t + 1) * ssum / threads;
+    if (t == threads - 1) iend = ssum;
+    uint32_t seed = (uint32_t)(25234 + 17 * t + test);
+    for (int i = istart; i < iend; ++i) {
+      double theta = 2. * WO_PI * wo_rand_r(&seed) / ((double)WO_RAND_MAX);
+      double R = sqrt(-2. * log(wo_rand_r(&seed) / ((double)WO_RAND_MAX)));
+      A[i] = R * cos(theta);
+      A[i + ssum] = R * sin(theta);
+    }
+  }
+
+  memset(out, 0, (size_t)nr * (size_t)nc * sizeof(int32_t));
+
+  int e = 0;
+  for (int b = 0; b < size; ++b) {
+    const int n_wide = wo_trunc_int(counts[b] * psf_ratio[b]);
+    for (int j = 0; j < counts[b]; ++j, ++e) {
+      /* the first n_wide electrons of the bin take the WIDE gaussian */
+      const double sig = (j < n_wide) ? psf_sigmah[b] : psf_sigmal[b];
+      const int xp = wo_trunc_int(A[e] * sig + x_pos[b]);
+      const int yp = wo_trunc_int(A[e + ssum] * sig + y_pos[b]);
+      if (xp > 0 && xp < nr && yp > 0 && yp < nc) out[yp * nc + xp] += 1;
+    }
+  }
+  free(A);
+  return 0;
+}
+
+/* --------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 v1.09).  The
+ * reference uses numpy's MT19937 + rand_r, whose streams depend on exposure
+ * order and `threads`; the MI355X path replaces them by counter-based draws
+ * keyed by (seed, stage, exposure, sub-sample/read, element).  This is the
+ * oracle's own statement of the generator, pinned by Random123's published
+ * known-answer vectors (tests/test_philox.py).
+ * ------------------------------------------------------------------------ */
+void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2],
+                             uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Stage ids of the production RNG stream layout (DESIGN.md "RNG streams").
+ * key = (seed, stage); counter = (element lo, element hi / draw, sub-sample or
+ * read, exposure). */
+enum { WO_STAGE_THROW = 2 };
+
+/* u32 -> uniform in (0,1): (x + 0.5) * 2^-32, evaluated in fp32 exactly as
+ * the device does (the product rounds to nearest fp32; never 0, may be 1.0f
+ * only for x >= 0xFFFFFF80 where logf gives 0 -> R = 0, a valid draw). */
+static inline float wo_u01(uint32_t x) {
+  return ((float)x + 0.5f) * 2.3283064365386963e-10f;
+}
+
+/*
+ * Production-mode thrower for ONE sub-sample: electron e (bin-major order,
+ * exactly the reference's numbering, pyparallel_menu.c:87-108) draws its pair
+ * of normals from Philox counter (e>>1, 0, subsample, exposure), words
+ * {0,1} for even e and {2,3} for odd e:
+ *    z_x = R cos(2 pi u_a), z_y = R sin(2 pi u_a), R = sqrt(-2 ln u_b)
+ * in fp32 (the device uses v_sin/v_cos/v_log hardware approximations, so
+ * device-vs-oracle agreement is "all but a ~1e-4 fraction of electrons land
+ * in the same pixel", asserted and counted in tests/test_thrower_philox.py).
+ * Positions are fp32.  Same sigma split, truncation and bounds rule as A4.
+ */
+int wayne_oracle_psf_philox(const int32_t *counts, int size,
+                            const float *x_pos, const float *y_pos,
+                            const double *psf_ratio, const float *psf_sigmal,
+                            const float *psf_sigmah, int nr, int nc,
+                            uint32_t seed, uint32_t exposure,
+                            uint32_t subsample, int32_t *out) {
+  if (size < 0 || nr <= 0 || nc <= 0) return -1;
+  memset(out, 0, (size_t)nr * (size_t)nc * sizeof(int32_t));
+  const uint32_t key[2] = {seed, WO_STAGE_THROW};
+  uint64_t e = 0;
+  uint32_t rnd[4] = {0, 0, 0, 0};
+  for (int b = 0; b < size; ++b) {
+    if (counts[b] < 0) return -2;
+    /* sigma split in fp64, as the reference (:89) */
+    const int n_wide = wo_trunc_int(counts[b] * psf_ratio[b]);
+    for (int j = 0; j < counts[b]; ++j, ++e) {
+      if ((e & 1u) == 0) {
+        /* new block: electrons 2q and 2q+1 share Philox counter q */
+        const uint64_t blk = e >> 1;
+        const uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), subsample,
+                                 exposure};
+        wayne_oracle_philox4x32(ctr, key, rnd);
+      }
+      const uint32_t ra = rnd[(e & 1u) * 2], rb = rnd[(e & 1u) * 2 + 1];
+      const float ua = wo_u01(ra), ub = wo_u01(rb);
+      const float R = sqrtf(-2.0f * logf(ub));
+      const float ang = 6.283185307179586f * ua;
+      const float zx = R * cosf(ang), zy = R * sinf(ang);
+      const float sig = (j < n_wide) ? psf_sigmah[b] : psf_sigmal[b];
+      /* explicit fma: the device contracts z*sig+pos into v_fma_f32 */
+      const int xp = wo_trunc_int((double)fmaf(zx, sig, x_pos[b]));
+      const int yp = wo_trunc_int((double)fmaf(zy, sig, y_pos[b]));
+      if (xp > 0 && xp < nr && yp > 0 && yp < nc) out[yp * nc + xp] += 1;
+    }
+  }
+  return 0;
+}

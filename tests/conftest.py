@@ -1,0 +1,40 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_psf_cases():
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "psf_*.npz")))
+
+
+def load_golden_psf(name):
+    z = np.load(os.path.join(GOLDEN, "psf_%s.npz" % name))
+    k = {n: z[n] for n in z.files}
+    for n in ("nr", "nc", "test", "threads"):
+        k[n] = int(k[n])
+    frame = np.zeros(k["nr"] * k["nc"], dtype=np.int32)
+    frame[k["idx"]] = k["val"]
+    k["frame"] = frame
+    return k
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One wayne_ctx on cuda:0 for the whole GPU session (fails loudly without a GPU)."""
+    from wayne_amd import _lib
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,60 @@
+"""CPU: libwayne_hip.so builds, loads and exports every symbol that
+include/wayne_hip.h declares; without a GPU the path fails loudly."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from wayne_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "wayne_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wayne_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "libwayne_hip.so does not export %s" % n
+    # and the binding covers them all
+    assert set(names) == set(_lib.SYMBOLS)
+
+
+def test_abi_version_and_strerror():
+    L = _lib.load()
+    assert L.wayne_abi_version() == 1
+    assert L.wayne_strerror(0) == b"ok"
+    assert b"gfx950" in L.wayne_strerror(_lib.E_NODEVICE)
+
+
+def test_host_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(v) for v in _lib.philox4x32(ctr, key)) == want
+
+
+def test_struct_layouts_match_header_sizes():
+    # a drifted struct would corrupt every call: check the sizes the C side sees
+    import ctypes as C
+    assert C.sizeof(_lib.GrismDesc) == 8 * (9 + 9 + 12) + 8 + 16 + 16
+    assert C.sizeof(_lib.Calibration) == 8 + 8 * (4 + 1 + 1 + 4 + 1 + 1 + 1)
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="a GPU is present")
+def test_no_gpu_fails_loudly():
+    with pytest.raises(_lib.WayneNoDeviceError):
+        _lib.Context(0)
+    from wayne_amd import pyparallel
+    with pytest.raises(_lib.WayneError):
+        pyparallel.apply_psf(np.ones(3), np.ones(3), np.ones(3), np.ones(3), np.ones(3), np.ones(3), 8, 8, 0, 1)

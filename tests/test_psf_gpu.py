@@ -1,0 +1,116 @@
+"""GPU: the HIP electron thrower through the C ABI (wayne_psf_apply) and the
+apply_psf drop-in, against the reference's golden frames and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden_psf_cases, load_golden_psf
+from oracle import clib
+
+pytestmark = pytest.mark.gpu
+CASES = golden_psf_cases()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_replay_mode_is_bit_exact_against_reference_golden(gpu_ctx, name):
+    k = load_golden_psf(name)
+    got = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], k["nr"], k["nc"],
+                            k["test"], k["threads"], rng_mode=0)
+    # Integer electron counts: bit-exact.  A flip needs A*sigma+x within ~1 ulp
+    # of an integer where device libm and glibc round differently (p ~ 1e-13
+    # per electron); any such electron is counted here, not hidden.
+    diff = int(np.abs(got.astype(np.int64) - k["frame"].astype(np.int64)).sum())
+    assert got.sum() == k["frame"].sum()
+    assert diff == 0, "%d electrons landed in a different pixel" % (diff // 2)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 7])
+def test_replay_mode_random_inputs_against_oracle(gpu_ctx, threads):
+    rng = np.random.RandomState(7 + threads)
+    for trial in range(6):
+        W = int(rng.randint(1, 3000))
+        N = int(rng.choice([32, 64, 256, 512]))
+        counts = rng.poisson(rng.uniform(0.1, 80), W).astype(np.int32)
+        x = np.sort(rng.uniform(-8, N + 8, W))
+        y = rng.uniform(0.3, 0.7) * N + 0.01 * x
+        ratio = rng.uniform(0, 1, W)
+        sl, sh = rng.uniform(0.3, 1.0, W), rng.uniform(3, 8, W)
+        test = int(rng.randint(0, 100000))
+        want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, test, threads)
+        got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, test, threads, rng_mode=0)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_apply_psf_dropin_signature_and_dtype(gpu_ctx):
+    from wayne_amd import pyparallel
+    k = load_golden_psf("s64_t3")
+    out = pyparallel.apply_psf(k["counts"].astype(np.float64), k["x"], k["y"], k["ratio"], k["sl"], k["sh"],
+                               k["nr"], k["nc"], k["test"], k["threads"])
+    assert out.dtype == np.float64 and out.shape == (k["nr"] * k["nc"],)   # pyparallel.pyx:31-34
+    np.testing.assert_array_equal(out, k["frame"].astype(np.float64))
+
+
+def test_philox_mode_against_oracle_same_counters(gpu_ctx):
+    # Same Philox counters, fp32 Box-Muller: the device uses the hardware
+    # sin/cos/log2 units, the oracle libm, so a small fraction of electrons may
+    # truncate into the neighbouring pixel.  Totals must agree exactly.
+    k = load_golden_psf("s256_t4")
+    for seed, exp, sub in [(1963, 0, 0), (7, 12, 3)]:
+        want = clib.psf_philox_oracle(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 256, 256,
+                                      seed, exp, sub)
+        got = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 256, 256, seed,
+                                threads=1, rng_mode=1, exposure=exp, subsample=sub)
+        moved = int(np.abs(got.astype(np.int64) - want.astype(np.int64)).sum()) // 2
+        total = int(want.sum())
+        assert abs(int(got.sum()) - total) <= 2          # only edge-of-frame flips change the total
+        assert moved <= 2e-3 * total, "%d of %d electrons moved" % (moved, total)
+
+
+def test_philox_mode_is_deterministic_and_geometry_invariant(gpu_ctx):
+    import os
+    k = load_golden_psf("s1014_t4")
+    a = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
+    b = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
+    np.testing.assert_array_equal(a, b)
+    old = os.environ.get("WAYNE_TILE_INTS")
+    os.environ["WAYNE_TILE_INTS"] = "300"          # tiny LDS tile: most electrons take the global path
+    try:
+        c = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
+    finally:
+        if old is None:
+            del os.environ["WAYNE_TILE_INTS"]
+        else:
+            os.environ["WAYNE_TILE_INTS"] = old
+    np.testing.assert_array_equal(a, c)
+    assert a.sum() == k["counts"].sum()             # nothing falls off this frame
+
+
+def test_philox_mode_psf_moments(gpu_ctx):
+    # one bin, many electrons: the double gaussian's second moment
+    n, N = 400000, 128
+    ratio, sl, sh = 0.25, 0.7, 5.5
+    f = gpu_ctx.psf_apply([n], [64.5], [64.5], [ratio], [sl], [sh], N, N, 3, rng_mode=1).reshape(N, N)
+    assert f.sum() == n
+    ys, xs = np.mgrid[0:N, 0:N]
+    mx, my = (f * xs).sum() / n, (f * ys).sum() / n
+    # truncation toward zero of x ~ N(64.5, s): pixel = floor(x), mean 64.0
+    assert abs(mx - 64.0) < 0.05 and abs(my - 64.0) < 0.05
+    var = (f * (xs - mx) ** 2).sum() / n
+    want = ratio * sh ** 2 + (1 - ratio) * sl ** 2 + 1.0 / 12.0
+    assert abs(var - want) < 0.03 * want
+
+
+def test_errors(gpu_ctx):
+    from wayne_amd import _lib
+    one = np.ones(3)
+    with pytest.raises(_lib.WayneError) as e:
+        gpu_ctx.psf_apply([1, -1, 2], one, one, one, one, one, 8, 8, 0, 1)
+    assert e.value.status == _lib.E_NEGATIVE
+    with pytest.raises(_lib.WayneError) as e:
+        gpu_ctx.psf_apply([2 ** 30, 2 ** 30 - 1, 0], one, one, one, one, one, 8, 8, 0, 2)
+    assert e.value.status == _lib.E_OVERFLOW
+    with pytest.raises(_lib.WayneError):
+        gpu_ctx.psf_apply([1, 1, 1], one, one, one, one, one, 8, 16, 0, 1)
+    # empty input -> all-zero frame
+    z = gpu_ctx.psf_apply(np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0),
+                          16, 16, 0, 1)
+    assert z.shape == (256,) and not z.any()

@@ -1,0 +1,370 @@
+"""ctypes binding of libwayne_hip.so (include/wayne_hip.h).
+
+The library is the only compute path.  If it is missing it is built with
+hipcc (wayne_amd/build.py); if that fails, or no gfx950 GPU is present when a
+context is requested, this raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+# status codes (wayne_hip.h)
+OK, E_INVALID, E_NEGATIVE, E_OVERFLOW, E_NOMEM, E_HIP, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
+RNG_REPLAY, RNG_PHILOX = 0, 1
+F_ADD_FLAT = 1 << 0
+F_ADD_GAIN_VARIATIONS = 1 << 1
+F_ADD_NON_LINEAR = 1 << 2
+F_CLIP_DET_LIMITS = 1 << 3
+F_ADD_READ_NOISE = 1 << 4
+F_ADD_STELLAR_NOISE = 1 << 5
+F_ADD_DARK = 1 << 6
+F_ADD_INITIAL_BIAS = 1 << 7
+F_OUT_F64 = 1 << 16
+PROF_KERNELS = 6
+
+
+class WayneError(RuntimeError):
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, "wayne_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class WayneNoDeviceError(WayneError):
+    pass
+
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class GrismDesc(C.Structure):
+    _fields_ = [("trace_coeff", C.c_double * 9), ("wl_solution", C.c_double * 9),
+                ("psf_ratio_poly", C.c_double * 4), ("psf_sigmal_poly", C.c_double * 4),
+                ("psf_sigmah_poly", C.c_double * 4), ("n_sens", C.c_int),
+                ("sens_wl_um", _dp), ("sens_val", _dp),
+                ("flat_wmin", C.c_double), ("flat_wmax", C.c_double)]
+
+
+class Calibration(C.Structure):
+    _fields_ = [("subarray", C.c_int), ("n_reads", C.c_int), ("flat", _fp * 4), ("pfl", _fp),
+                ("sky", _fp), ("lin", _fp * 4), ("dark_sci", _fp), ("dark_err", _fp),
+                ("zero_read", _dp)]
+
+
+class ExposureDesc(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("exposure_index", C.c_uint32), ("rng_mode", C.c_int),
+                ("threads_compat", C.c_int), ("flags", C.c_uint32), ("sub_scale", C.c_int),
+                ("n_wl", C.c_int), ("wl_um", _dp), ("flux", _dp), ("depth", _dp),
+                ("n_samples", C.c_int), ("x_ref", _dp), ("y_ref", _dp), ("dur_ms", _dp),
+                ("replay_seed", _ip), ("sample_read", _ip),
+                ("n_reads", C.c_int), ("read_dt_s", _dp),
+                ("sky_ct_s", C.c_double), ("cosmic_rate", C.c_double), ("scale_factor", C.c_double),
+                ("noise_mean", C.c_double), ("noise_std", C.c_double),
+                ("thrower_margin", C.c_int), ("thrower_splits", C.c_int)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("name", C.c_char_p * PROF_KERNELS), ("launches", C.c_uint64 * PROF_KERNELS),
+                ("ms", C.c_double * PROF_KERNELS), ("electrons", C.c_uint64)]
+
+
+# every symbol include/wayne_hip.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    "wayne_abi_version": (C.c_int, []),
+    "wayne_strerror": (C.c_char_p, [C.c_int]),
+    "wayne_device_count": (C.c_int, []),
+    "wayne_ctx_create": (_vp, [C.c_int, C.POINTER(C.c_int)]),
+    "wayne_ctx_destroy": (None, [_vp]),
+    "wayne_last_error": (C.c_char_p, [_vp]),
+    "wayne_ctx_synchronize": (C.c_int, [_vp]),
+    "wayne_ctx_stream": (_vp, [_vp]),
+    "wayne_psf_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                  C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "wayne_ctx_set_grism": (C.c_int, [_vp, C.POINTER(GrismDesc)]),
+    "wayne_ctx_set_calibration": (C.c_int, [_vp, C.POINTER(Calibration)]),
+    "wayne_ctx_slots": (C.c_int, [_vp]),
+    "wayne_exposure_upload": (C.c_int, [_vp, C.c_int, C.POINTER(ExposureDesc)]),
+    "wayne_exposure_run": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_download": (C.c_int, [_vp, C.c_int, _vp]),
+    "wayne_exposure_device_reads": (_vp, [_vp, C.c_int]),
+    "wayne_exposure_synthesize": (C.c_int, [_vp, C.POINTER(ExposureDesc), _vp]),
+    "wayne_exposure_debug_fetch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "wayne_exposure_run_front": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_run_back": (C.c_int, [_vp, C.c_int]),
+    "wayne_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "wayne_profile_reset": (C.c_int, [_vp]),
+    "wayne_profile_get": (C.c_int, [_vp, C.POINTER(Profile)]),
+    "wayne_philox4x32": (None, [_vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (building first if needed) libwayne_hip.so.  Raises on failure."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if _build.stale():
+            if os.path.exists(_build.HIPCC):
+                _build.build(verbose=False)
+            elif not os.path.exists(path):
+                raise ImportError("libwayne_hip.so is not built and hipcc is unavailable (%s)" % _build.HIPCC)
+        L = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            f.restype = res
+            f.argtypes = args
+        if L.wayne_abi_version() != 1:
+            raise ImportError("libwayne_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def ptr(a, ctype=None):
+    """Raw pointer of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    if ctype is None:
+        return a.ctypes.data_as(C.c_void_p)
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context(object):
+    """One wayne_ctx: a GPU, a HIP stream and the HBM buffers of the path."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        st = C.c_int(0)
+        self._h = self._L.wayne_ctx_create(int(device), C.byref(st))
+        if not self._h:
+            msg = self._L.wayne_strerror(st.value).decode()
+            cls = WayneNoDeviceError if st.value == E_NODEVICE else WayneError
+            raise cls(st.value, "wayne_ctx_create(device=%d): %s -- the HIP path is the only path, "
+                                "there is no CPU fallback" % (device, msg))
+        self.device = device
+        self._keep = []  # arrays referenced by descriptors during a call
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.wayne_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, status):
+        if status != OK:
+            raise WayneError(status, self._L.wayne_last_error(self._h).decode())
+
+    def synchronize(self):
+        self.check(self._L.wayne_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._L.wayne_ctx_stream(self._h)
+
+    # -- inner boundary -----------------------------------------------------
+    def psf_apply(self, counts, x, y, ratio, sl, sh, nr, nc, seed, threads=1, rng_mode=RNG_REPLAY,
+                  exposure=0, subsample=0):
+        counts = i32(counts)
+        x, y, ratio, sl, sh = f64(x), f64(y), f64(ratio), f64(sl), f64(sh)
+        n = counts.size
+        if not all(a.size == n for a in (x, y, ratio, sl, sh)):
+            raise ValueError("apply_psf: arrays differ in length")
+        out = np.empty(max(int(nr) * int(nc), 0), dtype=np.int32)
+        self.check(self._L.wayne_psf_apply(self._h, ptr(counts), n, ptr(x), ptr(y), ptr(ratio), ptr(sl),
+                                           ptr(sh), int(nr), int(nc), int(seed) & 0xFFFFFFFF, int(threads),
+                                           int(rng_mode), int(exposure), int(subsample), ptr(out)))
+        return out
+
+    # -- grism / calibration --------------------------------------------------
+    def set_grism(self, trace_coeff, wl_solution, psf_ratio_poly, psf_sigmal_poly, psf_sigmah_poly,
+                  sens_wl_um, sens_val, flat_wmin, flat_wmax):
+        g = GrismDesc()
+        g.trace_coeff[:] = list(map(float, trace_coeff))
+        g.wl_solution[:] = list(map(float, wl_solution))
+        g.psf_ratio_poly[:] = list(map(float, psf_ratio_poly))
+        g.psf_sigmal_poly[:] = list(map(float, psf_sigmal_poly))
+        g.psf_sigmah_poly[:] = list(map(float, psf_sigmah_poly))
+        wl, val = f64(sens_wl_um), f64(sens_val)
+        if wl.size != val.size:
+            raise ValueError("sensitivity table: wl and val differ in length")
+        g.n_sens = wl.size
+        g.sens_wl_um = ptr(wl, C.c_double)
+        g.sens_val = ptr(val, C.c_double)
+        g.flat_wmin, g.flat_wmax = float(flat_wmin), float(flat_wmax)
+        self.check(self._L.wayne_ctx_set_grism(self._h, C.byref(g)))
+
+    def set_calibration(self, subarray, n_reads, flat=None, pfl=None, sky=None, lin=None, dark_sci=None,
+                        dark_err=None, zero_read=None):
+        N = 1014 if subarray == 1024 else subarray
+        S = N + 10
+        k = Calibration()
+        k.subarray, k.n_reads = int(subarray), int(n_reads)
+        keep = []
+
+        def plane(a, shape, name, dt=np.float32):
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.shape != shape:
+                raise ValueError("%s: expected shape %s, got %s" % (name, shape, a.shape))
+            keep.append(a)
+            return a
+
+        if flat is not None:
+            for i in range(4):
+                k.flat[i] = ptr(plane(flat[i], (N, N), "flat[%d]" % i), C.c_float)
+        if pfl is not None:
+            k.pfl = ptr(plane(pfl, (N, N), "pfl"), C.c_float)
+        if sky is not None:
+            k.sky = ptr(plane(sky, (N, N), "sky"), C.c_float)
+        if lin is not None:
+            for i in range(4):
+                k.lin[i] = ptr(plane(lin[i], (S, S), "lin[%d]" % i), C.c_float)
+        if dark_sci is not None and dark_err is not None:
+            k.dark_sci = ptr(plane(dark_sci, (n_reads, S, S), "dark_sci"), C.c_float)
+            k.dark_err = ptr(plane(dark_err, (n_reads, S, S), "dark_err"), C.c_float)
+        if zero_read is not None:
+            k.zero_read = ptr(plane(zero_read, (S, S), "zero_read", np.float64), C.c_double)
+        self.check(self._L.wayne_ctx_set_calibration(self._h, C.byref(k)))
+        self.N, self.S, self.R = N, S, int(n_reads)
+
+    # -- exposures -------------------------------------------------------------
+    def make_desc(self, seed, exposure_index, flags, sub_scale, wl_um, flux, depth, x_ref, y_ref, dur_ms,
+                  sample_read, read_dt_s, replay_seed=None, rng_mode=RNG_PHILOX, threads_compat=1,
+                  sky_ct_s=0.0, cosmic_rate=-1.0, scale_factor=1.0, noise_mean=0.0, noise_std=0.0,
+                  thrower_margin=0, thrower_splits=0):
+        d = ExposureDesc()
+        keep = []
+
+        def arr(a, conv):
+            a = conv(a)
+            keep.append(a)
+            return a
+
+        wl_um, flux = arr(wl_um, f64), arr(flux, f64)
+        x_ref, y_ref, dur_ms = arr(x_ref, f64), arr(y_ref, f64), arr(dur_ms, f64)
+        sample_read, read_dt_s = arr(sample_read, i32), arr(read_dt_s, f64)
+        W, K = wl_um.size, x_ref.size
+        if flux.size != W or y_ref.size != K or dur_ms.size != K or sample_read.size != K:
+            raise ValueError("exposure descriptor: inconsistent array lengths")
+        d.seed, d.exposure_index = int(seed) & 0xFFFFFFFF, int(exposure_index) & 0xFFFFFFFF
+        d.rng_mode, d.threads_compat = int(rng_mode), int(threads_compat)
+        d.flags, d.sub_scale = int(flags), int(sub_scale)
+        d.n_wl, d.wl_um, d.flux = W, ptr(wl_um, C.c_double), ptr(flux, C.c_double)
+        if depth is not None:
+            depth = arr(depth, f64)
+            if depth.shape != (K, W):
+                raise ValueError("depth must have shape (K, W)")
+            d.depth = ptr(depth, C.c_double)
+        d.n_samples = K
+        d.x_ref, d.y_ref, d.dur_ms = ptr(x_ref, C.c_double), ptr(y_ref, C.c_double), ptr(dur_ms, C.c_double)
+        if replay_seed is not None:
+            replay_seed = arr(replay_seed, i32)
+            d.replay_seed = ptr(replay_seed, C.c_int32)
+        d.sample_read = ptr(sample_read, C.c_int32)
+        d.n_reads, d.read_dt_s = read_dt_s.size, ptr(read_dt_s, C.c_double)
+        d.sky_ct_s, d.cosmic_rate = float(sky_ct_s), float(cosmic_rate)
+        d.scale_factor, d.noise_mean, d.noise_std = float(scale_factor), float(noise_mean), float(noise_std)
+        d.thrower_margin, d.thrower_splits = int(thrower_margin), int(thrower_splits)
+        d._keep = keep
+        return d
+
+    def upload(self, slot, desc):
+        self.check(self._L.wayne_exposure_upload(self._h, int(slot), C.byref(desc)))
+        self._slot_meta = getattr(self, "_slot_meta", {})
+        self._slot_meta[slot] = (desc.n_samples, desc.n_wl, desc.n_reads, bool(desc.flags & F_OUT_F64))
+
+    def run(self, slot):
+        self.check(self._L.wayne_exposure_run(self._h, int(slot)))
+
+    def run_front(self, slot):
+        self.check(self._L.wayne_exposure_run_front(self._h, int(slot)))
+
+    def run_back(self, slot):
+        self.check(self._L.wayne_exposure_run_back(self._h, int(slot)))
+
+    def download(self, slot):
+        K, W, R, f64out = self._slot_meta[slot]
+        out = np.empty((R + 1, self.S, self.S), dtype=np.float64 if f64out else np.float32)
+        self.check(self._L.wayne_exposure_download(self._h, int(slot), ptr(out)))
+        return out
+
+    def synthesize(self, desc):
+        self.upload(0, desc)
+        self.run(0)
+        return self.download(0)
+
+    def debug_fetch(self, slot, acc=False):
+        K, W, R, _ = self._slot_meta[slot]
+        counts = np.empty((K, W), dtype=np.int32)
+        x = np.empty((K, W), dtype=np.float64)
+        y = np.empty((K, W), dtype=np.float64)
+        a = np.empty((R, self.S, self.S), dtype=np.float64) if acc else None
+        self.check(self._L.wayne_exposure_debug_fetch(self._h, int(slot), ptr(counts), ptr(x), ptr(y), ptr(a)))
+        return counts, x, y, a
+
+    # -- measurement -----------------------------------------------------------
+    def profile_enable(self, on=True):
+        self.check(self._L.wayne_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self.check(self._L.wayne_profile_reset(self._h))
+
+    def profile_get(self):
+        p = Profile()
+        self.check(self._L.wayne_profile_get(self._h, C.byref(p)))
+        out = {}
+        for i in range(PROF_KERNELS):
+            out[p.name[i].decode()] = {"launches": int(p.launches[i]), "ms": float(p.ms[i])}
+        out["electrons"] = int(p.electrons)
+        return out
+
+
+def device_count():
+    return load().wayne_device_count()
+
+
+def philox4x32(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    load().wayne_philox4x32(ptr(ctr), ptr(key), ptr(out))
+    return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,51 @@
+"""Build libwayne_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m wayne_amd.build          # build if stale
+    python -m wayne_amd.build --force
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the
+GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libwayne_hip.so")
+SOURCES = [os.path.join(CSRC, "wayne_hip.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("kernels.h", "philox.h", "samplers.h")] + [
+    os.path.join(ROOT, "include", "wayne_hip.h")]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # no fused multiply-adds the source does not spell out: the CPU oracle
+    # must see the same roundings (samplers.h)
+    "-ffp-contract=off",
+    "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=True):
+    if not force and not stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,715 @@
+// HIP kernels (gfx950) of the WFC3-IR exposure-synthesis path.
+//
+//   k_prep_wl      per-wavelength arrays: PSF polynomials, sensitivity LUT, bin widths   (A8, A9)
+//   k_prep_sub     per sub-sample: trace, bin positions, expected counts, Poisson/round,
+//                  sigma split, exclusive prefix of counts, LDS tile rectangle            (A6, A7, A9, A10)
+//   k_throw        the electron thrower: LDS int32 tile per (sub-sample, split),
+//                  flushed x flat into the read-interval accumulator                     (A1-A4, A11, A12)
+//   k_cosmic       cosmic-ray hits per read interval                                      (A13, cosmic_rays.py)
+//   k_ramp         fused up-the-ramp kernel: sky, gain, cumulative, dark, non-linearity,
+//                  clip, reference pixels, zero read, read noise                          (A13-A15)
+//
+// "A<n>" are the row ids of SURVEY.md section 8(a); reference file:line
+// citations are next to each formula.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "philox.h"
+#include "samplers.h"
+
+namespace wayne {
+
+constexpr int kBorder = 5;            // reference-pixel border (detector.py:146-147)
+constexpr double kQ = 1048576.0;      // accumulator fixed point: 2^20 per electron
+constexpr double kInvQ = 1.0 / 1048576.0;
+constexpr double kGain = 2.35;        // detector.py:30
+constexpr double kReadNoise = 14.1 / 2.35;  // detector.py:33
+constexpr double kMinCounts = -20.0;  // detector.py:26
+constexpr double kMaxCounts = 78000.0;  // detector.py:28
+constexpr double kPi = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------
+// shared device structs
+// ---------------------------------------------------------------------------
+struct GrismDev {
+  double trace[9], wlsol[9];
+  double p_ratio[4], p_sigl[4], p_sigh[4];
+  double flat_wmin, flat_wmax;
+  int n_sens;
+  const double* sens_wl;
+  const double* sens_val;
+};
+
+// Per sub-sample record written by k_prep_sub and read by k_throw.
+struct SubInfo {
+  uint32_t electrons;      // E_k
+  int tx0, ty0, tw, th;    // LDS tile rectangle, frame coordinates
+  int read;                // read interval this sub-sample accumulates into
+  int replay_seed;         // the reference's `test`
+  int pad_;
+  double x_ref, y_ref;     // star position of the sub-sample (full-frame coords)
+  double a_t_i, a_w, b_w;  // 1/m_t, m_w, c_w for the flat (grism.py:365-372)
+};
+
+struct WlArrays {   // all [W]
+  double* ratio;    // psf_ratio_poly(wl)   (fp64: the sigma split is done in fp64)
+  double* sigl;     // psf_sigmal_poly(wl)
+  double* sigh;     // psf_sigmah_poly(wl)
+  double* sens;     // np.interp(wl, throughput_wl, throughput_val)
+  double* dlam;     // tools.bin_centers_to_widths(wl)
+};
+
+__device__ __forceinline__ double poly3(const double* c, double x) {
+  // np.poly1d([c0,c1,c2,c3])(x): Horner, highest power first (grism.py:85-90,113-115)
+  return ((c[0] * x + c[1]) * x + c[2]) * x + c[3];
+}
+
+// ---------------------------------------------------------------------------
+// k_prep_wl : A8 + the wavelength-only part of A9
+// ---------------------------------------------------------------------------
+__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W) return;
+  const double x = wl[i];
+  o.ratio[i] = poly3(g.p_ratio, x);
+  o.sigl[i] = poly3(g.p_sigl, x);
+  o.sigh[i] = poly3(g.p_sigh, x);
+
+  // np.interp (grism.py:116-118): clamp outside the table, linear inside.
+  double s;
+  const int n = g.n_sens;
+  if (n <= 0) {
+    s = 1.0;
+  } else if (x <= g.sens_wl[0]) {
+    s = g.sens_val[0];
+  } else if (x >= g.sens_wl[n - 1]) {
+    s = g.sens_val[n - 1];
+  } else {
+    int lo = 0, hi = n - 1;  // sens_wl[lo] <= x < sens_wl[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (g.sens_wl[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double slope = (g.sens_val[lo + 1] - g.sens_val[lo]) / (g.sens_wl[lo + 1] - g.sens_wl[lo]);
+    s = slope * (x - g.sens_wl[lo]) + g.sens_val[lo];
+  }
+  o.sens[i] = s;
+
+  // tools.bin_centers_to_widths (tools.py:106-128): half-gaps to both
+  // neighbours; the end bins mirror their single neighbour.
+  double left, right;
+  if (W < 2) {
+    left = right = 0.0;
+  } else {
+    left = (i == 0) ? (wl[1] - wl[0]) / 2. : (wl[i] - wl[i - 1]) / 2.;
+    right = (i == W - 1) ? (wl[W - 1] - wl[W - 2]) / 2. : (wl[i + 1] - wl[i]) / 2.;
+  }
+  o.dlam[i] = left + right;
+}
+
+// ---------------------------------------------------------------------------
+// k_prep_sub : one workgroup per sub-sample
+// ---------------------------------------------------------------------------
+struct PrepArgs {
+  GrismDev g;
+  int W, K, N;               // bins, sub-samples, light-sensitive side
+  int sub_scale;             // 507 - SUBARRAY/2 (exposure_generator.py:630)
+  int margin;                // LDS tile margin (px)
+  int max_tile;              // LDS tile capacity (ints)
+  uint32_t seed, exposure;
+  uint32_t flags;
+  double scale_factor;
+  const double* wl;          // [W]
+  const double* flux;        // [W]
+  const double* depth;       // [K*W] or null
+  const double* x_ref;       // [K]
+  const double* y_ref;       // [K]
+  const double* dur_ms;      // [K]
+  const int32_t* replay_seed;  // [K]
+  const int32_t* sample_read;  // [K]
+  WlArrays wa;
+  // outputs
+  int32_t* counts;           // [K*W]
+  int32_t* nwide;            // [K*W]
+  uint32_t* prefix;          // [K*(W+1)] exclusive prefix of counts
+  double* xpos;              // [K*W] frame coords (x_sub)
+  double* ypos;              // [K*W]
+  SubInfo* sub;              // [K]
+  unsigned long long* total_electrons;  // += E_k
+  int* status;               // set non-zero on overflow
+};
+
+constexpr int kPrepThreads = 256;
+
+__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int W = a.W;
+  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
+  __shared__ uint32_t s_scan[kPrepThreads];
+  __shared__ double s_red[4][kPrepThreads / 64];
+  __shared__ uint32_t s_carry;
+
+  const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+  if (tid == 0) {
+    // wavelength_calibration_coeffs (grism.py:779-803)
+    const double* t = a.g.trace;
+    const double* b = a.g.wlsol;
+    const double m_t = t[3] + t[4] * x_ref + t[5] * y_ref + t[6] * (x_ref * x_ref) +
+                       t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);
+    const double c_t = t[0] + t[1] * x_ref + t[2] * y_ref;
+    const double m_w = b[3] + b[4] * x_ref + b[5] * y_ref + b[6] * (x_ref * x_ref) +
+                       b[7] * x_ref * y_ref + b[8] * (y_ref * y_ref);
+    const double c_w = (b[0] + b[1] * x_ref) + b[2] * y_ref;
+    // _get_x_to_wl_poly_coeffs (grism.py:553-602): line through the trace
+    // points at x_ref+10 and x_ref+20, wavelength in micron.
+    const double xa = x_ref + 10, xb = x_ref + 20;
+    const double ya = m_t * (xa - x_ref) + c_t + y_ref;  // x_to_y (grism.py:537)
+    const double yb = m_t * (xb - x_ref) + c_t + y_ref;
+    const double da = sqrt((ya - y_ref) * (ya - y_ref) + (xa - x_ref) * (xa - x_ref));
+    const double db = sqrt((yb - y_ref) * (yb - y_ref) + (xb - x_ref) * (xb - x_ref));
+    const double wa_ = (m_w * da + c_w) * 1e-4;  // angstrom -> micron
+    const double wb_ = (m_w * db + c_w) * 1e-4;
+    const double m_wl = (wb_ - wa_) / (xb - xa);
+    const double c_wl = wa_ - m_wl * xa;
+    s_tr[0] = m_t; s_tr[1] = c_t; s_tr[2] = m_w; s_tr[3] = c_w; s_tr[4] = m_wl; s_tr[5] = c_wl;
+    s_carry = 0;
+  }
+  __syncthreads();
+  const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
+  const double dur = a.dur_ms[k];
+  const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE
+
+  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  bool overflow = false;
+
+  // Chunks of kPrepThreads bins, in order, so the prefix is bin-major.
+  for (int base = 0; base < W; base += kPrepThreads) {
+    const int w = base + tid;
+    uint32_t c = 0;
+    if (w < W) {
+      const double wl = a.wl[w];
+      // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
+      // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
+      const double x = (wl - c_wl) / m_wl;
+      const double y = m_t * (x - x_ref) + c_t + y_ref;
+      const double xs = x - (double)a.sub_scale;
+      const double ys = y - (double)a.sub_scale;
+      a.xpos[(size_t)k * W + w] = xs;
+      a.ypos[(size_t)k * W + w] = ys;
+      // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
+      //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
+      double f = a.flux[w];
+      if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
+      double lam = f * a.wa.sens[w];
+      lam = lam * a.wa.dlam[w];
+      lam = lam * 1e4;
+      lam = lam * dur;
+      lam = lam * 1e-3;
+      lam = lam * a.scale_factor;
+      double cnt;
+      if (noisy) {
+        PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
+        cnt = poisson<double>(lam, rng);      // np.random.poisson (:626)
+      } else {
+        cnt = rint(lam);                      // np.round, half to even (:628)
+      }
+      if (!(cnt >= 0.)) cnt = 0.;             // negative / NaN flux throws no electrons
+      if (cnt > 2147483647.) { cnt = 2147483647.; overflow = true; }
+      c = (uint32_t)cnt;
+      a.counts[(size_t)k * W + w] = (int32_t)c;
+      // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
+      double nw = (double)(int32_t)c * a.wa.ratio[w];
+      int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
+      a.nwide[(size_t)k * W + w] = nwi;
+      if (c > 0) {
+        xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
+        ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
+      }
+    }
+    // block-wide exclusive scan of c (Hillis-Steele in LDS; W is small)
+    s_scan[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < kPrepThreads; off <<= 1) {
+      uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t incl = s_scan[tid];
+    const uint32_t carry = s_carry;
+    if (w < W) {
+      const uint64_t ex = (uint64_t)carry + incl - c;
+      if (ex + c > 0xFFFFFFFFull) overflow = true;
+      a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)ex;
+    }
+    __syncthreads();
+    if (tid == kPrepThreads - 1) s_carry = carry + incl;
+    __syncthreads();
+  }
+
+  // reduce the bounding box of populated bins
+  for (int off = 32; off > 0; off >>= 1) {
+    xmin = fmin(xmin, __shfl_down(xmin, off));
+    xmax = fmax(xmax, __shfl_down(xmax, off));
+    ymin = fmin(ymin, __shfl_down(ymin, off));
+    ymax = fmax(ymax, __shfl_down(ymax, off));
+  }
+  if ((tid & 63) == 0) {
+    s_red[0][tid >> 6] = xmin; s_red[1][tid >> 6] = xmax;
+    s_red[2][tid >> 6] = ymin; s_red[3][tid >> 6] = ymax;
+  }
+  if (overflow) atomicExch(a.status, 1);
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < kPrepThreads / 64; ++i) {
+      xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
+      ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
+    }
+    const uint32_t E = s_carry;
+    a.prefix[(size_t)k * (W + 1) + W] = E;
+    SubInfo si;
+    si.electrons = E;
+    si.read = a.sample_read[k];
+    si.replay_seed = a.replay_seed ? a.replay_seed[k] : 0;
+    si.pad_ = 0;
+    si.x_ref = x_ref; si.y_ref = y_ref;
+    si.a_t_i = 1. / m_t;            // grism.py:367
+    si.a_w = s_tr[2]; si.b_w = s_tr[3];
+    // LDS tile: bounding box of the populated trace + margin, clipped to the
+    // frame, shrunk symmetrically if it exceeds the LDS budget (electrons
+    // outside the tile take the global-atomic path, so this is speed only).
+    int tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    if (E > 0 && xmax >= xmin) {
+      int x0 = (int)floor(xmin) - a.margin, x1 = (int)floor(xmax) + a.margin + 1;
+      int y0 = (int)floor(ymin) - a.margin, y1 = (int)floor(ymax) + a.margin + 1;
+      x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, a.N); y1 = min(y1, a.N);
+      if (x1 > x0 && y1 > y0) {
+        tw = x1 - x0; th = y1 - y0;
+        while ((long long)tw * th > a.max_tile && th > 1) { y0 += 1; th -= 2; if (th < 1) th = 1; }
+        while ((long long)tw * th > a.max_tile && tw > 1) { x0 += 1; tw -= 2; if (tw < 1) tw = 1; }
+        tx0 = x0; ty0 = y0;
+      }
+    }
+    si.tx0 = tx0; si.ty0 = ty0; si.tw = tw; si.th = th;
+    a.sub[k] = si;
+    atomicAdd(a.total_electrons, (unsigned long long)E);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_throw : the electron thrower
+// ---------------------------------------------------------------------------
+// Electrons of sub-sample k are numbered bin-major exactly as the reference
+// numbers them (pyparallel_menu.c:87-108).  The E_k electrons are cut into
+// splits*T equal contiguous "slots"; workgroup (k, s) takes the slots
+// j*splits + s, its lane l / wave v takes j = l*(T/64) + v, so the 64 lanes
+// of a wave sit ~E_k/64 electrons apart, i.e. spread over the whole trace:
+// their LDS atomics rarely collide in a bank or on a pixel.  Each lane walks
+// its slot sequentially and re-loads bin parameters only when it crosses a
+// bin boundary (about once per counts[b] electrons).
+//
+// RNG_MODE 0 (replay): electron i belongs to the emulated OpenMP thread t with
+//   t*ssum/T <= i < (t+1)*ssum/T, stream seed 25234 + 17 t + test, and uses
+//   rand_r calls 2(i - start_t) and 2(i - start_t)+1 of that stream; the LCG
+//   state is reached by an O(log n) affine jump (pyparallel_menu.c:47-61).
+//   fp64 Box-Muller, fp64 positions -> bit-exact frames.
+// RNG_MODE 1 (Philox): electrons 2q, 2q+1 use words {0,1}, {2,3} of Philox
+//   counter (q, k, exposure), stage STAGE_THROW; fp32 Box-Muller on the
+//   hardware sin/cos/log2 units.
+//
+// FLUSH 0: add the int32 tile into an int32 frame (wayne_psf_apply).
+// FLUSH 1: multiply by the wavelength-dependent flat of THIS sub-sample
+//   (grism.py:349-409; applied where the frame is > 0, exposure_generator.py
+//   :641-645) and add round(n * flat * 2^20) into the int64 accumulator of the
+//   sub-sample's read interval, at the bordered position (y+5, x+5)
+//   (detector.py:146-147).  Integer atomics commute, so the result is
+//   bit-reproducible for any launch geometry.
+constexpr int kThrowThreads = 512;
+
+struct ThrowArgs {
+  int W, K, N, S;          // bins, sub-samples, frame side, bordered side
+  int splits;
+  int threads_compat;      // replay: emulated OpenMP team size
+  uint32_t seed, exposure, subsample0;
+  uint32_t flags;
+  int flat_off;            // (1014 - N) / 2  (grism.py:363)
+  double flat_wmin, flat_wmax;
+  const SubInfo* sub;      // [K]
+  const uint32_t* prefix;  // [K*(W+1)]
+  const int32_t* nwide;    // [K*W]
+  const double* xpos;      // [K*W]
+  const double* ypos;      // [K*W]
+  const double* sigl;      // [W]
+  const double* sigh;      // [W]
+  const float* flat[4];    // N*N each or null
+  long long* acc;          // FLUSH 1: [R*S*S]
+  int32_t* frame;          // FLUSH 0: [N*N]
+};
+
+struct Affine { uint32_t a, c; };  // x -> a*x + c (mod 2^32)
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t state, uint64_t n) {
+  // n steps of next = next*1103515245 + 12345 by square-and-multiply
+  uint32_t a = 1103515245u, c = 12345u;   // current power of the map
+  uint32_t ra = 1u, rc = 0u;               // accumulated map
+  while (n) {
+    if (n & 1ull) { ra = ra * a; rc = rc * a + c; }
+    c = c * a + c;  // (a,c) o (a,c) = (a*a, a*c + c)
+    a = a * a;
+    n >>= 1;
+  }
+  return ra * state + rc;
+}
+__device__ __forceinline__ int rand_r_step(uint32_t& s) {
+  // glibc rand_r: 11 + 10 + 10 bits of three LCG steps
+  uint32_t r;
+  s = s * 1103515245u + 12345u; r = (s >> 16) & 2047u;
+  s = s * 1103515245u + 12345u; r = (r << 10) ^ ((s >> 16) & 1023u);
+  s = s * 1103515245u + 12345u; r = (r << 10) ^ ((s >> 16) & 1023u);
+  return (int)r;
+}
+
+__device__ __forceinline__ double flat_value(const ThrowArgs& a, const SubInfo& si, int x, int y) {
+  // grism.py:362-385, evaluated for frame pixel (y, x)
+  const int xf = x + a.flat_off, yf = y + a.flat_off;
+  const double arr = si.y_ref - (double)yf + si.a_t_i * si.x_ref - si.a_t_i * (double)xf;
+  const double d = sqrt((arr * arr) / (si.a_t_i * si.a_t_i + 1));
+  const double wl = si.a_w * d + si.b_w;
+  const double t = (wl - a.flat_wmin) / (a.flat_wmax - a.flat_wmin);
+  const double t2 = t * t, t3 = t2 * t;
+  const size_t i = (size_t)y * a.N + x;
+  const double f = (double)a.flat[0][i] + ((double)a.flat[1][i] * t) + ((double)a.flat[2][i] * t2) +
+                   ((double)a.flat[3][i] * t3);
+  // flatfield = np.ones_like(self.flat_f0) is float32, so the assignment
+  // rounds the polynomial to float32 (grism.py:380-385)
+  return (double)(float)f;
+}
+
+template <int FLUSH>
+__device__ __forceinline__ void deposit_global(const ThrowArgs& a, const SubInfo& si, int x, int y, int n) {
+  if (FLUSH == 0) {
+    atomicAdd(&a.frame[(size_t)y * a.N + x], n);
+  } else {
+    double v = (double)n;
+    if ((a.flags & 1u) && a.flat[0]) v = v * flat_value(a, si, x, y);  // WAYNE_F_ADD_FLAT
+    const long long q = __double2ll_rn(v * kQ);
+    atomicAdd((unsigned long long*)&a.acc[((size_t)si.read * a.S + (y + kBorder)) * a.S + (x + kBorder)],
+              (unsigned long long)q);
+  }
+}
+
+template <int RNG_MODE, int FLUSH>
+__global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
+  extern __shared__ int tile[];
+  // XCD-aware block -> (sub-sample, split): blocks b and b+8 share an XCD
+  // (and its L2); keep all splits of a sub-sample, which read the same
+  // prefix / bin arrays and flush to the same frame region, on one XCD.
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int k = (local / a.splits) * 8 + xcd;
+  const int s = local % a.splits;
+  if (k >= a.K) return;
+  const SubInfo si = a.sub[k];
+  const uint32_t E = si.electrons;
+  if (E == 0) return;
+  const int W = a.W;
+  const int tid = threadIdx.x;
+  const int tw = si.tw, th = si.th, tx0 = si.tx0, ty0 = si.ty0;
+  const int tarea = tw * th;
+  for (int i = tid; i < tarea; i += kThrowThreads) tile[i] = 0;
+  __syncthreads();
+
+  const uint32_t* P = a.prefix + (size_t)k * (W + 1);
+  const int32_t* NW = a.nwide + (size_t)k * W;
+  const double* XP = a.xpos + (size_t)k * W;
+  const double* YP = a.ypos + (size_t)k * W;
+
+  constexpr uint32_t UNIT = (RNG_MODE == 1) ? 2u : 1u;  // electrons per work unit
+  const uint64_t n_units = ((uint64_t)E + UNIT - 1) / UNIT;
+  const uint64_t n_slots = (uint64_t)a.splits * kThrowThreads;
+  const uint64_t L = (n_units + n_slots - 1) / n_slots;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint64_t slot = ((uint64_t)lane * (kThrowThreads / 64) + wave) * a.splits + s;
+  uint64_t u = slot * L;
+  uint64_t u_end = u + L;
+  if (u_end > n_units) u_end = n_units;
+
+  if (u < u_end) {
+    uint32_t e = (uint32_t)(u * UNIT);
+    // bin b with P[b] <= e < P[b+1]
+    int lo = 0, hi = W;  // invariant: P[lo] <= e < P[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (P[mid] <= e) lo = mid; else hi = mid;
+    }
+    int b = lo;
+    uint32_t bin_start = P[b], bin_end = P[b + 1];
+    while (bin_end <= e && b + 1 < W) { ++b; bin_start = bin_end; bin_end = P[b + 1]; }
+    uint32_t wide_end = bin_start + (uint32_t)max(NW[b], 0);
+
+    // --- replay-mode state
+    uint32_t lcg = 0;
+    uint32_t part_end = 0;   // first electron of the next emulated thread
+    int part = 0;
+    const int T = a.threads_compat;
+    auto part_start_of = [&](int t) -> uint32_t { return (uint32_t)(((long long)t * (long long)E) / T); };
+    if (RNG_MODE == 0) {
+      // thread t owns [t*E/T, (t+1)*E/T); the last one ends at E (:48-49)
+      part = (int)(((unsigned long long)e * (unsigned long long)T) / E);
+      if (part >= T) part = T - 1;
+      while (part > 0 && part_start_of(part) > e) --part;
+      while (part + 1 < T && part_start_of(part + 1) <= e) ++part;
+      const uint32_t ps = part_start_of(part);
+      part_end = (part == T - 1) ? E : part_start_of(part + 1);
+      lcg = lcg_jump((uint32_t)(25234 + 17 * part + si.replay_seed), 6ull * (uint64_t)(e - ps));
+    }
+
+    if (RNG_MODE == 1) {
+      float x = (float)XP[b], y = (float)YP[b];
+      float sl = (float)a.sigl[b], sh = (float)a.sigh[b];
+      for (; u < u_end; ++u) {
+        const u32x4 r = philox4x32_10((uint32_t)u, (uint32_t)(u >> 32), (uint32_t)k + a.subsample0,
+                                      a.exposure, a.seed, STAGE_THROW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (e >= E) break;
+          if (e >= bin_end) {
+            do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
+            wide_end = bin_start + (uint32_t)max(NW[b], 0);
+            x = (float)XP[b]; y = (float)YP[b];
+            sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
+          }
+          const float ua = u01f(h == 0 ? r.v[0] : r.v[2]);
+          const float ub = u01f(h == 0 ? r.v[1] : r.v[3]);
+          // R = sqrt(-2 ln ub) = sqrt(-2 ln2 log2 ub); sin/cos take revolutions
+          const float R = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
+          const float zx = R * __builtin_amdgcn_cosf(ua);
+          const float zy = R * __builtin_amdgcn_sinf(ua);
+          const float sig = (e < wide_end) ? sh : sl;   // first N electrons: wide gaussian (:89-98)
+          const int xi = (int)fmaf(zx, sig, x);          // C truncation toward zero (:91-92)
+          const int yi = (int)fmaf(zy, sig, y);
+          if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) {   // (:93)
+            const int lx = xi - tx0, ly = yi - ty0;
+            if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+              atomicAdd(&tile[ly * tw + lx], 1);
+            else
+              deposit_global<FLUSH>(a, si, xi, yi, 1);
+          }
+          ++e;
+        }
+      }
+    } else {
+      double x = XP[b], y = YP[b];
+      double sl = a.sigl[b], sh = a.sigh[b];
+      for (; u < u_end; ++u, ++e) {
+        if (e >= bin_end) {
+          do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
+          wide_end = bin_start + (uint32_t)max(NW[b], 0);
+          x = XP[b]; y = YP[b]; sl = a.sigl[b]; sh = a.sigh[b];
+        }
+        if (e >= part_end) {
+          ++part;
+          part_end = (part == T - 1) ? E : part_start_of(part + 1);
+          lcg = (uint32_t)(25234 + 17 * part + si.replay_seed);
+        }
+        // pyparallel_menu.c:57-61
+        const double theta = 2. * kPi * rand_r_step(lcg) / ((double)2147483647);
+        const double R = sqrt(-2. * log(rand_r_step(lcg) / ((double)2147483647)));
+        const double zx = R * cos(theta);
+        const double zy = R * sin(theta);
+        const double sig = (e < wide_end) ? sh : sl;
+        const double px = zx * sig + x, py = zy * sig + y;
+        // (int) of a non-finite / out-of-range double: reject (x86 gives INT_MIN)
+        const bool okx = (px > -2147483649.0 && px < 2147483648.0);
+        const bool oky = (py > -2147483649.0 && py < 2147483648.0);
+        const int xi = okx ? (int)px : -1, yi = oky ? (int)py : -1;
+        if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) {
+          const int lx = xi - tx0, ly = yi - ty0;
+          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+            atomicAdd(&tile[ly * tw + lx], 1);
+          else
+            deposit_global<FLUSH>(a, si, xi, yi, 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush the tile
+  for (int i = tid; i < tarea; i += kThrowThreads) {
+    const int n = tile[i];
+    if (n > 0) {
+      const int ly = i / tw, lx = i - ly * tw;
+      deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, n);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_cosmic : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
+// ---------------------------------------------------------------------------
+struct CosmicArgs {
+  int R, N, S;
+  uint32_t seed, exposure;
+  double rate;               // hits per second per 1024^2 pixels
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S]
+};
+
+__global__ __launch_bounds__(256) void k_cosmic(CosmicArgs a) {
+  const int r = blockIdx.x;
+  if (r >= a.R) return;
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) {
+    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
+    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
+    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
+    double n = poisson<double>(rate_size * a.read_dt[r], rng);
+    if (!(n >= 0.)) n = 0.;
+    if (n > 1e7) n = 1e7;
+    s_n = (uint32_t)n;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
+    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
+    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
+    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
+    const long long q = (long long)energy << 20;
+    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
+              (unsigned long long)q);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_ramp : fused up-the-ramp kernel, one thread per bordered pixel
+// ---------------------------------------------------------------------------
+struct RampArgs {
+  int R, N, S;
+  uint32_t seed, exposure, flags;
+  double sky_ct_s;           // <= 0: no sky
+  double noise_mean, noise_std;
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S] read and cleared
+  const float* pfl;          // [S*S] (bordered layout; border unused) or null
+  const float* sky;          // [S*S] or null
+  const float* lin[4];       // [S*S] or null
+  const float* dark_sci;     // [R*S*S] or null
+  const float* dark_err;
+  const double* zero_read;   // [S*S] or null
+  void* out;                 // [(R+1)*S*S] float or double
+};
+
+__device__ __forceinline__ void normal_pair(uint32_t seed, uint32_t stage, uint32_t p, uint32_t r,
+                                            uint32_t exposure, float& z0, float& z1) {
+  const u32x4 w = philox4x32_10(p, 0u, r, exposure, seed, stage);
+  const float ua = u01f(w.v[0]), ub = u01f(w.v[1]);
+  const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
+  z0 = Rr * __builtin_amdgcn_cosf(ua);
+  z1 = Rr * __builtin_amdgcn_sinf(ua);
+}
+
+__device__ __forceinline__ double nonlinear_response(double px, float c1, float c2, float c3, float c4) {
+  // WFC3_IR.apply_non_linearity (detector.py:335-348): Newton-Raphson on
+  // u (1 + c1 + u (c2 + u (c3 + c4 u))) = px from u0 = px, until |du| < 1e-3.
+  // The reference iterates the whole frame until its slowest pixel converges;
+  // here each pixel stops on its own criterion (the extra iterations move a
+  // converged pixel by < 1e-9).  (1 + c1), 2*c2, 3*c3, 4*c4 are float32 in
+  // the reference because the coefficient planes are.
+  const double k1 = (double)(1.0f + c1);
+  const double k2 = (double)c2, k3 = (double)c3, k4 = (double)c4;
+  const double d2 = (double)(2.0f * c2), d3 = (double)(3.0f * c3), d4 = (double)(4.0f * c4);
+  double u0 = px, u1 = px;
+  for (int it = 0; it < 10000; ++it) {
+    const double f = -px + u0 * (k1 + u0 * (k2 + u0 * (k3 + k4 * u0)));
+    const double fp_ = k1 + d2 * u0 + d3 * u0 * u0 + d4 * u0 * u0 * u0;
+    u1 = u0 - f / fp_;
+    if (fabs(u1 - u0) < 1e-3) break;
+    u0 = u1;
+  }
+  return u1;
+}
+
+template <class OutT>
+__global__ __launch_bounds__(256) void k_ramp(RampArgs a) {
+  const int S = a.S;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S * S) return;
+  const int Y = p / S, X = p - Y * S;
+  const bool interior = (X >= kBorder && X < S - kBorder && Y >= kBorder && Y < S - kBorder);
+  const size_t SS = (size_t)S * S;
+  OutT* out = (OutT*)a.out;
+  const bool clip = (a.flags & (1u << 3)) != 0;
+  const bool rdn = (a.flags & (1u << 4)) != 0;
+  const bool do_dark = (a.flags & (1u << 6)) != 0 && a.dark_sci && a.dark_err;
+  const bool do_lin = (a.flags & (1u << 2)) != 0 && a.lin[0];
+  const bool gainvar = (a.flags & (1u << 1)) != 0 && a.pfl;
+  const bool do_noise = (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
+
+  // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
+  // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
+  double z = (a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
+  if (clip) z = fmin(fmax(z, kMinCounts), kMaxCounts);
+  if (!interior) z = 0.;
+  {
+    float zd, zr;
+    double v = z;
+    if (rdn) { normal_pair(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure, zd, zr); v = v + kReadNoise * (double)zr; }
+    out[p] = (OutT)v;
+  }
+
+  // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
+  // (detector.py:203-204), or the constant (exposure_generator.py:507-511)
+  double g = kGain;
+  float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  float skyv = 0;
+  if (interior) {
+    if (gainvar) g = (double)(2.35f / a.pfl[p]);
+    if (a.sky_ct_s > 0. && a.sky) skyv = a.sky[p];
+  }
+  if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
+
+  double cum = 0.;
+  for (int r = 0; r < a.R; ++r) {
+    double px = 0.;
+    if (interior) {
+      long long* ap = &a.acc[(size_t)r * SS + p];
+      const long long q = *ap;
+      *ap = 0;                       // leave the accumulator clean for the next exposure
+      px = (double)q * kInvQ;
+      const double dt = a.read_dt[r];
+      if (do_noise) {                // _gen_noise (:477-484, :712-727)
+        float z0, z1;
+        normal_pair(a.seed, STAGE_NOISE, (uint32_t)p, (uint32_t)r, a.exposure, z0, z1);
+        px = px + (a.noise_mean * dt + (a.noise_std * dt) * (double)z0);
+      }
+      if (skyv > 0.f) {
+        // master_sky *= bg_count is an in-place float32 multiply (:493)
+        const float lam = skyv * (float)(a.sky_ct_s * dt);
+        PhiloxStream rng(a.seed, STAGE_SKY, (uint32_t)p, (uint32_t)r, a.exposure);
+        const double ns = (lam < 256.f) ? (double)poisson<float>(lam, rng) : poisson<double>((double)lam, rng);
+        px = px + ns;                // (:495)
+      }
+      px = px / g;                   // electrons -> DN (:507-511)
+    }
+    cum = cum + px;                  // cumulative_pixel_array += pixel_array_full (:378)
+    double v = cum;
+    float zd = 0.f, zr = 0.f;
+    if (rdn || do_dark) normal_pair(a.seed, STAGE_READ, (uint32_t)p, (uint32_t)(r + 1), a.exposure, zd, zr);
+    if (interior) {
+      if (do_dark) {                 // detector.py:185-191
+        const float de = a.dark_err[(size_t)r * SS + p];
+        const double err = (de > 0.f) ? (double)de : 0.00001;
+        v = v + ((double)a.dark_sci[(size_t)r * SS + p] + err * (double)zd);
+      }
+      if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4);
+      if (clip) v = fmin(fmax(v, kMinCounts), kMaxCounts);
+    } else {
+      v = 0.;                        // reset_reference_pixels (exposure.py:122-131)
+    }
+    v = v + z;                       // add_zero_read (exposure.py:94-104)
+    if (rdn) v = v + kReadNoise * (double)zr;   // add_read_noise (detector.py:193-198)
+    out[(size_t)(r + 1) * SS + p] = (OutT)v;
+  }
+}
+
+}  // namespace wayne

@@ -1,0 +1,85 @@
+// Philox4x32-10 counter-based RNG and the uniform / normal transforms built
+// on it.  Replaces the reference's order-dependent numpy MT19937 stream
+// (reference: wayne/run_visit.py:68-77, exposure_generator.py:327-329,495,626,
+// detector.py:191,198, cosmic_rays.py:80-81,127,134) and its per-thread
+// rand_r streams (pyparallel_menu.c:52-58) with draws that are a pure function
+// of (seed, stage, exposure, sub-sample | read, element), so results do not
+// depend on how exposures are sharded over GPUs or on launch geometry.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define WAYNE_HD __host__ __device__ __forceinline__
+#else
+#define WAYNE_HD inline
+#endif
+
+namespace wayne {
+
+// RNG stages: key = (seed, stage); counter = (c0, c1, c2, c3) as commented.
+enum Stage : uint32_t {
+  STAGE_COUNTS = 1,   // (bin w, draw block, sub-sample k, exposure)  stellar Poisson
+  STAGE_THROW = 2,    // (pair lo, pair hi, sub-sample k, exposure)   electron thrower
+  STAGE_SKY = 3,      // (pixel, draw block, read r, exposure)        sky Poisson
+  STAGE_CR_COUNT = 4, // (0, draw block, read r, exposure)            number of cosmic hits
+  STAGE_CR_HIT = 5,   // (hit i, 0, read r, exposure)                 energy, y, x of hit i
+  STAGE_READ = 6,     // (pixel, 0, read r, exposure)                 dark + read-noise normals
+  STAGE_NOISE = 7,    // (pixel, 0, read r, exposure)                 optional gaussian noise
+  STAGE_HOST = 8,     // (sub-sample k, 0, 0, exposure)               jitter x/y, replay seed
+};
+
+struct u32x4 {
+  uint32_t v[4];
+};
+
+WAYNE_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                             uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  u32x4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// uint32 -> uniform in (0, 1]: (x + 0.5) * 2^-32 in fp32 / fp64.
+WAYNE_HD float u01f(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
+WAYNE_HD double u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+
+// uniform integer in [0, n) by multiply-shift (bias <= n / 2^32).
+WAYNE_HD uint32_t uint_below(uint32_t x, uint32_t n) {
+  return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32);
+}
+
+// A sequential reader of one Philox stream: counter (c0, block, c2, c3) with
+// the block index advancing every four words.
+struct PhiloxStream {
+  uint32_t c0, c2, c3, k0, k1, block, have;
+  u32x4 buf;
+  WAYNE_HD PhiloxStream(uint32_t seed, uint32_t stage, uint32_t c0_, uint32_t c2_,
+                        uint32_t c3_)
+      : c0(c0_), c2(c2_), c3(c3_), k0(seed), k1(stage), block(0), have(0) {}
+  WAYNE_HD uint32_t next() {
+    if (have == 0) {
+      buf = philox4x32_10(c0, block, c2, c3, k0, k1);
+      ++block;
+      have = 4;
+    }
+    // words are consumed in order 0,1,2,3 (static indexing keeps buf in VGPRs)
+    const uint32_t i = 4 - have;
+    --have;
+    return i == 0 ? buf.v[0] : i == 1 ? buf.v[1] : i == 2 ? buf.v[2] : buf.v[3];
+  }
+};
+
+}  // namespace wayne

@@ -1,0 +1,751 @@
+// libwayne_hip.so -- C ABI (include/wayne_hip.h) over the gfx950 kernels.
+// Host side: context, HBM buffers, launch sequence, HIP-event profiling.
+#include "../../include/wayne_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace wayne;
+
+namespace {
+
+enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_OTHER };
+const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub", "k_throw",
+                                                    "k_cosmic",  "k_ramp",     "other"};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct Slot {
+  bool uploaded = false;
+  bool front_done = false;
+  bool acc_dirty = false;
+  bool acc_init = false;
+  wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
+  int W = 0, K = 0, R = 0;
+  bool has_depth = false, has_replay_seed = false;
+  DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt;
+  DevBuf ratio, sigl, sigh, sens, dlam;
+  DevBuf counts, nwide, prefix, xpos, ypos, sub;
+  DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
+  void release() {
+    for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &ratio, &sigl,
+                      &sigh, &sens, &dlam, &counts, &nwide, &prefix, &xpos, &ypos, &sub, &acc, &out,
+                      &misc})
+      b->release();
+  }
+};
+
+struct ProfRec {
+  int kernel;
+  hipEvent_t a, b;
+};
+
+constexpr int kSlots = 2;
+
+}  // namespace
+
+struct wayne_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // grism
+  bool have_grism = false;
+  GrismDev g{};
+  DevBuf sens_wl, sens_val;
+  // calibration
+  bool have_cal = false;
+  int subarray = 0, N = 0, S = 0, cal_R = 0;
+  DevBuf flat[4], pfl, sky, lin[4], dark_sci, dark_err, zero_read;
+  bool has_flat = false, has_pfl = false, has_sky = false, has_lin = false, has_dark = false,
+       has_zero = false;
+  Slot slots[kSlots];
+  // psf_apply scratch
+  DevBuf pa_prefix, pa_nwide, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  uint64_t prof_launches[WAYNE_PROF_KERNELS] = {0};
+  double prof_ms[WAYNE_PROF_KERNELS] = {0};
+  uint64_t electrons = 0;  // thrown through wayne_psf_apply (host-counted)
+  DevBuf counters;         // [0] u64: electrons thrown by exposures (device-counted)
+};
+
+namespace {
+
+int fail(wayne_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail((ctx), WAYNE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+  } while (0)
+
+hipEvent_t get_event(wayne_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct ProfScope {
+  wayne_ctx* c;
+  ProfRec rec{};
+  bool on;
+  ProfScope(wayne_ctx* c_, int kernel) : c(c_), on(c_->prof_on) {
+    if (!on) return;
+    rec.kernel = kernel;
+    rec.a = get_event(c);
+    rec.b = get_event(c);
+    if (!rec.a || !rec.b) { on = false; return; }
+    (void)hipEventRecord(rec.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, c->stream);
+    c->prof.push_back(rec);
+  }
+};
+
+int collect_profile(wayne_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (ProfRec& r : c->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_ms[r.kernel] += ms;
+      c->prof_launches[r.kernel] += 1;
+    }
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->prof.clear();
+  return WAYNE_OK;
+}
+
+template <class T>
+int upload(wayne_ctx* c, DevBuf& b, const T* src, size_t n) {
+  HIP_TRY(c, b.reserve(std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return WAYNE_OK;
+}
+
+int side_of(int subarray) { return subarray == 1024 ? 1014 : subarray; }  // detector.py:116-119
+
+// N*N plane -> S*S bordered layout (value `fill` on the 5-px border)
+std::vector<float> embed(const float* src, int N, int S, float fill) {
+  std::vector<float> v((size_t)S * S, fill);
+  for (int y = 0; y < N; ++y)
+    std::memcpy(&v[(size_t)(y + kBorder) * S + kBorder], src + (size_t)y * N, (size_t)N * sizeof(float));
+  return v;
+}
+
+int thrower_lds_ints(const wayne_ctx*) {
+  const char* e = std::getenv("WAYNE_TILE_INTS");
+  int v = e ? std::atoi(e) : 12288;  // 48 KiB: three 512-thread workgroups per CU
+  return std::min(std::max(v, 256), 16000);
+}
+
+template <int RNG, int FLUSH>
+int launch_throw(wayne_ctx* c, const ThrowArgs& a, int lds_ints) {
+  const int groups = (a.K + 7) / 8;
+  const dim3 grid((unsigned)(groups * 8 * a.splits));
+  const size_t lds = (size_t)lds_ints * sizeof(int);
+  HIP_TRY(c, hipFuncSetAttribute((const void*)k_throw<RNG, FLUSH>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_throw<RNG, FLUSH>), grid, dim3(kThrowThreads), lds, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return WAYNE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wayne_abi_version(void) { return WAYNE_ABI_VERSION; }
+
+const char* wayne_strerror(int s) {
+  switch (s) {
+    case WAYNE_OK: return "ok";
+    case WAYNE_E_INVALID: return "invalid argument";
+    case WAYNE_E_NEGATIVE: return "negative electron count";
+    case WAYNE_E_OVERFLOW: return "electron count overflows the reference's int arithmetic";
+    case WAYNE_E_NOMEM: return "out of memory";
+    case WAYNE_E_HIP: return "HIP runtime error";
+    case WAYNE_E_NODEVICE: return "no gfx950 device";
+    case WAYNE_E_STATE: return "grism / calibration / upload missing";
+    default: return "unknown status";
+  }
+}
+
+int wayne_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+wayne_ctx* wayne_ctx_create(int device, int* status) {
+  auto set = [&](int s) { if (status) *status = s; };
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+    set(WAYNE_E_NODEVICE);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { set(WAYNE_E_HIP); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set(WAYNE_E_HIP); return nullptr; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    // the code object holds gfx950 ISA only; there is no other path
+    set(WAYNE_E_NODEVICE);
+    return nullptr;
+  }
+  wayne_ctx* c = new (std::nothrow) wayne_ctx();
+  if (!c) { set(WAYNE_E_NOMEM); return nullptr; }
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    set(WAYNE_E_HIP);
+    return nullptr;
+  }
+  if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    set(WAYNE_E_NOMEM);
+    return nullptr;
+  }
+  set(WAYNE_OK);
+  return c;
+}
+
+void wayne_ctx_destroy(wayne_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (Slot& s : c->slots) s.release();
+  for (DevBuf* b : {&c->counters, &c->sens_wl, &c->sens_val, &c->pfl, &c->sky, &c->dark_sci, &c->dark_err, &c->zero_read,
+                    &c->pa_prefix, &c->pa_nwide, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
+                    &c->pa_frame})
+    b->release();
+  for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* wayne_last_error(const wayne_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int wayne_ctx_synchronize(wayne_ctx* c) {
+  if (!c) return WAYNE_E_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WAYNE_OK;
+}
+
+void* wayne_ctx_stream(wayne_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int wayne_ctx_slots(const wayne_ctx*) { return kSlots; }
+
+// ---------------------------------------------------------------------------
+// wayne_psf_apply
+// ---------------------------------------------------------------------------
+int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double* x_pos,
+                    const double* y_pos, const double* psf_ratio, const double* psf_sigmal,
+                    const double* psf_sigmah, int nr, int nc, uint32_t seed, int threads_compat,
+                    int rng_mode, uint32_t exposure, uint32_t subsample, int32_t* out) {
+  if (!c) return WAYNE_E_INVALID;
+  if (size < 0 || nr <= 0 || nc <= 0 || !out) return fail(c, WAYNE_E_INVALID, "psf_apply: bad size / frame");
+  if (nr != nc)
+    return fail(c, WAYNE_E_INVALID,
+                "psf_apply: only square frames (the reference indexes ypos*nc+xpos but bounds xpos by nr)");
+  if (size > 0 && (!counts || !x_pos || !y_pos || !psf_ratio || !psf_sigmal || !psf_sigmah))
+    return fail(c, WAYNE_E_INVALID, "psf_apply: null input");
+  if (rng_mode != WAYNE_RNG_REPLAY && rng_mode != WAYNE_RNG_PHILOX)
+    return fail(c, WAYNE_E_INVALID, "psf_apply: rng_mode");
+  if (rng_mode == WAYNE_RNG_REPLAY && threads_compat <= 0)
+    return fail(c, WAYNE_E_INVALID, "psf_apply: threads_compat must be >= 1 in replay mode");
+  const int N = nr;
+  (void)hipSetDevice(c->device);
+
+  // A1: ssum, with the reference's silent int overflows turned into errors
+  long long total = 0;
+  for (int i = 0; i < size; ++i) {
+    if (counts[i] < 0) return fail(c, WAYNE_E_NEGATIVE, "psf_apply: negative count");
+    total += counts[i];
+  }
+  if (rng_mode == WAYNE_RNG_REPLAY && total * (long long)threads_compat > 2147483647LL)
+    return fail(c, WAYNE_E_OVERFLOW, "psf_apply: sum(counts)*threads >= 2^31 (pyparallel_menu.c:12,48)");
+  if (total > 0xFFFFFFFFLL) return fail(c, WAYNE_E_OVERFLOW, "psf_apply: more than 2^32-1 electrons");
+
+  HIP_TRY(c, c->pa_frame.reserve((size_t)N * N * sizeof(int32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->pa_frame.p, 0, (size_t)N * N * sizeof(int32_t), c->stream));  // A3
+
+  if (total > 0) {
+    std::vector<uint32_t> prefix((size_t)size + 1);
+    std::vector<int32_t> nwide((size_t)size);
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    uint32_t run = 0;
+    for (int i = 0; i < size; ++i) {
+      prefix[i] = run;
+      run += (uint32_t)counts[i];
+      const double nw = (double)counts[i] * psf_ratio[i];  // N = counts*ratio (:89)
+      nwide[i] = (nw >= 2147483647.) ? 2147483647
+                 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1)
+                 : (!(nw == nw))        ? (int32_t)(-2147483647 - 1)
+                                        : (int32_t)nw;
+      if (counts[i] > 0 && std::isfinite(x_pos[i]) && std::isfinite(y_pos[i])) {
+        xmin = std::min(xmin, x_pos[i]); xmax = std::max(xmax, x_pos[i]);
+        ymin = std::min(ymin, y_pos[i]); ymax = std::max(ymax, y_pos[i]);
+      }
+    }
+    prefix[size] = run;
+    const int lds_ints = thrower_lds_ints(c);
+    SubInfo si{};
+    si.electrons = run;
+    si.read = 0;
+    si.replay_seed = (int)seed;
+    const int margin = 20;
+    if (xmax >= xmin) {
+      auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
+      int x0 = std::max(clampi(std::floor(xmin)) - margin, 0), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
+      int y0 = std::max(clampi(std::floor(ymin)) - margin, 0), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
+      if (x1 > x0 && y1 > y0) {
+        int tw = x1 - x0, th = y1 - y0;
+        while ((long long)tw * th > lds_ints && th > 1) { y0 += 1; th = std::max(th - 2, 1); }
+        while ((long long)tw * th > lds_ints && tw > 1) { x0 += 1; tw = std::max(tw - 2, 1); }
+        si.tx0 = x0; si.ty0 = y0; si.tw = tw; si.th = th;
+      }
+    }
+    int rc;
+    if ((rc = upload(c, c->pa_prefix, prefix.data(), prefix.size()))) return rc;
+    if ((rc = upload(c, c->pa_nwide, nwide.data(), nwide.size()))) return rc;
+    if ((rc = upload(c, c->pa_x, x_pos, (size_t)size))) return rc;
+    if ((rc = upload(c, c->pa_y, y_pos, (size_t)size))) return rc;
+    if ((rc = upload(c, c->pa_sl, psf_sigmal, (size_t)size))) return rc;
+    if ((rc = upload(c, c->pa_sh, psf_sigmah, (size_t)size))) return rc;
+    if ((rc = upload(c, c->pa_sub, &si, 1))) return rc;
+
+    ThrowArgs a{};
+    a.W = size; a.K = 1; a.N = N; a.S = N + 2 * kBorder;
+    // enough workgroups to fill the chip when the call is big, one when small
+    a.splits = (int)std::min<long long>(512, std::max<long long>(1, total / (64LL * kThrowThreads)));
+    a.threads_compat = threads_compat;
+    a.seed = seed; a.exposure = exposure; a.subsample0 = subsample;
+    a.flags = 0; a.flat_off = 0; a.flat_wmin = 0; a.flat_wmax = 1;
+    a.sub = c->pa_sub.as<SubInfo>();
+    a.prefix = c->pa_prefix.as<uint32_t>();
+    a.nwide = c->pa_nwide.as<int32_t>();
+    a.xpos = c->pa_x.as<double>(); a.ypos = c->pa_y.as<double>();
+    a.sigl = c->pa_sl.as<double>(); a.sigh = c->pa_sh.as<double>();
+    for (int i = 0; i < 4; ++i) a.flat[i] = nullptr;
+    a.acc = nullptr;
+    a.frame = c->pa_frame.as<int32_t>();
+    {
+      ProfScope ps(c, PK_THROW);
+      rc = (rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 0>(c, a, lds_ints) : launch_throw<1, 0>(c, a, lds_ints);
+      if (rc) return rc;
+    }
+    c->electrons += run;
+  }
+  HIP_TRY(c, hipMemcpyAsync(out, c->pa_frame.p, (size_t)N * N * sizeof(int32_t), hipMemcpyDeviceToHost,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WAYNE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// grism + calibration
+// ---------------------------------------------------------------------------
+int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
+  if (!c || !g) return WAYNE_E_INVALID;
+  if (g->n_sens < 0 || (g->n_sens > 0 && (!g->sens_wl_um || !g->sens_val)))
+    return fail(c, WAYNE_E_INVALID, "set_grism: sensitivity table");
+  (void)hipSetDevice(c->device);
+  int rc;
+  if ((rc = upload(c, c->sens_wl, g->sens_wl_um, (size_t)g->n_sens))) return rc;
+  if ((rc = upload(c, c->sens_val, g->sens_val, (size_t)g->n_sens))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  GrismDev& d = c->g;
+  std::memcpy(d.trace, g->trace_coeff, sizeof d.trace);
+  std::memcpy(d.wlsol, g->wl_solution, sizeof d.wlsol);
+  std::memcpy(d.p_ratio, g->psf_ratio_poly, sizeof d.p_ratio);
+  std::memcpy(d.p_sigl, g->psf_sigmal_poly, sizeof d.p_sigl);
+  std::memcpy(d.p_sigh, g->psf_sigmah_poly, sizeof d.p_sigh);
+  d.flat_wmin = g->flat_wmin;
+  d.flat_wmax = g->flat_wmax;
+  d.n_sens = g->n_sens;
+  d.sens_wl = c->sens_wl.as<double>();
+  d.sens_val = c->sens_val.as<double>();
+  c->have_grism = true;
+  return WAYNE_OK;
+}
+
+int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
+  if (!c || !k) return WAYNE_E_INVALID;
+  const int sub = k->subarray;
+  if (sub != 64 && sub != 128 && sub != 256 && sub != 512 && sub != 1024)
+    return fail(c, WAYNE_E_INVALID, "set_calibration: SUBARRAY must be 64,128,256,512 or 1024");
+  if (k->n_reads < 1 || k->n_reads > 15) return fail(c, WAYNE_E_INVALID, "set_calibration: n_reads must be 1..15");
+  (void)hipSetDevice(c->device);
+  const int N = side_of(sub), S = N + 2 * kBorder;
+  const size_t NN = (size_t)N * N, SS = (size_t)S * S;
+  int rc;
+  c->has_flat = k->flat[0] && k->flat[1] && k->flat[2] && k->flat[3];
+  if (c->has_flat)
+    for (int i = 0; i < 4; ++i)
+      if ((rc = upload(c, c->flat[i], k->flat[i], NN))) return rc;
+  c->has_pfl = k->pfl != nullptr;
+  if (c->has_pfl) {
+    std::vector<float> v = embed(k->pfl, N, S, 1.0f);
+    if ((rc = upload(c, c->pfl, v.data(), SS))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->has_sky = k->sky != nullptr;
+  if (c->has_sky) {
+    std::vector<float> v = embed(k->sky, N, S, 0.0f);
+    if ((rc = upload(c, c->sky, v.data(), SS))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->has_lin = k->lin[0] && k->lin[1] && k->lin[2] && k->lin[3];
+  if (c->has_lin)
+    for (int i = 0; i < 4; ++i)
+      if ((rc = upload(c, c->lin[i], k->lin[i], SS))) return rc;
+  c->has_dark = k->dark_sci && k->dark_err;
+  if (c->has_dark) {
+    if ((rc = upload(c, c->dark_sci, k->dark_sci, SS * k->n_reads))) return rc;
+    if ((rc = upload(c, c->dark_err, k->dark_err, SS * k->n_reads))) return rc;
+  }
+  c->has_zero = k->zero_read != nullptr;
+  if (c->has_zero)
+    if ((rc = upload(c, c->zero_read, k->zero_read, SS))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->subarray = sub; c->N = N; c->S = S; c->cal_R = k->n_reads;
+  c->have_cal = true;
+  for (Slot& s : c->slots) { s.uploaded = false; s.acc_init = false; }
+  return WAYNE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exposure
+// ---------------------------------------------------------------------------
+int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) {
+  if (!c || !d) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "upload: slot");
+  if (!c->have_grism || !c->have_cal) return fail(c, WAYNE_E_STATE, "upload: set grism and calibration first");
+  const int W = d->n_wl, K = d->n_samples, R = d->n_reads;
+  if (W < 2 || K < 1 || R < 1) return fail(c, WAYNE_E_INVALID, "upload: need n_wl >= 2, n_samples >= 1, n_reads >= 1");
+  if (R != c->cal_R) return fail(c, WAYNE_E_INVALID, "upload: n_reads differs from the calibration's");
+  if (!d->wl_um || !d->flux || !d->x_ref || !d->y_ref || !d->dur_ms || !d->sample_read || !d->read_dt_s)
+    return fail(c, WAYNE_E_INVALID, "upload: null array");
+  if (d->rng_mode != WAYNE_RNG_REPLAY && d->rng_mode != WAYNE_RNG_PHILOX)
+    return fail(c, WAYNE_E_INVALID, "upload: rng_mode");
+  if (d->rng_mode == WAYNE_RNG_REPLAY && (d->threads_compat <= 0 || !d->replay_seed))
+    return fail(c, WAYNE_E_INVALID, "upload: replay mode needs threads_compat >= 1 and replay_seed");
+  for (int k = 0; k < K; ++k)
+    if (d->sample_read[k] < 0 || d->sample_read[k] >= R) return fail(c, WAYNE_E_INVALID, "upload: sample_read out of range");
+  if ((long long)K * W > 0x7FFFFFFFLL) return fail(c, WAYNE_E_INVALID, "upload: K*W too large");
+  (void)hipSetDevice(c->device);
+  Slot& s = c->slots[slot];
+  int rc;
+  const size_t KW = (size_t)K * W;
+  if ((rc = upload(c, s.wl, d->wl_um, (size_t)W))) return rc;
+  if ((rc = upload(c, s.flux, d->flux, (size_t)W))) return rc;
+  s.has_depth = d->depth != nullptr;
+  if (s.has_depth && (rc = upload(c, s.depth, d->depth, KW))) return rc;
+  if ((rc = upload(c, s.xref, d->x_ref, (size_t)K))) return rc;
+  if ((rc = upload(c, s.yref, d->y_ref, (size_t)K))) return rc;
+  if ((rc = upload(c, s.dur, d->dur_ms, (size_t)K))) return rc;
+  s.has_replay_seed = d->replay_seed != nullptr;
+  if (s.has_replay_seed && (rc = upload(c, s.rseed, d->replay_seed, (size_t)K))) return rc;
+  if ((rc = upload(c, s.sread, d->sample_read, (size_t)K))) return rc;
+  if ((rc = upload(c, s.read_dt, d->read_dt_s, (size_t)R))) return rc;
+  for (DevBuf* b : {&s.ratio, &s.sigl, &s.sigh, &s.sens, &s.dlam}) HIP_TRY(c, b->reserve((size_t)W * sizeof(double)));
+  HIP_TRY(c, s.counts.reserve(KW * sizeof(int32_t)));
+  HIP_TRY(c, s.nwide.reserve(KW * sizeof(int32_t)));
+  HIP_TRY(c, s.prefix.reserve((size_t)K * (W + 1) * sizeof(uint32_t)));
+  HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
+  HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
+  HIP_TRY(c, s.sub.reserve((size_t)K * sizeof(SubInfo)));
+  HIP_TRY(c, s.misc.reserve(64));
+  const size_t SS = (size_t)c->S * c->S;
+  const size_t acc_bytes = (size_t)R * SS * sizeof(long long);
+  if (s.acc.cap < acc_bytes) s.acc_init = false;
+  HIP_TRY(c, s.acc.reserve(acc_bytes));
+  if (!s.acc_init) {
+    HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, acc_bytes, c->stream));
+    s.acc_init = true;
+    s.acc_dirty = false;
+  }
+  const size_t out_elem = (d->flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
+  HIP_TRY(c, s.out.reserve((size_t)(R + 1) * SS * out_elem));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host arrays may go away after return
+  s.d = *d;
+  s.d.wl_um = s.d.flux = s.d.depth = s.d.x_ref = s.d.y_ref = s.d.dur_ms = s.d.read_dt_s = nullptr;
+  s.d.replay_seed = s.d.sample_read = nullptr;
+  s.W = W; s.K = K; s.R = R;
+  s.uploaded = true;
+  s.front_done = false;
+  return WAYNE_OK;
+}
+
+int wayne_exposure_run_front(wayne_ctx* c, int slot) {
+  if (!c) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "run: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "run: slot not uploaded");
+  (void)hipSetDevice(c->device);
+  const wayne_exposure_desc& d = s.d;
+  const int W = s.W, K = s.K, R = s.R, N = c->N, S = c->S;
+  const size_t SS = (size_t)S * S;
+  if (s.acc_dirty) {
+    HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
+    s.acc_dirty = false;
+  }
+  HIP_TRY(c, hipMemsetAsync(s.misc.p, 0, 64, c->stream));
+
+  WlArrays wa{s.ratio.as<double>(), s.sigl.as<double>(), s.sigh.as<double>(), s.sens.as<double>(),
+              s.dlam.as<double>()};
+  {
+    ProfScope ps(c, PK_PREP_WL);
+    hipLaunchKernelGGL(k_prep_wl, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->g, W,
+                       s.wl.as<double>(), wa);
+    HIP_TRY(c, hipGetLastError());
+  }
+  const int lds_ints = thrower_lds_ints(c);
+  {
+    PrepArgs a{};
+    a.g = c->g;
+    a.W = W; a.K = K; a.N = N;
+    a.sub_scale = d.sub_scale;
+    a.margin = d.thrower_margin > 0 ? d.thrower_margin : 20;
+    a.max_tile = lds_ints;
+    a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
+    a.scale_factor = d.scale_factor;
+    a.wl = s.wl.as<double>(); a.flux = s.flux.as<double>();
+    a.depth = s.has_depth ? s.depth.as<double>() : nullptr;
+    a.x_ref = s.xref.as<double>(); a.y_ref = s.yref.as<double>(); a.dur_ms = s.dur.as<double>();
+    a.replay_seed = s.has_replay_seed ? s.rseed.as<int32_t>() : nullptr;
+    a.sample_read = s.sread.as<int32_t>();
+    a.wa = wa;
+    a.counts = s.counts.as<int32_t>(); a.nwide = s.nwide.as<int32_t>();
+    a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
+    a.sub = s.sub.as<SubInfo>();
+    a.total_electrons = c->counters.as<unsigned long long>();
+    a.status = (int*)(s.misc.as<char>() + 8);
+    ProfScope ps(c, PK_PREP_SUB);
+    hipLaunchKernelGGL(k_prep_sub, dim3(K), dim3(kPrepThreads), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+  }
+  {
+    ThrowArgs a{};
+    a.W = W; a.K = K; a.N = N; a.S = S;
+    int splits = d.thrower_splits;
+    if (splits <= 0) {
+      const char* e = std::getenv("WAYNE_THROW_WGS");
+      const int target = e ? std::max(std::atoi(e), 1) : 1024;  // ~4 workgroups per CU
+      splits = std::max(1, (target + K - 1) / K);
+    }
+    a.splits = std::min(splits, 4096);
+    a.threads_compat = d.threads_compat;
+    a.seed = d.seed; a.exposure = d.exposure_index; a.subsample0 = 0;
+    a.flags = d.flags;
+    a.flat_off = (1014 - N) / 2;  // grism.py:363 (0 for the full array)
+    a.flat_wmin = c->g.flat_wmin; a.flat_wmax = c->g.flat_wmax;
+    a.sub = s.sub.as<SubInfo>(); a.prefix = s.prefix.as<uint32_t>(); a.nwide = s.nwide.as<int32_t>();
+    a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
+    a.sigl = s.sigl.as<double>(); a.sigh = s.sigh.as<double>();
+    for (int i = 0; i < 4; ++i) a.flat[i] = c->has_flat ? c->flat[i].as<float>() : nullptr;
+    a.acc = s.acc.as<long long>();
+    a.frame = nullptr;
+    if ((d.flags & WAYNE_F_ADD_FLAT) && !c->has_flat) return fail(c, WAYNE_E_STATE, "run: add_flat without a flat cube");
+    ProfScope ps(c, PK_THROW);
+    int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
+    if (rc) return rc;
+  }
+  s.acc_dirty = true;
+  if (d.cosmic_rate >= 0.) {
+    CosmicArgs a{};
+    a.R = R; a.N = N; a.S = S; a.seed = d.seed; a.exposure = d.exposure_index;
+    a.rate = d.cosmic_rate; a.read_dt = s.read_dt.as<double>(); a.acc = s.acc.as<long long>();
+    ProfScope ps(c, PK_COSMIC);
+    hipLaunchKernelGGL(k_cosmic, dim3(R), dim3(256), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+  }
+  s.front_done = true;
+  return WAYNE_OK;
+}
+
+int wayne_exposure_run_back(wayne_ctx* c, int slot) {
+  if (!c) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "run: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded || !s.front_done) return fail(c, WAYNE_E_STATE, "run_back: run_front first");
+  (void)hipSetDevice(c->device);
+  const wayne_exposure_desc& d = s.d;
+  const int S = c->S;
+  RampArgs a{};
+  a.R = s.R; a.N = c->N; a.S = S;
+  a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
+  a.sky_ct_s = d.sky_ct_s; a.noise_mean = d.noise_mean; a.noise_std = d.noise_std;
+  a.read_dt = s.read_dt.as<double>();
+  a.acc = s.acc.as<long long>();
+  a.pfl = c->has_pfl ? c->pfl.as<float>() : nullptr;
+  a.sky = c->has_sky ? c->sky.as<float>() : nullptr;
+  for (int i = 0; i < 4; ++i) a.lin[i] = c->has_lin ? c->lin[i].as<float>() : nullptr;
+  a.dark_sci = c->has_dark ? c->dark_sci.as<float>() : nullptr;
+  a.dark_err = c->has_dark ? c->dark_err.as<float>() : nullptr;
+  a.zero_read = c->has_zero ? c->zero_read.as<double>() : nullptr;
+  a.out = s.out.p;
+  if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
+  if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
+  if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
+  const int threads = 256;
+  const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
+  {
+    ProfScope ps(c, PK_RAMP);
+    if (d.flags & WAYNE_F_OUT_F64)
+      hipLaunchKernelGGL(k_ramp<double>, dim3(blocks), dim3(threads), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(k_ramp<float>, dim3(blocks), dim3(threads), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+  }
+  s.acc_dirty = false;
+  s.front_done = false;
+  return WAYNE_OK;
+}
+
+int wayne_exposure_run(wayne_ctx* c, int slot) {
+  int rc = wayne_exposure_run_front(c, slot);
+  if (rc) return rc;
+  return wayne_exposure_run_back(c, slot);
+}
+
+static int check_status(wayne_ctx* c, Slot& s) {
+  struct { unsigned long long electrons; int status; int pad; } m{};
+  HIP_TRY(c, hipMemcpyAsync(&m, s.misc.p, sizeof m, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (m.status != 0) return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  return WAYNE_OK;
+}
+
+int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
+  if (!c || !out_reads) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "download: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "download: slot not uploaded");
+  (void)hipSetDevice(c->device);
+  const size_t SS = (size_t)c->S * c->S;
+  const size_t out_elem = (s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
+  HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
+  return check_status(c, s);
+}
+
+void* wayne_exposure_device_reads(wayne_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= kSlots) return nullptr;
+  return c->slots[slot].out.p;
+}
+
+int wayne_exposure_synthesize(wayne_ctx* c, const wayne_exposure_desc* d, void* out_reads) {
+  int rc = wayne_exposure_upload(c, 0, d);
+  if (rc) return rc;
+  if ((rc = wayne_exposure_run(c, 0))) return rc;
+  return wayne_exposure_download(c, 0, out_reads);
+}
+
+int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* x_pos, double* y_pos,
+                               double* acc_e) {
+  if (!c) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "debug_fetch: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "debug_fetch: slot not uploaded");
+  (void)hipSetDevice(c->device);
+  const size_t KW = (size_t)s.K * s.W;
+  if (counts) HIP_TRY(c, hipMemcpyAsync(counts, s.counts.p, KW * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (x_pos) HIP_TRY(c, hipMemcpyAsync(x_pos, s.xpos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (y_pos) HIP_TRY(c, hipMemcpyAsync(y_pos, s.ypos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (acc_e) {
+    const size_t n = (size_t)s.R * c->S * c->S;
+    std::vector<long long> tmp(n);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), s.acc.p, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) acc_e[i] = (double)tmp[i] * kInvQ;
+  }
+  return check_status(c, s);
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+int wayne_profile_enable(wayne_ctx* c, int on) {
+  if (!c) return WAYNE_E_INVALID;
+  c->prof_on = on != 0;
+  return WAYNE_OK;
+}
+
+int wayne_profile_reset(wayne_ctx* c) {
+  if (!c) return WAYNE_E_INVALID;
+  int rc = collect_profile(c);
+  if (rc) return rc;
+  for (int i = 0; i < WAYNE_PROF_KERNELS; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; }
+  c->electrons = 0;
+  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WAYNE_OK;
+}
+
+int wayne_profile_get(wayne_ctx* c, wayne_profile* out) {
+  if (!c || !out) return WAYNE_E_INVALID;
+  int rc = collect_profile(c);
+  if (rc) return rc;
+  for (int i = 0; i < WAYNE_PROF_KERNELS; ++i) {
+    out->name[i] = kProfNames[i];
+    out->launches[i] = c->prof_launches[i];
+    out->ms[i] = c->prof_ms[i];
+  }
+  unsigned long long dev = 0;
+  HIP_TRY(c, hipMemcpy(&dev, c->counters.p, sizeof dev, hipMemcpyDeviceToHost));
+  out->electrons = c->electrons + dev;
+  return WAYNE_OK;
+}
+
+void wayne_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  const u32x4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+
+}  // extern "C"
