@@ -237,6 +237,14 @@ int wayne_profile_get(wayne_ctx *ctx, wayne_profile *out); /* synchronises */
  * jitter / seed draws (exposure_generator.py:327-329). */
 void wayne_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* The per-exposure host draws of scanning_frame (exposure_generator.py:327-329)
+ * from the Philox HOST stage: for sub-sample k, block (k, 0, 0, exposure) gives
+ * two standard normals (Box-Muller of words 0,1; the caller scales them by
+ * x_jitter / y_jitter) and s_rand_seeds[k] = randint(0, 100000) from word 2.
+ * Pure host arithmetic; any output pointer may be NULL. */
+void wayne_host_sample_draws(uint32_t seed, uint32_t exposure, int n_samples,
+                             double *z_x, double *z_y, int32_t *rand_seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,155 @@
+"""GPU: a whole exposure through wayne_exposure_synthesize (via the
+ExposureGenerator mirror) against the numpy oracle, stage by stage.
+
+Tolerances (stated per test):
+  * counts per bin: exact (integers); bin positions: 1e-9 px (fp64 both sides)
+  * electrons accumulated per read interval, replay thrower + flat: the device
+    keeps round(n * flat * 2^28) per tile flush, so |d| <= flushes * 2^-29 e-
+  * deterministic reads (noise sources off): 1e-3 DN absolute on float32 output
+    is dominated by float32 rounding of values up to 78 000 DN (ulp 0.0078):
+    tolerance 0.02 DN + 2e-7 relative; float64 output: 1e-6 DN
+  * stochastic reads under the same Philox counters: same tolerance for all but
+    a counted handful of pixels whose Poisson draw flipped on a 1-ulp logf/expf
+    difference between libm and the device.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import wayne_oracle as wo
+from wayne_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DET_OFF = dict(add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False)
+
+
+def run_both(name, i=0, thrower="oracle", rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64, threads=3, **over):
+    v = helpers.make_visit(name, n_exposures=max(i + 1, 1))
+    kw = v.frame_kwargs(i, **over)
+    pg = helpers.product_generator(v, i)
+    rec = {}
+    exp = pg.scanning_frame(threads=threads, rng_mode=rng_mode, out_dtype=out_dtype, record=rec, **kw)
+    got = np.stack([r[0] for r in exp.reads])
+    eo = helpers.oracle_generator(v)
+    orec = {}
+    draws = wo.PhiloxDraws(v.seed, i, pg.detector.light_sensitive_size(v.SUBARRAY))
+    want = np.stack(eo.scanning_frame(threads=threads, draws=draws, thrower=thrower, record=orec,
+                                      **helpers.oracle_kwargs(kw)))
+    return v, got, want, rec, orec
+
+
+@pytest.mark.parametrize("name", ["tiny", "small256"])
+def test_prep_counts_and_positions(name):
+    v, got, want, rec, orec = run_both(name, **DET_OFF)
+    np.testing.assert_array_equal(rec["counts"], np.stack(orec["counts"]))       # np.round of the counts chain
+    np.testing.assert_allclose(rec["x"], np.stack(orec["x"]), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rec["y"], np.stack(orec["y"]), rtol=0, atol=1e-9)
+    assert rec["counts"].sum() > 0
+
+
+@pytest.mark.parametrize("name", ["tiny", "small256"])
+def test_prep_counts_with_stellar_poisson(name):
+    v, got, want, rec, orec = run_both(name, **dict(DET_OFF, add_stellar_noise=True))
+    a, b = rec["counts"], np.stack(orec["counts"])
+    # fp64 PTRS both sides: a differing draw needs a 1-ulp log() difference on a decision boundary
+    assert (a != b).mean() < 1e-5
+    lam_mean = b.mean()
+    assert abs(a.mean() - lam_mean) < 1e-3 * lam_mean
+
+
+@pytest.mark.parametrize("name,flat", [("tiny", True), ("tiny", False), ("small256", True)])
+def test_accumulated_electrons_replay_thrower_and_flat(name, flat):
+    v, got, want, rec, orec = run_both(name, **dict(DET_OFF, add_flat=flat))
+    acc_o = np.stack(orec["acc"])
+    assert rec["acc"].shape == acc_o.shape
+    flushes = 4096.0 * v.K   # bound on tile flushes into one pixel (workgroups per sub-sample x K)
+    np.testing.assert_allclose(rec["acc"], acc_o, rtol=1e-13, atol=flushes * 2.0 ** -29)
+    assert acc_o.sum() > 0.5 * rec["counts"].sum() * 0.3   # a good part of the spectrum is on the frame
+
+
+@pytest.mark.parametrize("name", ["tiny", "small256"])
+def test_deterministic_reads_float64(name):
+    v, got, want, rec, orec = run_both(name, **DET_OFF)
+    assert got.dtype == np.float64 and got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-4)
+    # border pixels are reference pixels: zero without read noise
+    assert not got[:, :5, :].any() and not got[:, :, -5:].any()
+    assert got[-1].max() > 10
+
+
+def test_deterministic_reads_float32_output():
+    v, got, want, rec, orec = run_both("small256", out_dtype=np.float32, **DET_OFF)
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0.02)
+
+
+def test_flags_off_paths():
+    over = dict(DET_OFF, add_flat=False, add_gain_variations=False, add_non_linear=False,
+                clip_values_det_limits=False, add_initial_bias=False, scale_factor=None, planet_signal=None)
+    v, got, want, rec, orec = run_both("tiny", **over)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-4)
+    # without any detector effect the last read is (electrons on frame) / 2.35
+    total_e = np.stack(orec["acc"]).sum()
+    assert abs(got[-1].sum() * 2.35 - total_e) < 1e-6 * total_e
+
+
+def test_full_noise_philox_everything_on():
+    over = dict(noise_mean=2.0, noise_std=0.5)
+    v, got, want, rec, orec = run_both("tiny", thrower="philox", rng_mode=_lib.RNG_PHILOX, **over)
+    d = np.abs(got - want)
+    tol = 0.05 + 1e-6 * np.abs(want)
+    bad = int((d > tol).sum())
+    # hardware sin/cos/log2 in the thrower move a few electrons to the next pixel, and a
+    # float32 Poisson decision may flip: both show as isolated pixels off by ~1 e-/2.35
+    assert bad <= 2e-3 * got.size, "%d of %d pixels differ" % (bad, got.size)
+    assert np.median(d) < 5e-3
+
+
+def test_noise_statistics_small256():
+    over = dict(add_stellar_noise=True)
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0, **over)
+    pg = helpers.product_generator(v, 0)
+    exp = pg.scanning_frame(out_dtype=np.float64, **kw)
+    reads = np.stack([r[0] for r in exp.reads])
+    # reference pixels: pure read noise N(0, 14.1/2.35) on every read (exposure.py:61-68, 122-131)
+    border = np.concatenate([reads[:, :5, :].ravel(), reads[:, -5:, :].ravel()])
+    assert abs(border.mean()) < 0.1 and abs(border.std() - 14.1 / 2.35) < 0.1
+    # zero read interior = clipped bias + read noise
+    assert abs(np.median(reads[0][5:-5, 5:-5]) - np.median(np.clip(v.calibration.bias_256, -20, 78000)[5:-5, 5:-5])) < 2.0
+    # sky-only corner far from the spectrum: mean of the first read = sky*dt/gain + dark, in DN
+    dt = v.read_times[0]
+    corner = reads[1][200:250, 10:60] - reads[0][200:250, 10:60]
+    want = v.sky[0] * dt / 2.35 + 0.05 * dt
+    assert abs(corner.mean() - want) < 0.5 + 0.05 * want
+
+
+def test_exposure_is_deterministic_and_split_invariant():
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0)
+    pg = helpers.product_generator(v, 0)
+    a = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    np.testing.assert_array_equal(a, b)
+    import os
+    os.environ["WAYNE_THROW_WGS"] = "37"
+    os.environ["WAYNE_TILE_INTS"] = "2000"
+    try:
+        c = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    finally:
+        del os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"]
+    np.testing.assert_array_equal(a, c)      # integer accumulation: launch geometry cannot change a bit
+    other = helpers.product_generator(v, 1)
+    d = np.stack([r[0] for r in other.scanning_frame(**kw).reads])
+    assert np.abs(a - d).max() > 1.0          # a different exposure index draws different noise
+
+
+def test_staring_frame_matches_scanning_at_zero_speed():
+    v = helpers.make_visit("tiny")
+    kw = v.frame_kwargs(0, **DET_OFF)
+    pg = helpers.product_generator(v, 0)
+    eg_kw = {k: kw[k] for k in kw if k not in ("scan_speed", "sample_rate", "ssv_generator")}
+    st = np.stack([r[0] for r in pg.staring_frame(rng_mode=_lib.RNG_REPLAY, **eg_kw).reads])
+    sc = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_REPLAY, **dict(kw, scan_speed=0.0)).reads])
+    np.testing.assert_array_equal(st, sc)

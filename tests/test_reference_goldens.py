@@ -1,0 +1,157 @@
+"""CPU: the golden values the reference's own unit tests hold for this path
+(tests/test_grism.py, test_detector.py, test_tools.py, trend_generators/*),
+checked against BOTH the oracle restatement and the product's host-side
+mirror.  Numbers are quoted from those tests (file:line in each case)."""
+import numpy as np
+import pytest
+
+from oracle import wayne_oracle as wo
+from wayne_amd import detector as pdet
+from wayne_amd import grism as pgrism
+from wayne_amd import tools as ptools
+from wayne_amd.trend_generators import visit_trends
+
+
+def grisms():
+    return [("oracle", wo.Grism("G141")), ("product", pgrism.G141())]
+
+
+@pytest.mark.parametrize("which,g", grisms())
+def test_get_pixel_wl(which, g):                       # tests/test_grism.py:16-21
+    for args, want in [((50, 50, 100, 50), 11222.2), ((50, 50, 200, 50), 15748.6), ((50, 50, 100, 51), 11222.7),
+                       ((50, 60, 100, 50), 11218.8), ((60, 50, 100, 50), 10770.6)]:
+        assert abs(g.get_pixel_wl(*args) - want) < 0.05
+
+
+@pytest.mark.parametrize("which,g", grisms())
+def test_get_pixel_wl_per_row(which, g):               # tests/test_grism.py:29-46
+    wl = g.get_pixel_wl_per_row(50, 50, np.arange(1024))
+    assert len(wl) == 1024
+    assert abs(wl.mean() - 29961.2) < 0.05 and abs(wl.min() - 8959.) < 0.05 and abs(wl.max() - 53001.1) < 0.05
+    np.testing.assert_array_almost_equal(g.get_pixel_wl_per_row(50, 50, np.array([100, 110, 120, 150, 200])),
+                                         [11222.2, 11674.8, 12127.5, 13485.4, 15748.6], 1)
+    np.testing.assert_array_almost_equal(g.get_pixel_wl_per_row(50, 50, np.array([100, 110, 120, 150, 200]), 51),
+                                         [11222.7, 11675.3, 12127.9, 13485.9, 15749.1], 1)
+
+
+@pytest.mark.parametrize("which,g", grisms())
+def test_get_pixel_edges_and_bin_limits(which, g):     # tests/test_grism.py:48-57
+    wl = g.get_pixel_edges_wl_per_row(50, 50, np.array([100, 110, 120, 130]), None, 10)
+    np.testing.assert_array_almost_equal(wl, [10995.9, 11448.5, 11901.2, 12353.8, 12806.5], 1)
+    np.testing.assert_array_equal(g._bin_centers_to_limits(np.array([-1, 0, 1]), 1), np.arange(-1.5, 2.))
+
+
+@pytest.mark.parametrize("fn", [wo.wavelength_calibration_coeffs, pgrism.wavelength_calibration_coeffs])
+def test_wavelength_calibration_coeffs(fn):            # tests/test_grism.py:66-80
+    for xy, want in [((50, 50), [0.0099, 1.8767, 45.2665, 8958.9896]),
+                     ((100, 50), [0.0096, 1.8812, 45.2776, 8963.6693]),
+                     ((50, 100), [0.0099, 1.7801, 45.3782, 8958.9896])]:
+        got = np.array(fn(xy[0], xy[1], pgrism.g141_trace_coeff, pgrism.g141_wl_solution))
+        np.testing.assert_array_almost_equal(got, want, decimal=4)
+
+
+def test_trace_constants_agree_between_oracle_and_product():
+    assert wo.G141_TRACE == pgrism.g141_trace_coeff and wo.G102_TRACE == pgrism.g102_trace_coeff
+    assert wo.G141_WLSOL == pgrism.g141_wl_solution and wo.G102_WLSOL == pgrism.g102_wl_solution
+    for x, y in [(404.5, 457.4), (783.5, 80.0)]:
+        a, b = wo.SpectrumTrace(x, y, wo.G141_TRACE, wo.G141_WLSOL), pgrism.G141_Trace(x, y)
+        wl = np.linspace(1.0, 1.7, 9)
+        np.testing.assert_allclose(a.wl_to_x(wl), b.wl_to_x(wl), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a.wl_to_y(wl), b.wl_to_y(wl), rtol=0, atol=1e-9)
+        # the spectrum sits to the right of the star: 1.1 um ~ 45 A/px from the zero point
+        assert 30 < a.wl_to_x(np.array([1.1]))[0] - x < 60
+
+
+@pytest.mark.parametrize("det", [wo.Detector(), pdet.WFC3_IR()])
+def test_mode_tables(det):                             # tests/test_detector.py:16-32, 72-81
+    assert sum(len(t) for sub in det.modes_exp_table.values() for t in sub.values()) == 360
+    assert det.exptime(NSAMP=2, SAMPSEQ="RAPID", SUBARRAY=1024) == 2.932
+    assert det.exptime(NSAMP=16, SAMPSEQ="RAPID", SUBARRAY=64) == 0.912
+    # test_detector.py:32 asserts `value - 161.302 < 0.001` (no abs): the table row is
+    # SAMPNUM = NSAMP - 1 = 7 -> 138.381 s (161.302 is SAMPNUM 8)
+    assert det.exptime(NSAMP=8, SAMPSEQ="SPARS25", SUBARRAY=512) - 161.302 < 0.001
+    assert det.exptime(NSAMP=8, SAMPSEQ="SPARS25", SUBARRAY=512) == 138.381
+    np.testing.assert_array_almost_equal(det.get_read_times(NSAMP=5, SAMPSEQ="RAPID", SUBARRAY=1024),
+                                         [2.932, 5.865, 8.797, 11.729], 3)
+    np.testing.assert_array_almost_equal(det.get_read_times(NSAMP=3, SAMPSEQ="SPARS10", SUBARRAY=256),
+                                         [0.278, 7.624], 3)
+
+
+def test_mode_errors():                                # tests/test_detector.py:44-108
+    det = pdet.WFC3_IR()
+    assert sum(len(v) for v in det.modes_calb_table.values()) == 19
+    for kw in [dict(NSAMP=17, SAMPSEQ="RAPID", SUBARRAY=1024), dict(NSAMP=0, SAMPSEQ="RAPID", SUBARRAY=1024),
+               dict(NSAMP=15, SAMPSEQ="WRONG", SUBARRAY=1024), dict(NSAMP=15, SAMPSEQ="SPARS25", SUBARRAY=128),
+               dict(NSAMP=15, SAMPSEQ="RAPID", SUBARRAY=1023), dict(NSAMP=15, SAMPSEQ="RAPID", SUBARRAY=0)]:
+        with pytest.raises(pdet.WFC3SimSampleModeError):
+            det.exptime(**kw)
+        with pytest.raises(pdet.WFC3SimSampleModeError):
+            det.get_read_times(**kw)
+        with pytest.raises(wo.SampleModeError):
+            wo.Detector().get_read_times(**kw)
+
+
+@pytest.mark.parametrize("mod", [wo, ptools])
+def test_crop_and_bins(mod):                           # tests/test_tools.py:12-81
+    wl, flux = np.arange(10.), np.arange(10.) * 2
+    for lo, hi, want in [(1, 8, [1, 2, 3, 4, 5, 6, 7, 8]), (0.99, 8.99, [1, 2, 3, 4, 5, 6, 7, 8]),
+                         (1.5, 7.5, [2, 3, 4, 5, 6, 7])]:
+        cw, cf = mod.crop_spectrum(lo, hi, wl.copy(), flux)
+        np.testing.assert_array_equal(cw, want)
+        np.testing.assert_array_equal(cf, np.array(want) * 2)
+    np.testing.assert_array_equal(mod.bin_centers_to_edges(np.array([1, 2, 3, 4])), [0.5, 1.5, 2.5, 3.5, 4.5])
+    np.testing.assert_array_almost_equal(mod.bin_centers_to_edges(np.array([1, 2, 4, 5.4])), [0.5, 1.5, 3, 4.7, 6.1], 6)
+    np.testing.assert_array_equal(mod.bin_centers_to_widths(np.array([1, 2, 3, 4])), [1, 1, 1, 1])
+    np.testing.assert_array_almost_equal(mod.bin_centers_to_widths(np.array([1, 2, 4, 5.4])), [1, 1.5, 1.7, 1.4], 6)
+
+
+def test_crop_central_box():
+    a = np.arange(100.).reshape(10, 10)
+    for mod in (wo, ptools):
+        np.testing.assert_array_equal(mod.crop_central_box(a, 4), a[3:7, 3:7])
+        assert mod.crop_central_box(a, 10) is a      # the reference returns an EMPTY array here (tools.py:322-324)
+
+
+def test_hook_and_long_term_ramp():                    # tests/trend_generators/test_visit_trends.py:38-52
+    t = np.array([6, 9, 12, 95, 98, 101]) / 60. / 24.
+    vt = visit_trends.HookAndLongTermRamp({"exp_start_times": t, "orbit_start_index": [0, 3]},
+                                          (0.005, 0.0011, 400, 9 / 60 / 24))
+    np.testing.assert_array_almost_equal(vt.scale_factors, [0.99891, 0.99952, 0.99978, 0.9986, 0.99921, 0.99947],
+                                         decimal=5)
+    assert vt.get_scale_factor(3) == vt.scale_factors[3]
+
+
+def test_cosmic_generator_statistics():                # tests/trend_generators/test_cosmic_rays.py:53-70
+    for draws in (wo.LegacyDraws(5), wo.PhiloxDraws(5, 0, 64)):
+        n = []
+        for r in range(100):
+            # rate 11 /s on a full 1024^2 frame for 1 s: mean 11 hits
+            if draws.philox:
+                d = wo.PhiloxDraws(5, r, 64)
+                lam = np.array([11.0])
+                out = np.empty(1)
+                from oracle import clib
+                clib.lib().wayne_oracle_poisson_f64(lam, 1, 5, wo.STAGE_CR_COUNT, 0, 0, r, out)
+                n.append(out[0])
+            else:
+                n.append(draws.rs.poisson(11))
+        assert 10 <= np.mean(n) <= 12
+    f = wo.PhiloxDraws(9, 3, 64).cosmic_frame(11. * 1024 * 1024 / 64 / 64, 20.0, 64, 0)
+    hits = f[f > 0]
+    assert f.shape == (64, 64) and hits.size > 100
+    assert hits.min() >= 10000                          # energies in [10000, 35000), overlaps add
+    single = hits[hits < 35000]
+    assert single.size > 50 and single.max() < 35000
+
+
+def test_sample_times_example_visit_shape():
+    # example yml: SUBARRAY 256, SPARS10, NSAMP 5, 10 ms sampling -> K = 2233 sub-samples
+    from wayne_amd.exposure_generator import ExposureGenerator
+    eg = ExposureGenerator(pdet.WFC3_IR(), pgrism.G141(), 5, "SPARS10", 256)
+    starts, mids, durs, read_index = eg._gen_scanning_sample_times(10.)
+    eo = wo.ExposureOracle(wo.Detector(), wo.Grism("G141"), 5, "SPARS10", 256)
+    s2, m2, d2, r2 = eo._gen_scanning_sample_times(10.)
+    assert len(starts) == 2233 and read_index == r2 == [27, 762, 1497, 2232]
+    np.testing.assert_array_equal(mids, m2)
+    np.testing.assert_array_equal(durs, d2)
+    assert abs(durs.sum() - 22.317 * 1000) < 1e-6 and durs.min() > 0

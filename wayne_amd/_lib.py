@@ -100,6 +100,7 @@ SYMBOLS = {
     "wayne_profile_reset": (C.c_int, [_vp]),
     "wayne_profile_get": (C.c_int, [_vp, C.POINTER(Profile)]),
     "wayne_philox4x32": (None, [_vp, _vp, _vp]),
+    "wayne_host_sample_draws": (None, [C.c_uint32, C.c_uint32, C.c_int, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -358,6 +359,16 @@ def philox4x32(ctr, key):
     out = np.empty(4, dtype=np.uint32)
     load().wayne_philox4x32(ptr(ctr), ptr(key), ptr(out))
     return out
+
+
+def host_sample_draws(seed, exposure, n_samples):
+    """(z_x, z_y, rand_seed) of the Philox HOST stage for one exposure."""
+    zx = np.empty(n_samples, dtype=np.float64)
+    zy = np.empty(n_samples, dtype=np.float64)
+    rs = np.empty(n_samples, dtype=np.int32)
+    load().wayne_host_sample_draws(int(seed) & 0xFFFFFFFF, int(exposure) & 0xFFFFFFFF, int(n_samples),
+                                   ptr(zx), ptr(zy), ptr(rs))
+    return zx, zy, rs
 
 
 _default_ctx = {}

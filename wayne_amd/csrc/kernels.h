@@ -20,8 +20,9 @@
 namespace wayne {
 
 constexpr int kBorder = 5;            // reference-pixel border (detector.py:146-147)
-constexpr double kQ = 1048576.0;      // accumulator fixed point: 2^20 per electron
-constexpr double kInvQ = 1.0 / 1048576.0;
+constexpr int kQBits = 28;            // accumulator fixed point: 2^28 per electron
+constexpr double kQ = 268435456.0;    //   (int64: 3.4e10 e- of range per pixel and read interval,
+constexpr double kInvQ = 1.0 / 268435456.0;  // 1.9e-9 e- rounding per tile flush)
 constexpr double kGain = 2.35;        // detector.py:30
 constexpr double kReadNoise = 14.1 / 2.35;  // detector.py:33
 constexpr double kMinCounts = -20.0;  // detector.py:26
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
 // FLUSH 0: add the int32 tile into an int32 frame (wayne_psf_apply).
 // FLUSH 1: multiply by the wavelength-dependent flat of THIS sub-sample
 //   (grism.py:349-409; applied where the frame is > 0, exposure_generator.py
-//   :641-645) and add round(n * flat * 2^20) into the int64 accumulator of the
+//   :641-645) and add round(n * flat * 2^28) into the int64 accumulator of the
 //   sub-sample's read interval, at the bordered position (y+5, x+5)
 //   (detector.py:146-147).  Integer atomics commute, so the result is
 //   bit-reproducible for any launch geometry.
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256) void k_cosmic(CosmicArgs a) {
     const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
     const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
     const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
-    const long long q = (long long)energy << 20;
+    const long long q = (long long)energy << kQBits;
     atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
               (unsigned long long)q);
   }

@@ -748,4 +748,17 @@ void wayne_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
   for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
 
+void wayne_host_sample_draws(uint32_t seed, uint32_t exposure, int n_samples, double* z_x, double* z_y,
+                             int32_t* rand_seed) {
+  for (int k = 0; k < n_samples; ++k) {
+    const u32x4 w = philox4x32_10((uint32_t)k, 0u, 0u, exposure, seed, STAGE_HOST);
+    const double ua = u01d(w.v[0]), ub = u01d(w.v[1]);
+    const double R = std::sqrt(-2.0 * std::log(ub));
+    const double ang = 6.283185307179586476925 * ua;
+    if (z_x) z_x[k] = R * std::cos(ang);
+    if (z_y) z_y[k] = R * std::sin(ang);
+    if (rand_seed) rand_seed[k] = (int32_t)uint_below(w.v[2], 100000u);
+  }
+}
+
 }  // extern "C"

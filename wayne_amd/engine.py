@@ -1,0 +1,54 @@
+"""One GPU's exposure engine: a wayne_ctx configured for a grism and a
+(SUBARRAY, SAMPSEQ, NSAMP) mode, with calibration planes resident in HBM.
+
+The reference re-derives this state for every exposure -- re-opening gain,
+sky and dark FITS files per read (detector.py:187,202; grism.py:417).  Here it
+is built once per (device, grism, mode) and reused for the whole visit.
+"""
+import numpy as np
+
+from . import _lib
+
+_engines = {}
+
+
+class Engine(object):
+    def __init__(self, device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY,
+                 add_initial_bias=True):
+        self.device = device
+        self.grism, self.detector, self.calibration = grism, detector, calibration
+        self.NSAMP, self.SAMPSEQ, self.SUBARRAY = NSAMP, SAMPSEQ, SUBARRAY
+        self.read_times = detector.get_read_times(NSAMP, SUBARRAY, SAMPSEQ)    # seconds
+        self.ctx = _lib.Context(device)
+        sens_wl, sens_val = calibration.sensitivity(grism.name)
+        wmin, wmax = calibration.flat_wl.get(grism.name, (0.0, 1.0))
+        self.ctx.set_grism(grism.trace_coeff, grism.wl_solution, grism.psf_ratio_poly.coeffs,
+                           grism.psf_sigmal_poly.coeffs, grism.psf_sigmah_poly.coeffs,
+                           sens_wl, sens_val, wmin, wmax)
+        planes = calibration.for_mode(grism.name, SUBARRAY, SAMPSEQ, self.read_times,
+                                      add_initial_bias=add_initial_bias, detector=detector)
+        self.has_dark = "dark_sci" in planes
+        self.ctx.set_calibration(planes["subarray"], planes["n_reads"], flat=planes.get("flat"),
+                                 pfl=planes.get("pfl"), sky=planes.get("sky"), lin=planes.get("lin"),
+                                 dark_sci=planes.get("dark_sci"), dark_err=planes.get("dark_err"),
+                                 zero_read=planes.get("zero_read"))
+        self.N, self.S, self.R = self.ctx.N, self.ctx.S, self.ctx.R
+
+    def close(self):
+        self.ctx.close()
+
+
+def get_engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias=True):
+    """Cached engine per (device, grism, mode, calibration object)."""
+    key = (device, grism.name, NSAMP, SAMPSEQ, SUBARRAY, id(calibration), bool(add_initial_bias))
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias)
+        _engines[key] = eng
+    return eng
+
+
+def close_all():
+    for e in _engines.values():
+        e.close()
+    _engines.clear()
