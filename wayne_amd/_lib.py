@@ -258,45 +258,8 @@ class Context(object):
         self.N, self.S, self.R = N, S, int(n_reads)
 
     # -- exposures -------------------------------------------------------------
-    def make_desc(self, seed, exposure_index, flags, sub_scale, wl_um, flux, depth, x_ref, y_ref, dur_ms,
-                  sample_read, read_dt_s, replay_seed=None, rng_mode=RNG_PHILOX, threads_compat=1,
-                  sky_ct_s=0.0, cosmic_rate=-1.0, scale_factor=1.0, noise_mean=0.0, noise_std=0.0,
-                  thrower_margin=0, thrower_splits=0):
-        d = ExposureDesc()
-        keep = []
-
-        def arr(a, conv):
-            a = conv(a)
-            keep.append(a)
-            return a
-
-        wl_um, flux = arr(wl_um, f64), arr(flux, f64)
-        x_ref, y_ref, dur_ms = arr(x_ref, f64), arr(y_ref, f64), arr(dur_ms, f64)
-        sample_read, read_dt_s = arr(sample_read, i32), arr(read_dt_s, f64)
-        W, K = wl_um.size, x_ref.size
-        if flux.size != W or y_ref.size != K or dur_ms.size != K or sample_read.size != K:
-            raise ValueError("exposure descriptor: inconsistent array lengths")
-        d.seed, d.exposure_index = int(seed) & 0xFFFFFFFF, int(exposure_index) & 0xFFFFFFFF
-        d.rng_mode, d.threads_compat = int(rng_mode), int(threads_compat)
-        d.flags, d.sub_scale = int(flags), int(sub_scale)
-        d.n_wl, d.wl_um, d.flux = W, ptr(wl_um, C.c_double), ptr(flux, C.c_double)
-        if depth is not None:
-            depth = arr(depth, f64)
-            if depth.shape != (K, W):
-                raise ValueError("depth must have shape (K, W)")
-            d.depth = ptr(depth, C.c_double)
-        d.n_samples = K
-        d.x_ref, d.y_ref, d.dur_ms = ptr(x_ref, C.c_double), ptr(y_ref, C.c_double), ptr(dur_ms, C.c_double)
-        if replay_seed is not None:
-            replay_seed = arr(replay_seed, i32)
-            d.replay_seed = ptr(replay_seed, C.c_int32)
-        d.sample_read = ptr(sample_read, C.c_int32)
-        d.n_reads, d.read_dt_s = read_dt_s.size, ptr(read_dt_s, C.c_double)
-        d.sky_ct_s, d.cosmic_rate = float(sky_ct_s), float(cosmic_rate)
-        d.scale_factor, d.noise_mean, d.noise_std = float(scale_factor), float(noise_mean), float(noise_std)
-        d.thrower_margin, d.thrower_splits = int(thrower_margin), int(thrower_splits)
-        d._keep = keep
-        return d
+    def make_desc(self, *a, **k):
+        return make_desc(*a, **k)
 
     def upload(self, slot, desc):
         self.check(self._L.wayne_exposure_upload(self._h, int(slot), C.byref(desc)))
@@ -347,6 +310,47 @@ class Context(object):
             out[p.name[i].decode()] = {"launches": int(p.launches[i]), "ms": float(p.ms[i])}
         out["electrons"] = int(p.electrons)
         return out
+
+
+def make_desc(seed, exposure_index, flags, sub_scale, wl_um, flux, depth, x_ref, y_ref, dur_ms,
+              sample_read, read_dt_s, replay_seed=None, rng_mode=RNG_PHILOX, threads_compat=1,
+              sky_ct_s=0.0, cosmic_rate=-1.0, scale_factor=1.0, noise_mean=0.0, noise_std=0.0,
+              thrower_margin=0, thrower_splits=0):
+    d = ExposureDesc()
+    keep = []
+
+    def arr(a, conv):
+        a = conv(a)
+        keep.append(a)
+        return a
+
+    wl_um, flux = arr(wl_um, f64), arr(flux, f64)
+    x_ref, y_ref, dur_ms = arr(x_ref, f64), arr(y_ref, f64), arr(dur_ms, f64)
+    sample_read, read_dt_s = arr(sample_read, i32), arr(read_dt_s, f64)
+    W, K = wl_um.size, x_ref.size
+    if flux.size != W or y_ref.size != K or dur_ms.size != K or sample_read.size != K:
+        raise ValueError("exposure descriptor: inconsistent array lengths")
+    d.seed, d.exposure_index = int(seed) & 0xFFFFFFFF, int(exposure_index) & 0xFFFFFFFF
+    d.rng_mode, d.threads_compat = int(rng_mode), int(threads_compat)
+    d.flags, d.sub_scale = int(flags), int(sub_scale)
+    d.n_wl, d.wl_um, d.flux = W, ptr(wl_um, C.c_double), ptr(flux, C.c_double)
+    if depth is not None:
+        depth = arr(depth, f64)
+        if depth.shape != (K, W):
+            raise ValueError("depth must have shape (K, W)")
+        d.depth = ptr(depth, C.c_double)
+    d.n_samples = K
+    d.x_ref, d.y_ref, d.dur_ms = ptr(x_ref, C.c_double), ptr(y_ref, C.c_double), ptr(dur_ms, C.c_double)
+    if replay_seed is not None:
+        replay_seed = arr(replay_seed, i32)
+        d.replay_seed = ptr(replay_seed, C.c_int32)
+    d.sample_read = ptr(sample_read, C.c_int32)
+    d.n_reads, d.read_dt_s = read_dt_s.size, ptr(read_dt_s, C.c_double)
+    d.sky_ct_s, d.cosmic_rate = float(sky_ct_s), float(cosmic_rate)
+    d.scale_factor, d.noise_mean, d.noise_std = float(scale_factor), float(noise_mean), float(noise_std)
+    d.thrower_margin, d.thrower_splits = int(thrower_margin), int(thrower_splits)
+    d._keep = keep
+    return d
 
 
 def device_count():

@@ -119,6 +119,47 @@ class ExposureGenerator(object):
         sub-sample; electrons accumulated per read interval) for parity tests.
         """
         start_time = time.time()
+        eng = _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP,
+                                 self.SAMPSEQ, self.SUBARRAY, add_initial_bias)
+        desc = self.build_descriptor(
+            eng, x_ref, y_ref, x_jitter, y_jitter, wl, stellar_flux, planet_signal, scan_speed, sample_rate,
+            sample_mid_points, sample_durations, read_index, ssv_generator, noise_mean, noise_std, add_dark,
+            add_flat, cosmic_rate, sky_background, scale_factor, add_gain_variations, add_non_linear,
+            clip_values_det_limits, add_read_noise, add_stellar_noise, add_initial_bias, progress_bar, threads,
+            rng_mode, out_dtype, reference_quirks)
+        R = len(self.read_times)
+        read_dt = self._read_dt
+        if record is None:
+            reads = eng.ctx.synthesize(desc)
+        else:
+            eng.ctx.upload(0, desc)
+            eng.ctx.run_front(0)
+            record["counts"], record["x"], record["y"], record["acc"] = eng.ctx.debug_fetch(0, acc=True)
+            record.update(self._host_vectors)
+            eng.ctx.run_back(0)
+            reads = eng.ctx.download(0)
+
+        # read 0 is the zero read (:301-303); reads 1..R carry their timing (:371-382)
+        self.exposure.add_read(reads[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
+        for r in range(R):
+            self.exposure.add_read(reads[r + 1], {"cumulative_exp_time": float(self.read_times[r]),
+                                                  "read_exp_time": float(read_dt[r]), "CRPIX1": 0})
+        assert len(self.exposure.reads) == self.NSAMP                                  # (:397)
+        self.exp_info["sim_time"] = time.time() - start_time
+        return self.exposure
+
+    def build_descriptor(self, eng, x_ref, y_ref, x_jitter, y_jitter, wl, stellar_flux, planet_signal,
+                         scan_speed, sample_rate, sample_mid_points=None, sample_durations=None,
+                         read_index=None, ssv_generator=None, noise_mean=False, noise_std=False,
+                         add_dark=True, add_flat=True, cosmic_rate=None, sky_background=1.0,
+                         scale_factor=None, add_gain_variations=True, add_non_linear=True,
+                         clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
+                         add_initial_bias=True, progress_bar=None, threads=2,
+                         rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False):
+        """The host half of scanning_frame: sample timing, scan positions, SSV,
+        jitter / seed draws, spectrum crop (exposure_generator.py:247-334) ->
+        one wayne_exposure_desc for the device.  Pure host code (`eng` may be
+        None when no GPU is involved, e.g. when sharding a visit on the CPU)."""
         wl = np.asarray(wl, dtype=float)
         stellar_flux = np.asarray(stellar_flux, dtype=float)
         scan_speed_ms = scan_speed / 1000.          # px/s -> px/ms (:247)
@@ -143,9 +184,7 @@ class ExposureGenerator(object):
         })
         self.exposure = exposure.Exposure(self.detector, self.grism, self.planet, self.exp_info)
 
-        eng = _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP,
-                                 self.SAMPSEQ, self.SUBARRAY, add_initial_bias)
-        if add_dark and not eng.has_dark:
+        if add_dark and eng is not None and not eng.has_dark:
             # the reference switches the dark off with a warning when the mode has no super-dark (:414-423)
             warnings.warn("No Dark file found for SAMPSEQ = {}, SUBARRAY={} - Switching Dark Off".format(
                 self.SAMPSEQ, self.SUBARRAY), WFC3SimNoDarkFileWarning)
@@ -190,7 +229,9 @@ class ExposureGenerator(object):
         if self.SUBARRAY == 1024 and not reference_quirks:
             sub_scale = 0
 
-        desc = eng.ctx.make_desc(
+        self._read_dt = read_dt
+        self._host_vectors = {"x_ref": s_x, "y_ref": s_y, "dur": s_dur, "seeds": s_rand_seeds}
+        return _lib.make_desc(
             self.seed, self.exposure_index, flags, sub_scale, s_wl, flux, depth, s_x, s_y, s_dur,
             sample_read, read_dt, replay_seed=s_rand_seeds, rng_mode=rng_mode, threads_compat=threads,
             sky_ct_s=float(sky_background) if sky_background else 0.0,
@@ -198,24 +239,6 @@ class ExposureGenerator(object):
             scale_factor=1.0 if scale_factor is None else float(scale_factor),
             noise_mean=float(noise_mean) if noise_mean else 0.0,
             noise_std=float(noise_std) if noise_std else 0.0)
-        if record is None:
-            reads = eng.ctx.synthesize(desc)
-        else:
-            eng.ctx.upload(0, desc)
-            eng.ctx.run_front(0)
-            record["counts"], record["x"], record["y"], record["acc"] = eng.ctx.debug_fetch(0, acc=True)
-            record["x_ref"], record["y_ref"], record["dur"], record["seeds"] = s_x, s_y, s_dur, s_rand_seeds
-            eng.ctx.run_back(0)
-            reads = eng.ctx.download(0)
-
-        # read 0 is the zero read (:301-303); reads 1..R carry their timing (:371-382)
-        self.exposure.add_read(reads[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
-        for r in range(R):
-            self.exposure.add_read(reads[r + 1], {"cumulative_exp_time": float(self.read_times[r]),
-                                                  "read_exp_time": float(read_dt[r]), "CRPIX1": 0})
-        assert len(self.exposure.reads) == self.NSAMP                                  # (:397)
-        self.exp_info["sim_time"] = time.time() - start_time
-        return self.exposure
 
     def direct_image(self, x_ref, y_ref):
         """The unscaled 2-D gaussian direct image used to calibrate x_ref / y_ref

@@ -1,0 +1,104 @@
+"""Running a visit: exposures sharded round-robin over GPUs, one process per GPU.
+
+Exposures of a visit share no state (the reference only couples them through
+its sequential global RNG, observation.py:403-405, which the Philox counters
+remove), so exposure i goes to rank i mod G with no collective in the data
+path.  Each rank owns one Engine (context + resident
+calibration) and writes its own NNNN_raw.fits files (observation.py:427).
+"""
+import hashlib
+import os
+
+import numpy as np
+
+from . import engine as _engine
+from .exposure import Exposure
+from .exposure_generator import ExposureGenerator
+
+
+def shard(n_exposures, rank, world):
+    """Exposure indices of `rank`: i = rank, rank + world, ... (round-robin keeps
+    orbit phase, and so per-exposure cost, balanced across ranks)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    return list(range(rank, n_exposures, world))
+
+
+def descriptor_digest(desc):
+    """SHA-1 over everything a descriptor hands to the device (for sharding tests)."""
+    h = hashlib.sha1()
+    for name, _ in desc._fields_:
+        v = getattr(desc, name)
+        if isinstance(v, (int, float)):
+            h.update(repr((name, v)).encode())
+    for a in desc._keep:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+class VisitRunner(object):
+    """Generate the exposures `indices` of a synthetic.Visit-like object on one GPU."""
+
+    def __init__(self, visit, device=0, out_dir=None, out_dtype=np.float32, frame_overrides=None):
+        self.visit, self.device, self.out_dir = visit, device, out_dir
+        self.out_dtype = out_dtype
+        self.frame_overrides = frame_overrides or {}
+        self._eng = None
+
+    def engine(self):
+        if self._eng is None:
+            v = self.visit
+            self._eng = _engine.get_engine(self.device, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ,
+                                           v.SUBARRAY)
+        return self._eng
+
+    def generator(self, i):
+        v = self.visit
+        return ExposureGenerator(v.detector, v.grism, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=v.calibration,
+                                 device=self.device, seed=v.seed, exposure_index=i,
+                                 filename="%04d_raw.fits" % (i + 1))
+
+    def descriptor(self, i, eng=None):
+        return self.generator(i).build_descriptor(eng, out_dtype=self.out_dtype,
+                                                  **self.visit.frame_kwargs(i, **self.frame_overrides))
+
+    def run(self, indices, keep=False):
+        """Synthesise the given exposures.  The next exposure's host preparation and
+        upload overlap the current one's kernels (two HBM slots, asynchronous launch).
+        Returns {index: reads} when keep=True; writes FITS files when out_dir is set."""
+        eng = self.engine()
+        ctx = eng.ctx
+        results = {}
+        indices = list(indices)
+        pending = None
+        for n, i in enumerate(indices):
+            slot = n % 2
+            gen = self.generator(i)
+            desc = gen.build_descriptor(eng, out_dtype=self.out_dtype,
+                                        **self.visit.frame_kwargs(i, **self.frame_overrides))
+            if pending is not None and pending[1] == slot:
+                self._finish(ctx, pending, results, keep)
+                pending = None
+            ctx.upload(slot, desc)
+            ctx.run(slot)                       # asynchronous
+            if pending is not None:
+                self._finish(ctx, pending, results, keep)
+            pending = (i, slot, gen)
+        if pending is not None:
+            self._finish(ctx, pending, results, keep)
+        return results
+
+    def _finish(self, ctx, pending, results, keep):
+        i, slot, gen = pending
+        reads = ctx.download(slot)
+        if keep:
+            results[i] = reads
+        if self.out_dir is not None:
+            os.makedirs(self.out_dir, exist_ok=True)
+            exp = Exposure(gen.detector, gen.grism, None, gen.exp_info)
+            read_dt = np.diff(np.concatenate([[0.0], gen.read_times]))
+            exp.add_read(reads[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
+            for r in range(len(gen.read_times)):
+                exp.add_read(reads[r + 1], {"cumulative_exp_time": float(gen.read_times[r]),
+                                            "read_exp_time": float(read_dt[r]), "CRPIX1": 0})
+            exp.generate_fits(self.out_dir, gen.exp_info["filename"])
