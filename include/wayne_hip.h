@@ -53,6 +53,9 @@ extern "C" {
 #define WAYNE_F_ADD_DARK (1u << 6)
 #define WAYNE_F_ADD_INITIAL_BIAS (1u << 7)
 #define WAYNE_F_OUT_F64 (1u << 16) /* reads delivered as float64 (the reference's dtype) instead of float32 */
+#define WAYNE_F_EXACT_SAMPLERS (1u << 17) /* IEEE divide/sqrt + libm-grade log/exp/sin/cos in the per-pixel
+                                             Poisson / normal draws (parity runs) instead of the hardware
+                                             approximations (production); same algorithm, same streams */
 
 typedef struct wayne_ctx wayne_ctx;
 

@@ -55,12 +55,14 @@ def lib():
         L.wayne_oracle_poisson_f64.restype = None
         L.wayne_oracle_poisson_f64.argtypes = [_f64p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, _f64p]
-        L.wayne_oracle_poisson_sky.restype = None
-        L.wayne_oracle_poisson_sky.argtypes = [_f32p, _u32p, C.c_int64, C.c_uint32, C.c_uint32,
-                                               C.c_uint32, C.c_uint32, _f64p]
-        L.wayne_oracle_normal_pairs.restype = None
-        L.wayne_oracle_normal_pairs.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
-                                                C.c_uint32, _f32p, _f32p]
+        L.wayne_oracle_seed_streams.restype = None
+        L.wayne_oracle_seed_streams.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+        L.wayne_oracle_poisson_sky_step.restype = None
+        L.wayne_oracle_poisson_sky_step.argtypes = [_f32p, C.c_int64, _u32p, _f64p]
+        L.wayne_oracle_normal_step.restype = None
+        L.wayne_oracle_normal_step.argtypes = [C.c_int64, _u32p, _f32p, _f32p]
+        L.wayne_oracle_xo_next.restype = C.c_uint32
+        L.wayne_oracle_xo_next.argtypes = [_u32p]
         L.wayne_oracle_philox_blocks.restype = None
         L.wayne_oracle_philox_blocks.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_uint32, _u32p]

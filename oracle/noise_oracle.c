@@ -22,12 +22,16 @@
 #include <stdint.h>
 
 void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+uint32_t wayne_oracle_xo_next(uint32_t state[4]);
 
+/* A word source: either consecutive Philox blocks (counter word 1 = block
+ * index) or a Philox-seeded xoshiro128+ state (`xo` != NULL). */
 typedef struct {
   uint32_t ctr[4];
   uint32_t key[2];
   uint32_t buf[4];
   int have;
+  uint32_t *xo;
 } wo_stream;
 
 static void wo_stream_init(wo_stream *s, uint32_t seed, uint32_t stage, uint32_t c0,
@@ -35,9 +39,11 @@ static void wo_stream_init(wo_stream *s, uint32_t seed, uint32_t stage, uint32_t
   s->ctr[0] = c0; s->ctr[1] = 0; s->ctr[2] = c2; s->ctr[3] = c3;
   s->key[0] = seed; s->key[1] = stage;
   s->have = 0;
+  s->xo = 0;
 }
 
 static uint32_t wo_next(wo_stream *s) {
+  if (s->xo) return wayne_oracle_xo_next(s->xo);
   if (s->have == 0) {
     wayne_oracle_philox4x32(s->ctr, s->key, s->buf);
     s->ctr[1] += 1;
@@ -151,26 +157,35 @@ void wayne_oracle_poisson_f64(const double *lam, int64_t n, uint32_t seed, uint3
   }
 }
 
-/* the sky draw of the ramp kernel: float32 sampler below lam = 256, float64
- * above; element i uses counter c0 = idx[i] (the bordered pixel index) */
-void wayne_oracle_poisson_sky(const float *lam, const uint32_t *idx, int64_t n, uint32_t seed,
-                              uint32_t stage, uint32_t c2, uint32_t c3, double *out) {
+/* Seeded streams (wayne_amd/csrc/philox.h): the 128-bit xoshiro128+ state of
+ * element idx[i] is Philox block (idx[i], 0, 0, exposure) of `stage`. */
+void wayne_oracle_seed_streams(const uint32_t *idx, int64_t n, uint32_t seed, uint32_t stage,
+                               uint32_t exposure, uint32_t *state /* n*4 */) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t ctr[4] = {idx[i], 0u, 0u, exposure};
+    const uint32_t key[2] = {seed, stage};
+    wayne_oracle_philox4x32(ctr, key, state + 4 * i);
+  }
+}
+
+/* One sky Poisson draw per pixel from its STAGE_SKY stream, advancing the
+ * state (the ramp kernel draws read 0, 1, ... in this order): product of
+ * uniforms below lam = 10, float32 PTRS below 256, float64 PTRS above. */
+void wayne_oracle_poisson_sky_step(const float *lam, int64_t n, uint32_t *state, double *out) {
   for (int64_t i = 0; i < n; ++i) {
     wo_stream s;
-    wo_stream_init(&s, seed, stage, idx[i], c2, c3);
+    s.xo = state + 4 * i;
+    s.have = 0;
     out[i] = (lam[i] < 256.0f) ? (double)wo_poisson_f(lam[i], &s) : wo_poisson_d((double)lam[i], &s);
   }
 }
 
-/* Box-Muller pair from words 0,1 of block (idx[i], 0, c2, c3): fp32, libm. */
-void wayne_oracle_normal_pairs(const uint32_t *idx, int64_t n, uint32_t seed, uint32_t stage,
-                               uint32_t c2, uint32_t c3, float *z0, float *z1) {
+/* One Box-Muller pair per pixel from its next two stream words (fp32, libm). */
+void wayne_oracle_normal_step(int64_t n, uint32_t *state, float *z0, float *z1) {
   for (int64_t i = 0; i < n; ++i) {
-    const uint32_t ctr[4] = {idx[i], 0u, c2, c3};
-    const uint32_t key[2] = {seed, stage};
-    uint32_t w[4];
-    wayne_oracle_philox4x32(ctr, key, w);
-    const float ua = wo_u01f(w[0]), ub = wo_u01f(w[1]);
+    const uint32_t w0 = wayne_oracle_xo_next(state + 4 * i);
+    const uint32_t w1 = wayne_oracle_xo_next(state + 4 * i);
+    const float ua = wo_u01f(w0), ub = wo_u01f(w1);
     const float R = sqrtf(-2.0f * logf(ub));
     const float ang = 6.283185307179586f * ua;
     z0[i] = R * cosf(ang);

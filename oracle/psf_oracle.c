@@ -147,15 +147,40 @@ static inline float wo_u01(uint32_t x) {
   return ((float)x + 0.5f) * 2.3283064365386963e-10f;
 }
 
+/* xoshiro128+ (Blackman & Vigna, 2018; public domain algorithm), the
+ * oracle's own statement: 32-bit words, state seeded by one Philox block. */
+typedef struct { uint32_t s[4]; } wo_xo;
+
+static inline uint32_t wo_xo_next(wo_xo *g) {
+  const uint32_t r = g->s[0] + g->s[3];
+  const uint32_t t = g->s[1] << 9;
+  g->s[2] ^= g->s[0];
+  g->s[3] ^= g->s[1];
+  g->s[1] ^= g->s[2];
+  g->s[0] ^= g->s[3];
+  g->s[2] ^= t;
+  g->s[3] = (g->s[3] << 11) | (g->s[3] >> 21);
+  return r;
+}
+
+uint32_t wayne_oracle_xo_next(uint32_t state[4]) {
+  wo_xo g;
+  memcpy(g.s, state, sizeof g.s);
+  uint32_t r = wo_xo_next(&g);
+  memcpy(state, g.s, sizeof g.s);
+  return r;
+}
+
 /*
  * Production-mode thrower for ONE sub-sample: electron e (bin-major order,
- * exactly the reference's numbering, pyparallel_menu.c:87-108) draws its pair
- * of normals from Philox counter (e>>1, 0, subsample, exposure), words
- * {0,1} for even e and {2,3} for odd e:
+ * exactly the reference's numbering, pyparallel_menu.c:87-108) belongs to
+ * block e/128; the block's stream is xoshiro128+ seeded by Philox counter
+ * (e/128, 0, subsample, exposure), key (seed, STAGE_THROW); electron j = e%128
+ * of the block takes the stream's words 2j (angle) and 2j+1 (radius):
  *    z_x = R cos(2 pi u_a), z_y = R sin(2 pi u_a), R = sqrt(-2 ln u_b)
  * in fp32 (the device uses v_sin/v_cos/v_log hardware approximations, so
  * device-vs-oracle agreement is "all but a ~1e-4 fraction of electrons land
- * in the same pixel", asserted and counted in tests/test_thrower_philox.py).
+ * in the same pixel", asserted and counted in tests/test_psf_gpu.py).
  * Positions are fp32.  Same sigma split, truncation and bounds rule as A4.
  */
 int wayne_oracle_psf_philox(const int32_t *counts, int size,
@@ -168,20 +193,19 @@ int wayne_oracle_psf_philox(const int32_t *counts, int size,
   memset(out, 0, (size_t)nr * (size_t)nc * sizeof(int32_t));
   const uint32_t key[2] = {seed, WO_STAGE_THROW};
   uint64_t e = 0;
-  uint32_t rnd[4] = {0, 0, 0, 0};
+  wo_xo g = {{0, 0, 0, 0}};
   for (int b = 0; b < size; ++b) {
     if (counts[b] < 0) return -2;
     /* sigma split in fp64, as the reference (:89) */
     const int n_wide = wo_trunc_int(counts[b] * psf_ratio[b]);
     for (int j = 0; j < counts[b]; ++j, ++e) {
-      if ((e & 1u) == 0) {
-        /* new block: electrons 2q and 2q+1 share Philox counter q */
-        const uint64_t blk = e >> 1;
-        const uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), subsample,
-                                 exposure};
-        wayne_oracle_philox4x32(ctr, key, rnd);
+      if ((e & 127u) == 0) {
+        /* new block of 128 electrons: fresh stream */
+        const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
+        wayne_oracle_philox4x32(ctr, key, g.s);
       }
-      const uint32_t ra = rnd[(e & 1u) * 2], rb = rnd[(e & 1u) * 2 + 1];
+      const uint32_t ra = wo_xo_next(&g);
+      const uint32_t rb = wo_xo_next(&g);
       const float ua = wo_u01(ra), ub = wo_u01(rb);
       const float R = sqrtf(-2.0f * logf(ub));
       const float ang = 6.283185307179586f * ua;

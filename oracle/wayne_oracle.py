@@ -373,9 +373,11 @@ class LegacyDraws(object):
 
 
 class PhiloxDraws(object):
-    """The MI355X path's counter layout (wayne_amd/csrc/philox.h):
-    key = (seed, stage), counter = (element, block, sub-sample | read, exposure).
-    Pixel elements are indices into the BORDERED S x S frame."""
+    """The MI355X path's stream layout (wayne_amd/csrc/philox.h):
+    key = (seed, stage), counter = (element, block, sub-sample | read, exposure);
+    the per-pixel stages (SKY, READ, NOISE) and the thrower use one Philox block
+    as the state of a short xoshiro128+ stream.  Pixel elements are indices
+    into the BORDERED S x S frame."""
     philox = True
 
     def __init__(self, seed, exposure, N):
@@ -383,7 +385,10 @@ class PhiloxDraws(object):
         yy, xx = np.mgrid[0:N, 0:N]
         self.interior_idx = np.ascontiguousarray(((yy + 5) * self.S + (xx + 5)).ravel().astype(np.uint32))
         self.all_idx = np.arange(self.S * self.S, dtype=np.uint32)
-        self._pairs = {}
+        self._pairs = []          # (z_dark, z_read) of read 0, 1, ... from the STAGE_READ streams
+        self._state = {}
+        self._sky_next = 0
+        self._noise_next = 0
 
     def _blocks(self, c0, c1, c2, stage):
         c0 = np.ascontiguousarray(c0, dtype=np.uint32)
@@ -406,21 +411,36 @@ class PhiloxDraws(object):
         clib.lib().wayne_oracle_poisson_f64(lam, lam.size, self.seed, STAGE_COUNTS, 0, int(k), self.exposure, out)
         return out
 
-    def _normal_pairs(self, idx, stage, r):
-        z0 = np.empty(idx.size, dtype=np.float32)
-        z1 = np.empty(idx.size, dtype=np.float32)
-        clib.lib().wayne_oracle_normal_pairs(idx, idx.size, self.seed, stage, int(r), self.exposure, z0, z1)
+    def _stream(self, name, idx, stage):
+        """xoshiro128+ states of the seeded stream `stage` for the pixels `idx`."""
+        if name not in self._state:
+            st = np.empty((idx.size, 4), dtype=np.uint32)
+            clib.lib().wayne_oracle_seed_streams(idx, idx.size, self.seed, stage, self.exposure, st)
+            self._state[name] = st
+        return self._state[name]
+
+    def _normal_step(self, state):
+        n = state.shape[0]
+        z0 = np.empty(n, dtype=np.float32)
+        z1 = np.empty(n, dtype=np.float32)
+        clib.lib().wayne_oracle_normal_step(n, state, z0, z1)
         return z0, z1
 
     def gaussian_noise(self, mean, std, dim, r):
-        z0, _ = self._normal_pairs(self.interior_idx, STAGE_NOISE, r)
+        # STAGE_NOISE stream of each interior pixel: words 2r, 2r+1 -> read interval r (calls come in order)
+        assert r == self._noise_next
+        self._noise_next += 1
+        z0, _ = self._normal_step(self._stream("noise", self.interior_idx, STAGE_NOISE))
         return mean + std * z0.astype(np.float64).reshape(dim, dim)
 
     def sky_poisson(self, lam, r):
+        # STAGE_SKY stream of each interior pixel, consumed read after read
+        assert r == self._sky_next
+        self._sky_next += 1
         lam32 = np.ascontiguousarray(lam, dtype=np.float32).ravel()
         out = np.empty(lam32.size)
-        clib.lib().wayne_oracle_poisson_sky(lam32, self.interior_idx, lam32.size, self.seed, STAGE_SKY, int(r),
-                                            self.exposure, out)
+        clib.lib().wayne_oracle_poisson_sky_step(lam32, lam32.size, self._stream("sky", self.interior_idx, STAGE_SKY),
+                                                 out)
         return out.reshape(lam.shape)
 
     def cosmic_frame(self, rate, time, size, r):
@@ -439,8 +459,10 @@ class PhiloxDraws(object):
         return array
 
     def _read_pair(self, r):
-        if r not in self._pairs:
-            self._pairs[r] = self._normal_pairs(self.all_idx, STAGE_READ, r)
+        # words 2i, 2i+1 of every pixel's STAGE_READ stream belong to read i (0 = zero read)
+        st = self._stream("read", self.all_idx, STAGE_READ)
+        while len(self._pairs) <= r:
+            self._pairs.append(self._normal_step(st))
         return self._pairs[r]
 
     def dark_normal(self, dark, err, r):

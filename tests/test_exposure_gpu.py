@@ -24,12 +24,14 @@ pytestmark = pytest.mark.gpu
 DET_OFF = dict(add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False)
 
 
-def run_both(name, i=0, thrower="oracle", rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64, threads=3, **over):
+def run_both(name, i=0, thrower="oracle", rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64, threads=3, exact=True,
+             **over):
     v = helpers.make_visit(name, n_exposures=max(i + 1, 1))
     kw = v.frame_kwargs(i, **over)
     pg = helpers.product_generator(v, i)
     rec = {}
-    exp = pg.scanning_frame(threads=threads, rng_mode=rng_mode, out_dtype=out_dtype, record=rec, **kw)
+    exp = pg.scanning_frame(threads=threads, rng_mode=rng_mode, out_dtype=out_dtype, record=rec,
+                            exact_samplers=exact, **kw)
     got = np.stack([r[0] for r in exp.reads])
     eo = helpers.oracle_generator(v)
     orec = {}
@@ -104,6 +106,30 @@ def test_full_noise_philox_everything_on():
     # float32 Poisson decision may flip: both show as isolated pixels off by ~1 e-/2.35
     assert bad <= 2e-3 * got.size, "%d of %d pixels differ" % (bad, got.size)
     assert np.median(d) < 5e-3
+
+
+def test_noise_stages_exact_samplers_replay_thrower():
+    # every noise source on, but the bit-exact replay thrower: what differs from the oracle can
+    # only come from the Poisson / normal stages (same streams, libm vs ocml within 1 ulp)
+    v, got, want, rec, orec = run_both("small256", **dict(add_stellar_noise=True, noise_mean=1.0, noise_std=0.3))
+    d = np.abs(got - want)
+    bad = int((d > 1e-3 + 1e-6 * np.abs(want)).sum())
+    assert bad <= 1e-4 * got.size, "%d of %d pixels differ" % (bad, got.size)
+    assert np.median(d) < 1e-4
+
+
+def test_fast_samplers_agree_with_exact():
+    # production math (v_rcp/v_sqrt/v_log/v_exp/v_sin/v_cos) against the exact policy, same streams
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0)
+    pg = helpers.product_generator(v, 0)
+    a = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, exact_samplers=True, **kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, exact_samplers=False, **kw).reads])
+    d = np.abs(a - b)
+    # normals differ by the hardware sin/cos error (< 1e-4 sigma); a Poisson draw flips on a ~1e-6 boundary
+    bad = int((d > 5e-3).sum())
+    assert bad <= 1e-3 * a.size, "%d of %d pixels differ" % (bad, a.size)
+    assert np.median(d) < 1e-3 and d.max() < 40.0
 
 
 def test_noise_statistics_small256():

@@ -23,6 +23,7 @@ F_ADD_STELLAR_NOISE = 1 << 5
 F_ADD_DARK = 1 << 6
 F_ADD_INITIAL_BIAS = 1 << 7
 F_OUT_F64 = 1 << 16
+F_EXACT_SAMPLERS = 1 << 17
 PROF_KERNELS = 6
 
 

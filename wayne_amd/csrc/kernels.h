@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "philox.h"
 #include "samplers.h"
 
@@ -140,15 +141,17 @@ struct PrepArgs {
   int* status;               // set non-zero on overflow
 };
 
-constexpr int kPrepThreads = 256;
+constexpr int kPrepThreads = 512;
 
 __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int W = a.W;
+  constexpr int NW = kPrepThreads / 64;
   __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
-  __shared__ uint32_t s_scan[kPrepThreads];
-  __shared__ double s_red[4][kPrepThreads / 64];
+  __shared__ uint32_t s_wsum[NW];   // per-wave totals of the current chunk
+  __shared__ double s_red[4][NW];
   __shared__ uint32_t s_carry;
 
   const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       double cnt;
       if (noisy) {
         PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
-        cnt = poisson<double>(lam, rng);      // np.random.poisson (:626)
+        cnt = poisson<ExactMath<double> >(lam, rng);   // np.random.poisson (:626)
       } else {
         cnt = rint(lam);                      // np.round, half to even (:628)
       }
@@ -228,24 +231,31 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
         ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
       }
     }
-    // block-wide exclusive scan of c (Hillis-Steele in LDS; W is small)
-    s_scan[tid] = c;
-    __syncthreads();
-    for (int off = 1; off < kPrepThreads; off <<= 1) {
-      uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
+    // block-wide exclusive scan of c: shuffle scan inside each wave, then the
+    // 16 wave totals through LDS
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
     }
-    const uint32_t incl = s_scan[tid];
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, chunk_total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const uint32_t t = s_wsum[i];
+      if (i < wave) wave_off += t;
+      chunk_total += t;
+    }
     const uint32_t carry = s_carry;
     if (w < W) {
-      const uint64_t ex = (uint64_t)carry + incl - c;
+      const uint64_t ex = (uint64_t)carry + wave_off + incl - c;
       if (ex + c > 0xFFFFFFFFull) overflow = true;
       a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)ex;
     }
     __syncthreads();
-    if (tid == kPrepThreads - 1) s_carry = carry + incl;
+    if (tid == 0) s_carry = carry + chunk_total;
     __syncthreads();
   }
 
@@ -256,14 +266,14 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     ymin = fmin(ymin, __shfl_down(ymin, off));
     ymax = fmax(ymax, __shfl_down(ymax, off));
   }
-  if ((tid & 63) == 0) {
-    s_red[0][tid >> 6] = xmin; s_red[1][tid >> 6] = xmax;
-    s_red[2][tid >> 6] = ymin; s_red[3][tid >> 6] = ymax;
+  if (lane == 0) {
+    s_red[0][wave] = xmin; s_red[1][wave] = xmax;
+    s_red[2][wave] = ymin; s_red[3][wave] = ymax;
   }
   if (overflow) atomicExch(a.status, 1);
   __syncthreads();
   if (tid == 0) {
-    for (int i = 1; i < kPrepThreads / 64; ++i) {
+    for (int i = 1; i < NW; ++i) {
       xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
       ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
     }
@@ -278,13 +288,14 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     si.a_t_i = 1. / m_t;            // grism.py:367
     si.a_w = s_tr[2]; si.b_w = s_tr[3];
     // LDS tile: bounding box of the populated trace + margin, clipped to the
-    // frame, shrunk symmetrically if it exceeds the LDS budget (electrons
-    // outside the tile take the global-atomic path, so this is speed only).
+    // frame's populated range [1, N) (pixel row / column 0 is never hit,
+    // pyparallel_menu.c:93), shrunk symmetrically if it exceeds the LDS budget
+    // (electrons outside the tile take the global-atomic path: speed only).
     int tx0 = 0, ty0 = 0, tw = 0, th = 0;
     if (E > 0 && xmax >= xmin) {
       int x0 = (int)floor(xmin) - a.margin, x1 = (int)floor(xmax) + a.margin + 1;
       int y0 = (int)floor(ymin) - a.margin, y1 = (int)floor(ymax) + a.margin + 1;
-      x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, a.N); y1 = min(y1, a.N);
+      x0 = max(x0, 1); y0 = max(y0, 1); x1 = min(x1, a.N); y1 = min(y1, a.N);
       if (x1 > x0 && y1 > y0) {
         tw = x1 - x0; th = y1 - y0;
         while ((long long)tw * th > a.max_tile && th > 1) { y0 += 1; th -= 2; if (th < 1) th = 1; }
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
 // ---------------------------------------------------------------------------
 // Electrons of sub-sample k are numbered bin-major exactly as the reference
 // numbers them (pyparallel_menu.c:87-108).  The E_k electrons are cut into
-// splits*T equal contiguous "slots"; workgroup (k, s) takes the slots
+// splits*T equal contiguous "slots" (T = 512 threads); workgroup (k, s) takes the slots
 // j*splits + s, its lane l / wave v takes j = l*(T/64) + v, so the 64 lanes
 // of a wave sit ~E_k/64 electrons apart, i.e. spread over the whole trace:
 // their LDS atomics rarely collide in a bank or on a pixel.  Each lane walks
@@ -315,8 +326,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
 //   rand_r calls 2(i - start_t) and 2(i - start_t)+1 of that stream; the LCG
 //   state is reached by an O(log n) affine jump (pyparallel_menu.c:47-61).
 //   fp64 Box-Muller, fp64 positions -> bit-exact frames.
-// RNG_MODE 1 (Philox): electrons 2q, 2q+1 use words {0,1}, {2,3} of Philox
-//   counter (q, k, exposure), stage STAGE_THROW; fp32 Box-Muller on the
+// RNG_MODE 1 (Philox): electron e uses words 2j, 2j+1 (j = e mod 128) of the
+//   xoshiro128+ stream seeded by Philox block (e / 128, 0, k, exposure), stage
+//   STAGE_THROW (philox.h); slots are whole blocks, so the draws of an
+//   electron do not depend on the launch geometry.  fp32 Box-Muller on the
 //   hardware sin/cos/log2 units.
 //
 // FLUSH 0: add the int32 tile into an int32 frame (wayne_psf_apply).
@@ -424,18 +437,20 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   const double* XP = a.xpos + (size_t)k * W;
   const double* YP = a.ypos + (size_t)k * W;
 
-  constexpr uint32_t UNIT = (RNG_MODE == 1) ? 2u : 1u;  // electrons per work unit
+  // slots: contiguous electron ranges, whole RNG blocks in Philox mode
+  constexpr uint32_t UNIT = (RNG_MODE == 1) ? kThrowBlock : 1u;
   const uint64_t n_units = ((uint64_t)E + UNIT - 1) / UNIT;
   const uint64_t n_slots = (uint64_t)a.splits * kThrowThreads;
   const uint64_t L = (n_units + n_slots - 1) / n_slots;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint64_t slot = ((uint64_t)lane * (kThrowThreads / 64) + wave) * a.splits + s;
-  uint64_t u = slot * L;
-  uint64_t u_end = u + L;
-  if (u_end > n_units) u_end = n_units;
+  const uint64_t e_begin64 = slot * L * UNIT;
+  uint64_t e_end64 = (slot + 1) * L * UNIT;
+  if (e_end64 > E) e_end64 = E;
 
-  if (u < u_end) {
-    uint32_t e = (uint32_t)(u * UNIT);
+  if (e_begin64 < e_end64) {
+    uint32_t e = (uint32_t)e_begin64;
+    const uint32_t e_end = (uint32_t)e_end64;
     // bin b with P[b] <= e < P[b+1]
     int lo = 0, hi = W;  // invariant: P[lo] <= e < P[hi]
     while (hi - lo > 1) {
@@ -444,43 +459,24 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
     }
     int b = lo;
     uint32_t bin_start = P[b], bin_end = P[b + 1];
-    while (bin_end <= e && b + 1 < W) { ++b; bin_start = bin_end; bin_end = P[b + 1]; }
     uint32_t wide_end = bin_start + (uint32_t)max(NW[b], 0);
-
-    // --- replay-mode state
-    uint32_t lcg = 0;
-    uint32_t part_end = 0;   // first electron of the next emulated thread
-    int part = 0;
-    const int T = a.threads_compat;
-    auto part_start_of = [&](int t) -> uint32_t { return (uint32_t)(((long long)t * (long long)E) / T); };
-    if (RNG_MODE == 0) {
-      // thread t owns [t*E/T, (t+1)*E/T); the last one ends at E (:48-49)
-      part = (int)(((unsigned long long)e * (unsigned long long)T) / E);
-      if (part >= T) part = T - 1;
-      while (part > 0 && part_start_of(part) > e) --part;
-      while (part + 1 < T && part_start_of(part + 1) <= e) ++part;
-      const uint32_t ps = part_start_of(part);
-      part_end = (part == T - 1) ? E : part_start_of(part + 1);
-      lcg = lcg_jump((uint32_t)(25234 + 17 * part + si.replay_seed), 6ull * (uint64_t)(e - ps));
-    }
 
     if (RNG_MODE == 1) {
       float x = (float)XP[b], y = (float)YP[b];
       float sl = (float)a.sigl[b], sh = (float)a.sigh[b];
-      for (; u < u_end; ++u) {
-        const u32x4 r = philox4x32_10((uint32_t)u, (uint32_t)(u >> 32), (uint32_t)k + a.subsample0,
-                                      a.exposure, a.seed, STAGE_THROW);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (e >= E) break;
+      while (e < e_end) {
+        // one seeded stream per block of kThrowBlock electrons
+        SeededStream rng(a.seed, STAGE_THROW, e / kThrowBlock, (uint32_t)k + a.subsample0, a.exposure);
+        const uint32_t blk_end = min(e_end, (e / kThrowBlock + 1u) * kThrowBlock);
+        for (; e < blk_end; ++e) {
           if (e >= bin_end) {
             do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
             wide_end = bin_start + (uint32_t)max(NW[b], 0);
             x = (float)XP[b]; y = (float)YP[b];
             sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
           }
-          const float ua = u01f(h == 0 ? r.v[0] : r.v[2]);
-          const float ub = u01f(h == 0 ? r.v[1] : r.v[3]);
+          const float ua = u01f(rng.next());
+          const float ub = u01f(rng.next());
           // R = sqrt(-2 ln ub) = sqrt(-2 ln2 log2 ub); sin/cos take revolutions
           const float R = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
           const float zx = R * __builtin_amdgcn_cosf(ua);
@@ -488,26 +484,35 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
           const float sig = (e < wide_end) ? sh : sl;   // first N electrons: wide gaussian (:89-98)
           const int xi = (int)fmaf(zx, sig, x);          // C truncation toward zero (:91-92)
           const int yi = (int)fmaf(zy, sig, y);
-          if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) {   // (:93)
-            const int lx = xi - tx0, ly = yi - ty0;
-            if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-              atomicAdd(&tile[ly * tw + lx], 1);
-            else
-              deposit_global<FLUSH>(a, si, xi, yi, 1);
-          }
-          ++e;
+          const int lx = xi - tx0, ly = yi - ty0;
+          // the tile lies inside [1, N) x [1, N), so this one test implies the
+          // reference's 0 < pos < n bounds (:93) on the fast path
+          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+            atomicAdd(&tile[ly * tw + lx], 1);
+          else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
+            deposit_global<FLUSH>(a, si, xi, yi, 1);
         }
       }
     } else {
+      // replay: electron i belongs to the emulated OpenMP thread t that owns
+      // [t*E/T, (t+1)*E/T) (the last one ends at E, :48-49)
+      const int T = a.threads_compat;
+      auto part_start_of = [&](int t) -> uint32_t { return (uint32_t)(((long long)t * (long long)E) / T); };
+      int part = (int)(((unsigned long long)e * (unsigned long long)T) / E);
+      if (part >= T) part = T - 1;
+      while (part > 0 && part_start_of(part) > e) --part;
+      while (part + 1 < T && part_start_of(part + 1) <= e) ++part;
+      uint32_t part_end = (part == T - 1) ? E : part_start_of(part + 1);
+      uint32_t lcg = lcg_jump((uint32_t)(25234 + 17 * part + si.replay_seed), 6ull * (uint64_t)(e - part_start_of(part)));
       double x = XP[b], y = YP[b];
       double sl = a.sigl[b], sh = a.sigh[b];
-      for (; u < u_end; ++u, ++e) {
+      for (; e < e_end; ++e) {
         if (e >= bin_end) {
           do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
           wide_end = bin_start + (uint32_t)max(NW[b], 0);
           x = XP[b]; y = YP[b]; sl = a.sigl[b]; sh = a.sigh[b];
         }
-        if (e >= part_end) {
+        while (e >= part_end && part + 1 < T) {   // next emulated thread: fresh stream
           ++part;
           part_end = (part == T - 1) ? E : part_start_of(part + 1);
           lcg = (uint32_t)(25234 + 17 * part + si.replay_seed);
@@ -523,13 +528,11 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
         const bool okx = (px > -2147483649.0 && px < 2147483648.0);
         const bool oky = (py > -2147483649.0 && py < 2147483648.0);
         const int xi = okx ? (int)px : -1, yi = oky ? (int)py : -1;
-        if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) {
-          const int lx = xi - tx0, ly = yi - ty0;
-          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-            atomicAdd(&tile[ly * tw + lx], 1);
-          else
-            deposit_global<FLUSH>(a, si, xi, yi, 1);
-        }
+        const int lx = xi - tx0, ly = yi - ty0;
+        if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+          atomicAdd(&tile[ly * tw + lx], 1);
+        else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
+          deposit_global<FLUSH>(a, si, xi, yi, 1);
       }
     }
   }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void k_cosmic(CosmicArgs a) {
     // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
     const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
     PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
-    double n = poisson<double>(rate_size * a.read_dt[r], rng);
+    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
     if (!(n >= 0.)) n = 0.;
     if (n > 1e7) n = 1e7;
     s_n = (uint32_t)n;
@@ -600,13 +603,24 @@ struct RampArgs {
   void* out;                 // [(R+1)*S*S] float or double
 };
 
-__device__ __forceinline__ void normal_pair(uint32_t seed, uint32_t stage, uint32_t p, uint32_t r,
-                                            uint32_t exposure, float& z0, float& z1) {
-  const u32x4 w = philox4x32_10(p, 0u, r, exposure, seed, stage);
-  const float ua = u01f(w.v[0]), ub = u01f(w.v[1]);
-  const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
-  z0 = Rr * __builtin_amdgcn_cosf(ua);
-  z1 = Rr * __builtin_amdgcn_sinf(ua);
+constexpr int kRampThreads = 256;
+constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
+
+// Box-Muller pair from two words.  EXACT mirrors the oracle's libm formula;
+// FAST uses the hardware units (sin / cos take revolutions, log is log2).
+template <bool FAST>
+__device__ __forceinline__ void bm_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
+  const float ua = u01f(w0), ub = u01f(w1);
+  if (FAST) {
+    const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
+    z0 = Rr * __builtin_amdgcn_cosf(ua);
+    z1 = Rr * __builtin_amdgcn_sinf(ua);
+  } else {
+    const float Rr = sqrtf(-2.0f * logf(ub));
+    const float ang = 6.283185307179586f * ua;
+    z0 = Rr * cosf(ang);
+    z1 = Rr * sinf(ang);
+  }
 }
 
 __device__ __forceinline__ double nonlinear_response(double px, float c1, float c2, float c3, float c4) {
@@ -615,28 +629,88 @@ __device__ __forceinline__ double nonlinear_response(double px, float c1, float 
   // The reference iterates the whole frame until its slowest pixel converges;
   // here each pixel stops on its own criterion (the extra iterations move a
   // converged pixel by < 1e-9).  (1 + c1), 2*c2, 3*c3, 4*c4 are float32 in
-  // the reference because the coefficient planes are.
+  // the reference because the coefficient planes are.  The residual is
+  // evaluated in fp64; the reciprocal of the derivative (within 2e-7 of
+  // 1 + small) in fp32, which changes an iterate by < 1e-7 of its step.
   const double k1 = (double)(1.0f + c1);
   const double k2 = (double)c2, k3 = (double)c3, k4 = (double)c4;
-  const double d2 = (double)(2.0f * c2), d3 = (double)(3.0f * c3), d4 = (double)(4.0f * c4);
+  const float d1 = 1.0f + c1, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
   double u0 = px, u1 = px;
   for (int it = 0; it < 10000; ++it) {
-    const double f = -px + u0 * (k1 + u0 * (k2 + u0 * (k3 + k4 * u0)));
-    const double fp_ = k1 + d2 * u0 + d3 * u0 * u0 + d4 * u0 * u0 * u0;
-    u1 = u0 - f / fp_;
-    if (fabs(u1 - u0) < 1e-3) break;
+    const double f = fma(u0, fma(u0, fma(u0, fma(k4, u0, k3), k2), k1), -px);
+    const float uf = (float)u0;
+    const float fp_ = fmaf(uf, fmaf(uf, fmaf(uf, d4, d3), d2), d1);
+    const double step = f * (double)__builtin_amdgcn_rcpf(fp_);
+    u1 = u0 - step;
+    if (fabs(step) < 1e-3) break;
     u0 = u1;
   }
   return u1;
 }
 
-template <class OutT>
-__global__ __launch_bounds__(256) void k_ramp(RampArgs a) {
+// Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
+// (exposure_generator.py:488-495), from the pixel's seeded stream, written to
+// LDS.  Lanes advance through their reads independently ("lane-asynchronous"):
+// a lane whose trial is rejected retries while its neighbours move on to their
+// next read, so a wave runs ~R * 1.15 trial rounds instead of R * (the slowest
+// of 64 lanes).  The per-pixel draw sequence is sequential, so the result does
+// not depend on this scheduling.
+template <bool FAST>
+__device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int tid, bool active, float skyv,
+                                           const float* s_c, uint32_t (*s_sky)[kRampThreads]) {
+  typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
+  SeededStream rng(a.seed, STAGE_SKY, p, 0u, a.exposure);
+  int r = 0, mode = 0, guard = 0;
+  PtrsSetup<M> ps;
+  ps.lam = ps.b = ps.a = ps.vr = ps.loglam = ps.invalpha = 0.f;
+  float prod = 1.f, enlam = 0.f, kk = 0.f, lam = 0.f;
+  const int R = a.R;
+  while (__any(active)) {
+    if (active) {
+      float done = -1.f;
+      if (mode == 0) {
+        // master_sky *= bg_count is an in-place float32 multiply (:493)
+        lam = skyv * s_c[r];
+        if (!(lam > 0.f)) {
+          done = 0.f;
+        } else if (lam < 10.f) {
+          enlam = M::exp_(-lam); prod = 1.f; kk = 0.f; mode = 1;
+        } else if (lam < 256.f) {
+          ps.init(lam); mode = 2;
+        } else {
+          done = (float)poisson<ExactMath<double> >((double)lam, rng);   // rare: long reads
+        }
+      }
+      if (mode == 1) {
+        prod = prod * M::u01(rng.next());
+        if (prod > enlam) kk = kk + 1.f; else done = kk;
+      } else if (mode == 2) {
+        const uint32_t w1 = rng.next();
+        const uint32_t w2 = rng.next();
+        float k;
+        if (ps.trial(w1, w2, k)) done = k;
+      }
+      if (++guard > 64 + 600 * kMaxReads && done < 0.f) done = floorf(lam + 0.5f);   // unreachable safety net
+      if (done >= 0.f) {
+        s_sky[r][tid] = (uint32_t)done;
+        mode = 0;
+        if (++r >= R) active = false;
+      }
+    }
+  }
+}
+
+template <class OutT, bool FAST>
+__global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
+  __shared__ uint32_t s_sky[kMaxReads][kRampThreads];
+  __shared__ float s_c[kMaxReads + 1];
   const int S = a.S;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= S * S) return;
+  const int tid = threadIdx.x;
+  const int p_raw = blockIdx.x * blockDim.x + tid;
+  const bool valid = p_raw < S * S;
+  const int p = valid ? p_raw : 0;
   const int Y = p / S, X = p - Y * S;
-  const bool interior = (X >= kBorder && X < S - kBorder && Y >= kBorder && Y < S - kBorder);
+  const bool interior = valid && (X >= kBorder && X < S - kBorder && Y >= kBorder && Y < S - kBorder);
   const size_t SS = (size_t)S * S;
   OutT* out = (OutT*)a.out;
   const bool clip = (a.flags & (1u << 3)) != 0;
@@ -645,6 +719,18 @@ __global__ __launch_bounds__(256) void k_ramp(RampArgs a) {
   const bool do_lin = (a.flags & (1u << 2)) != 0 && a.lin[0];
   const bool gainvar = (a.flags & (1u << 1)) != 0 && a.pfl;
   const bool do_noise = (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
+  const bool do_sky = a.sky_ct_s > 0. && a.sky;
+
+  if (tid < a.R) s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);        // bg_count of read tid (:489-491)
+  float skyv = 0.f;
+  if (interior && do_sky) skyv = a.sky[p];
+  __syncthreads();
+  if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c, s_sky);
+  __syncthreads();
+  if (!valid) return;
+
+  SeededStream rn(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  SeededStream rg(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
 
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
@@ -653,53 +739,47 @@ __global__ __launch_bounds__(256) void k_ramp(RampArgs a) {
   if (!interior) z = 0.;
   {
     float zd, zr;
+    const uint32_t w0 = rn.next(), w1 = rn.next();
     double v = z;
-    if (rdn) { normal_pair(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure, zd, zr); v = v + kReadNoise * (double)zr; }
+    if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }
     out[p] = (OutT)v;
   }
 
   // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
-  // (detector.py:203-204), or the constant (exposure_generator.py:507-511)
-  double g = kGain;
+  // (detector.py:203-204), or the constant (exposure_generator.py:507-511);
+  // applied as a multiplication by its fp64 reciprocal
+  double inv_g = 1.0 / kGain;
   float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-  float skyv = 0;
-  if (interior) {
-    if (gainvar) g = (double)(2.35f / a.pfl[p]);
-    if (a.sky_ct_s > 0. && a.sky) skyv = a.sky[p];
-  }
+  if (interior && gainvar) inv_g = 1.0 / (double)(2.35f / a.pfl[p]);
   if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
 
   double cum = 0.;
   for (int r = 0; r < a.R; ++r) {
     double px = 0.;
+    const uint32_t g0 = do_noise ? rg.next() : 0u, g1 = do_noise ? rg.next() : 0u;
     if (interior) {
       long long* ap = &a.acc[(size_t)r * SS + p];
       const long long q = *ap;
       *ap = 0;                       // leave the accumulator clean for the next exposure
       px = (double)q * kInvQ;
-      const double dt = a.read_dt[r];
       if (do_noise) {                // _gen_noise (:477-484, :712-727)
+        const double dt = a.read_dt[r];
         float z0, z1;
-        normal_pair(a.seed, STAGE_NOISE, (uint32_t)p, (uint32_t)r, a.exposure, z0, z1);
+        bm_pair<FAST>(g0, g1, z0, z1);
         px = px + (a.noise_mean * dt + (a.noise_std * dt) * (double)z0);
       }
-      if (skyv > 0.f) {
-        // master_sky *= bg_count is an in-place float32 multiply (:493)
-        const float lam = skyv * (float)(a.sky_ct_s * dt);
-        PhiloxStream rng(a.seed, STAGE_SKY, (uint32_t)p, (uint32_t)r, a.exposure);
-        const double ns = (lam < 256.f) ? (double)poisson<float>(lam, rng) : poisson<double>((double)lam, rng);
-        px = px + ns;                // (:495)
-      }
-      px = px / g;                   // electrons -> DN (:507-511)
+      if (skyv > 0.f) px = px + (double)s_sky[r][tid];   // += np.random.poisson(master_sky) (:495)
+      px = px * inv_g;               // electrons -> DN (:507-511)
     }
     cum = cum + px;                  // cumulative_pixel_array += pixel_array_full (:378)
     double v = cum;
     float zd = 0.f, zr = 0.f;
-    if (rdn || do_dark) normal_pair(a.seed, STAGE_READ, (uint32_t)p, (uint32_t)(r + 1), a.exposure, zd, zr);
+    const uint32_t w0 = rn.next(), w1 = rn.next();
+    if (rdn || (do_dark && interior)) bm_pair<FAST>(w0, w1, zd, zr);
     if (interior) {
       if (do_dark) {                 // detector.py:185-191
         const float de = a.dark_err[(size_t)r * SS + p];
-        const double err = (de > 0.f) ? (double)de : 0.00001;
+        const double err = (de > 0.f) ? (double)de : (double)0.00001f;
         v = v + ((double)a.dark_sci[(size_t)r * SS + p] + err * (double)zd);
       }
       if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4);

@@ -17,16 +17,24 @@
 namespace wayne {
 
 // RNG stages: key = (seed, stage); counter = (c0, c1, c2, c3) as commented.
+// "Philox stream" stages read consecutive Philox blocks (c1 = block index).
+// "seeded stream" stages use ONE Philox block as the 128-bit state of a short
+// xoshiro128+ sequence (Blackman & Vigna 2018): the bulk draws -- one stream
+// per 128 thrown electrons, one per pixel -- cost ~8 full-rate VALU ops per
+// word instead of Philox's five quarter-rate 32x32->64 multiplies, and are
+// still a pure function of (seed, stage, exposure, element): independent of
+// sharding and launch geometry.
 enum Stage : uint32_t {
-  STAGE_COUNTS = 1,   // (bin w, draw block, sub-sample k, exposure)  stellar Poisson
-  STAGE_THROW = 2,    // (pair lo, pair hi, sub-sample k, exposure)   electron thrower
-  STAGE_SKY = 3,      // (pixel, draw block, read r, exposure)        sky Poisson
-  STAGE_CR_COUNT = 4, // (0, draw block, read r, exposure)            number of cosmic hits
-  STAGE_CR_HIT = 5,   // (hit i, 0, read r, exposure)                 energy, y, x of hit i
-  STAGE_READ = 6,     // (pixel, 0, read r, exposure)                 dark + read-noise normals
-  STAGE_NOISE = 7,    // (pixel, 0, read r, exposure)                 optional gaussian noise
-  STAGE_HOST = 8,     // (sub-sample k, 0, 0, exposure)               jitter x/y, replay seed
+  STAGE_COUNTS = 1,   // Philox stream (bin w, block, sub-sample k, exposure)     stellar Poisson
+  STAGE_THROW = 2,    // seeded stream (electron block e>>7, 0, sub-sample k, exposure): words 2j, 2j+1 -> electron j of the block
+  STAGE_SKY = 3,      // seeded stream (pixel, 0, 0, exposure): sky Poisson draws of reads 0..R-1 in order
+  STAGE_CR_COUNT = 4, // Philox stream (0, block, read r, exposure)               number of cosmic hits
+  STAGE_CR_HIT = 5,   // Philox block  (hit i, 0, read r, exposure)               energy, y, x of hit i
+  STAGE_READ = 6,     // seeded stream (pixel, 0, 0, exposure): words 2i, 2i+1 -> (dark, read-noise) normals of read i (0 = zero read)
+  STAGE_NOISE = 7,    // seeded stream (pixel, 0, 0, exposure): words 2r, 2r+1 -> optional gaussian noise of read interval r
+  STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
 };
+constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 
 struct u32x4 {
   uint32_t v[4];
@@ -79,6 +87,26 @@ struct PhiloxStream {
     const uint32_t i = 4 - have;
     --have;
     return i == 0 ? buf.v[0] : i == 1 ? buf.v[1] : i == 2 ? buf.v[2] : buf.v[3];
+  }
+};
+
+// xoshiro128+ seeded from one Philox block.
+struct SeededStream {
+  uint32_t s0, s1, s2, s3;
+  WAYNE_HD SeededStream(uint32_t seed, uint32_t stage, uint32_t c0, uint32_t c2, uint32_t c3) {
+    const u32x4 b = philox4x32_10(c0, 0u, c2, c3, seed, stage);
+    s0 = b.v[0]; s1 = b.v[1]; s2 = b.v[2]; s3 = b.v[3];
+  }
+  WAYNE_HD uint32_t next() {
+    const uint32_t result = s0 + s3;
+    const uint32_t t = s1 << 9;
+    s2 ^= s0;
+    s3 ^= s1;
+    s1 ^= s2;
+    s0 ^= s3;
+    s2 ^= t;
+    s3 = (s3 << 11) | (s3 >> 21);
+    return result;
   }
 };
 

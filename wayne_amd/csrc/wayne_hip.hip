@@ -345,8 +345,8 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     const int margin = 20;
     if (xmax >= xmin) {
       auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
-      int x0 = std::max(clampi(std::floor(xmin)) - margin, 0), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
-      int y0 = std::max(clampi(std::floor(ymin)) - margin, 0), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
+      int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
+      int y0 = std::max(clampi(std::floor(ymin)) - margin, 1), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
       if (x1 > x0 && y1 > y0) {
         int tw = x1 - x0, th = y1 - y0;
         while ((long long)tw * th > lds_ints && th > 1) { y0 += 1; th = std::max(th - 2, 1); }
@@ -423,7 +423,7 @@ int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
   const int sub = k->subarray;
   if (sub != 64 && sub != 128 && sub != 256 && sub != 512 && sub != 1024)
     return fail(c, WAYNE_E_INVALID, "set_calibration: SUBARRAY must be 64,128,256,512 or 1024");
-  if (k->n_reads < 1 || k->n_reads > 15) return fail(c, WAYNE_E_INVALID, "set_calibration: n_reads must be 1..15");
+  if (k->n_reads < 1 || k->n_reads > kMaxReads) return fail(c, WAYNE_E_INVALID, "set_calibration: n_reads must be 1..15");
   (void)hipSetDevice(c->device);
   const int N = side_of(sub), S = N + 2 * kBorder;
   const size_t NN = (size_t)N * N, SS = (size_t)S * S;
@@ -637,14 +637,15 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
-  const int threads = 256;
+  const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
     ProfScope ps(c, PK_RAMP);
-    if (d.flags & WAYNE_F_OUT_F64)
-      hipLaunchKernelGGL(k_ramp<double>, dim3(blocks), dim3(threads), 0, c->stream, a);
-    else
-      hipLaunchKernelGGL(k_ramp<float>, dim3(blocks), dim3(threads), 0, c->stream, a);
+    const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
+    if (f64 && exact) hipLaunchKernelGGL((k_ramp<double, false>), dim3(blocks), dim3(threads), 0, c->stream, a);
+    else if (f64) hipLaunchKernelGGL((k_ramp<double, true>), dim3(blocks), dim3(threads), 0, c->stream, a);
+    else if (exact) hipLaunchKernelGGL((k_ramp<float, false>), dim3(blocks), dim3(threads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ramp<float, true>), dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
   s.acc_dirty = false;

@@ -107,7 +107,7 @@ class ExposureGenerator(object):
                        clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                        add_initial_bias=True, progress_bar=None, threads=2,
                        rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False,
-                       record=None):
+                       record=None, exact_samplers=False):
         """Generate a spatially scanned exposure (exposure_generator.py:178-405).
 
         Extra keywords (not in the reference): `rng_mode` (RNG_PHILOX production
@@ -116,7 +116,10 @@ class ExposureGenerator(object):
         float64 reads; `reference_quirks` keeps the reference's -5 px frame
         offset at SUBARRAY=1024 (exposure_generator.py:630); `record`, if a dict,
         receives the device's intermediate products (counts, x, y per bin and
-        sub-sample; electrons accumulated per read interval) for parity tests.
+        sub-sample; electrons accumulated per read interval) for parity tests;
+        `exact_samplers` evaluates the per-pixel Poisson / normal draws with IEEE
+        divide / sqrt and accurate log / exp / sin / cos instead of the hardware
+        approximations (same algorithm and streams; for parity runs).
         """
         start_time = time.time()
         eng = _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP,
@@ -126,7 +129,7 @@ class ExposureGenerator(object):
             sample_mid_points, sample_durations, read_index, ssv_generator, noise_mean, noise_std, add_dark,
             add_flat, cosmic_rate, sky_background, scale_factor, add_gain_variations, add_non_linear,
             clip_values_det_limits, add_read_noise, add_stellar_noise, add_initial_bias, progress_bar, threads,
-            rng_mode, out_dtype, reference_quirks)
+            rng_mode, out_dtype, reference_quirks, exact_samplers)
         R = len(self.read_times)
         read_dt = self._read_dt
         if record is None:
@@ -155,7 +158,8 @@ class ExposureGenerator(object):
                          scale_factor=None, add_gain_variations=True, add_non_linear=True,
                          clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                          add_initial_bias=True, progress_bar=None, threads=2,
-                         rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False):
+                         rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False,
+                         exact_samplers=False):
         """The host half of scanning_frame: sample timing, scan positions, SSV,
         jitter / seed draws, spectrum crop (exposure_generator.py:247-334) ->
         one wayne_exposure_desc for the device.  Pure host code (`eng` may be
@@ -220,7 +224,8 @@ class ExposureGenerator(object):
                         (add_non_linear, _lib.F_ADD_NON_LINEAR), (clip_values_det_limits, _lib.F_CLIP_DET_LIMITS),
                         (add_read_noise, _lib.F_ADD_READ_NOISE), (add_stellar_noise, _lib.F_ADD_STELLAR_NOISE),
                         (add_dark, _lib.F_ADD_DARK), (add_initial_bias, _lib.F_ADD_INITIAL_BIAS),
-                        (np.dtype(out_dtype) == np.float64, _lib.F_OUT_F64)):
+                        (np.dtype(out_dtype) == np.float64, _lib.F_OUT_F64),
+                        (exact_samplers, _lib.F_EXACT_SAMPLERS)):
             if on:
                 flags |= bit
         # frame offset 507 - SUBARRAY/2 (:630).  At 1024 the reference gets -5,
