@@ -54,8 +54,8 @@ static uint32_t wo_next(wo_stream *s) {
   return v;
 }
 
-static float wo_u01f(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
-static double wo_u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+static float wo_u01f(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
+static double wo_u01d(uint32_t x) { return fma((double)x, 2.3283064365386963e-10, 1.1641532182693481e-10); }
 
 /* ---- ln Gamma via shift + Stirling, double and float ------------------- */
 static double wo_loggam_d(double x) {

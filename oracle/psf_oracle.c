@@ -140,11 +140,11 @@ void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2],
  * read, exposure). */
 enum { WO_STAGE_THROW = 2 };
 
-/* u32 -> uniform in (0,1): (x + 0.5) * 2^-32, evaluated in fp32 exactly as
- * the device does (the product rounds to nearest fp32; never 0, may be 1.0f
- * only for x >= 0xFFFFFF80 where logf gives 0 -> R = 0, a valid draw). */
+/* u32 -> uniform in (0,1]: x * 2^-32 + 2^-33 as one fused multiply-add, exactly
+ * as the device does (never 0; 1.0f only for x >= 0xFFFFFF80, where logf
+ * gives 0 -> R = 0, a valid draw). */
 static inline float wo_u01(uint32_t x) {
-  return ((float)x + 0.5f) * 2.3283064365386963e-10f;
+  return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
 /* xoshiro128+ (Blackman & Vigna, 2018; public domain algorithm), the

@@ -398,8 +398,9 @@ class PhiloxDraws(object):
 
     def sample_draws(self, K, x_jitter, y_jitter):
         w = self._blocks(np.arange(K), 0, 0, STAGE_HOST)
-        ua = (w[:, 0].astype(np.float64) + 0.5) * 2.3283064365386963e-10
-        ub = (w[:, 1].astype(np.float64) + 0.5) * 2.3283064365386963e-10
+        # x * 2^-32 + 2^-33 (a fused multiply-add on the host side; exact here: < 2^53)
+        ua = w[:, 0].astype(np.float64) * 2.3283064365386963e-10 + 1.1641532182693481e-10
+        ub = w[:, 1].astype(np.float64) * 2.3283064365386963e-10 + 1.1641532182693481e-10
         R = np.sqrt(-2.0 * np.log(ub))
         ang = 6.283185307179586476925 * ua
         seeds = ((w[:, 2].astype(np.uint64) * np.uint64(100000)) >> np.uint64(32)).astype(np.int64)

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
           // the tile lies inside [1, N) x [1, N), so this one test implies the
           // reference's 0 < pos < n bounds (:93) on the fast path
           if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-            atomicAdd(&tile[ly * tw + lx], 1);
+            atomicAdd(&tile[__umul24(ly, tw) + lx], 1);   // tile area < 2^14: 24-bit multiply-add
           else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
             deposit_global<FLUSH>(a, si, xi, yi, 1);
         }
@@ -753,14 +753,26 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
   if (interior && gainvar) inv_g = 1.0 / (double)(2.35f / a.pfl[p]);
   if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
 
+  // software-pipelined ramp: the planes of read r+1 are requested before the
+  // (VALU-heavy) work on read r so that HBM latency hides behind it
+  long long* __restrict__ accp = a.acc + p;
+  const float* __restrict__ dsp = a.dark_sci ? a.dark_sci + p : nullptr;
+  const float* __restrict__ dep = a.dark_err ? a.dark_err + p : nullptr;
+  const bool ld_dark = do_dark && interior;
+  long long q_next = interior ? accp[0] : 0;
+  float ds_next = ld_dark ? dsp[0] : 0.f, de_next = ld_dark ? dep[0] : 0.f;
   double cum = 0.;
   for (int r = 0; r < a.R; ++r) {
+    const long long q = q_next;
+    const float ds = ds_next, de = de_next;
+    if (r + 1 < a.R) {
+      if (interior) q_next = accp[(size_t)(r + 1) * SS];
+      if (ld_dark) { ds_next = dsp[(size_t)(r + 1) * SS]; de_next = dep[(size_t)(r + 1) * SS]; }
+    }
     double px = 0.;
     const uint32_t g0 = do_noise ? rg.next() : 0u, g1 = do_noise ? rg.next() : 0u;
     if (interior) {
-      long long* ap = &a.acc[(size_t)r * SS + p];
-      const long long q = *ap;
-      *ap = 0;                       // leave the accumulator clean for the next exposure
+      accp[(size_t)r * SS] = 0;      // leave the accumulator clean for the next exposure
       px = (double)q * kInvQ;
       if (do_noise) {                // _gen_noise (:477-484, :712-727)
         const double dt = a.read_dt[r];
@@ -775,12 +787,11 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
     double v = cum;
     float zd = 0.f, zr = 0.f;
     const uint32_t w0 = rn.next(), w1 = rn.next();
-    if (rdn || (do_dark && interior)) bm_pair<FAST>(w0, w1, zd, zr);
+    if (rdn || ld_dark) bm_pair<FAST>(w0, w1, zd, zr);
     if (interior) {
       if (do_dark) {                 // detector.py:185-191
-        const float de = a.dark_err[(size_t)r * SS + p];
         const double err = (de > 0.f) ? (double)de : (double)0.00001f;
-        v = v + ((double)a.dark_sci[(size_t)r * SS + p] + err * (double)zd);
+        v = v + ((double)ds + err * (double)zd);
       }
       if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4);
       if (clip) v = fmin(fmax(v, kMinCounts), kMaxCounts);

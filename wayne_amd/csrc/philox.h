@@ -6,6 +6,7 @@
 // of (seed, stage, exposure, sub-sample | read, element), so results do not
 // depend on how exposures are sharded over GPUs or on launch geometry.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -60,9 +61,10 @@ WAYNE_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
   return o;
 }
 
-// uint32 -> uniform in (0, 1]: (x + 0.5) * 2^-32 in fp32 / fp64.
-WAYNE_HD float u01f(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
-WAYNE_HD double u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+// uint32 -> uniform in (0, 1]: x * 2^-32 + 2^-33 as ONE fused multiply-add
+// (cvt + fma on the device), fp32 / fp64.
+WAYNE_HD float u01f(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
+WAYNE_HD double u01d(uint32_t x) { return fma((double)x, 2.3283064365386963e-10, 1.1641532182693481e-10); }
 
 // uniform integer in [0, n) by multiply-shift (bias <= n / 2^32).
 WAYNE_HD uint32_t uint_below(uint32_t x, uint32_t n) {

@@ -32,6 +32,10 @@ template <> struct ExactMath<float> {
   static WAYNE_HD float floor_(float x) { return floorf(x); }
   static WAYNE_HD float abs_(float x) { return fabsf(x); }
   static WAYNE_HD float div_(float a, float b) { return a / b; }
+  // PTRS acceptance: log V + log(1/alpha) - log(a/us^2 + b) <= rhs
+  static WAYNE_HD bool accept(float V, float invalpha, float den, float rhs) {
+    return logf(V) + logf(invalpha) - logf(den) <= rhs;
+  }
 };
 template <> struct ExactMath<double> {
   typedef double type;
@@ -42,6 +46,9 @@ template <> struct ExactMath<double> {
   static WAYNE_HD double floor_(double x) { return floor(x); }
   static WAYNE_HD double abs_(double x) { return fabs(x); }
   static WAYNE_HD double div_(double a, double b) { return a / b; }
+  static WAYNE_HD bool accept(double V, double invalpha, double den, double rhs) {
+    return log(V) + log(invalpha) - log(den) <= rhs;
+  }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -54,6 +61,10 @@ struct FastMath {
   static __device__ __forceinline__ float floor_(float x) { return floorf(x); }
   static __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
   static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  // the three logs folded into one: log(V * invalpha / den)
+  static __device__ __forceinline__ bool accept(float V, float invalpha, float den, float rhs) {
+    return log_(V * invalpha * __builtin_amdgcn_rcpf(den)) <= rhs;
+  }
 };
 #else
 typedef ExactMath<float> FastMath;   // host pass: never executed
@@ -102,9 +113,7 @@ struct PtrsSetup {
     k = M::floor_((M::div_((T)2 * a, us) + b) * U + lam + (T)0.43);
     if (us >= (T)0.07 && V <= vr) return true;
     if (k < (T)0 || (us < (T)0.013 && V > us)) return false;
-    const T lhs = M::log_(V) + M::log_(invalpha) - M::log_(M::div_(a, us * us) + b);
-    const T rhs = -lam + k * loglam - loggam<M>(k + (T)1);
-    return lhs <= rhs;
+    return M::accept(V, invalpha, M::div_(a, us * us) + b, -lam + k * loglam - loggam<M>(k + (T)1));
   }
 };
 
