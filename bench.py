@@ -128,7 +128,11 @@ def main():
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-f64", action="store_true", help="float64 reads (the reference's dtype)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="HIP streams in the timed region (1: kernels never co-run, so per-kernel event times are "
+                         "clean; the 2-stream rate is reported separately as two_streams)")
     args = ap.parse_args()
+    os.environ["WAYNE_STREAMS"] = "2"        # the context always owns two streams; slots select them
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -159,8 +163,8 @@ def main():
     visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=total * n_gpus)
     eng = engine.get_engine(local_rank, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
     ctx = eng.ctx
-    if total > 250:
-        raise SystemExit("at most 250 exposures (HBM slots) per rank per run")
+    if total > 125:
+        raise SystemExit("at most 125 exposures (HBM slots) per rank per run")
 
     from wayne_amd.exposure_generator import ExposureGenerator
     out_dtype = np.float64 if args.out_f64 else np.float32
@@ -170,7 +174,7 @@ def main():
         eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                device=local_rank, seed=visit.seed, exposure_index=i)
         desc = eg.build_descriptor(eng, out_dtype=out_dtype, **visit.frame_kwargs(i))
-        ctx.upload(j, desc)      # inputs resident in HBM before the timed region
+        ctx.upload(j * (1 if args.streams == 2 else 2), desc)      # inputs resident in HBM before the timed region
         W = desc.n_wl
     ctx.synchronize()
 
@@ -180,15 +184,21 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # slot j runs on stream j % 2: with --streams 1 only even slots are used
+    stride = 1 if args.streams == 2 else 2
+
+    def slot_of(j):
+        return j * stride
+
     for j in range(args.warmup):
-        ctx.run(j)
+        ctx.run(slot_of(j))
     sync_all()
     ctx.profile_enable(True)
     ctx.profile_reset()
     sync_all()
     t0 = time.perf_counter()
     for j in range(args.warmup, total):
-        ctx.run(j)
+        ctx.run(slot_of(j))
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -200,8 +210,28 @@ def main():
     prof = ctx.profile_get()
     ctx.profile_enable(False)
 
+    # extra pass: the same exposures alternating over the context's two HIP streams
+    # (prep / ramp of one exposure co-run with the thrower of another)
+    two = None
+    if args.streams == 1 and n_gpus == 1:
+        for j in range(total):
+            ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
+                                            device=local_rank, seed=visit.seed, exposure_index=rank + j * n_gpus
+                                            ).build_descriptor(eng, out_dtype=out_dtype,
+                                                               **visit.frame_kwargs(rank + j * n_gpus)))
+        for j in range(args.warmup):
+            ctx.run(j)
+        sync_all()
+        t1 = time.perf_counter()
+        for j in range(args.warmup, total):
+            ctx.run(j)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        two = args.steps / (time.perf_counter() - t1)
+        stride = 1
+
     # sanity: the last exposure really produced a frame
-    reads = ctx.download(total - 1)
+    reads = ctx.download(slot_of(total - 1) if two is None else total - 1)
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
 
     if rank == 0:
@@ -237,7 +267,15 @@ def main():
             "kernels_ms_per_exposure": {k: v["ms"] / max(args.steps, 1) for k, v in prof.items() if k != "electrons"},
             "thrower": {"electrons_per_exposure": electrons, "ms": throw_ms,
                         "electrons_per_s": electrons / (throw_ms * 1e-3) if throw_ms > 0 else None},
+            "two_streams": None if two is None else {"value": two, "unit": "exposures/s",
+                                                     "note": "same exposures alternating over two HIP streams"},
         }
+        traffic_file = os.path.join(ROOT, "profiles", "k_ramp_traffic.json")
+        if os.path.exists(traffic_file):
+            t = json.load(open(traffic_file)).get("%s/%s" % (args.config, "f64" if args.out_f64 else "f32"))
+            if t:
+                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = t["source"]
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline(visit)
         else:

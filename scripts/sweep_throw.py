@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Sweep the thrower's launch geometry (workgroups per exposure, LDS tile size, margin) on cfg4."""
+import itertools
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
+from wayne_amd.exposure_generator import ExposureGenerator  # noqa: E402
+
+cal = calibration.CalibrationSet.synthetic(11)
+det = detector.WFC3_IR()
+gr = grism.G141(cal)
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+v = synthetic.Visit(name, det, gr, cal, n_exposures=1)
+eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+ctx = eng.ctx
+eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
+for wgs, tile, margin in itertools.product([256, 512, 768, 1024, 1536], [10240, 12288, 16384, 20000], [24]):
+    os.environ["WAYNE_THROW_WGS"] = str(wgs)
+    os.environ["WAYNE_TILE_INTS"] = str(tile)
+    desc = eg.build_descriptor(eng, **v.frame_kwargs(0))
+    desc.thrower_margin = margin
+    ctx.upload(0, desc)
+    ctx.run(0)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(4):
+        ctx.run(0)
+    p = ctx.profile_get()
+    ctx.profile_enable(False)
+    print("wgs=%5d tile=%6d margin=%2d  throw=%.3f ms" % (wgs, tile, margin, p["k_throw"]["ms"] / p["k_throw"]["launches"]),
+          flush=True)

@@ -76,9 +76,13 @@ constexpr int kSlots = 256;
 
 }  // namespace
 
+constexpr int kStreams = 2;   // exposures in even / odd slots run on different HIP streams
+
 struct wayne_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;          // stream of the call in progress (one of streams[])
+  hipStream_t streams[kStreams] = {nullptr, nullptr};
+  int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
   std::string err;
   // grism
   bool have_grism = false;
@@ -147,8 +151,17 @@ struct ProfScope {
   }
 };
 
+int sync_all(wayne_ctx* c) {
+  for (int i = 0; i < kStreams; ++i) HIP_TRY(c, hipStreamSynchronize(c->streams[i]));
+  return WAYNE_OK;
+}
+
+// slot-based calls work on the slot's stream; everything else on stream 0
+void use_slot_stream(wayne_ctx* c, int slot) { c->stream = c->streams[slot % c->n_streams]; }
+
 int collect_profile(wayne_ctx* c) {
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = sync_all(c);
+  if (rc) return rc;
   for (ProfRec& r : c->prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -182,7 +195,7 @@ std::vector<float> embed(const float* src, int N, int S, float fill) {
 int thrower_lds_ints(const wayne_ctx*) {
   const char* e = std::getenv("WAYNE_TILE_INTS");
   int v = e ? std::atoi(e) : 12288;  // 48 KiB: three 512-thread workgroups per CU
-  return std::min(std::max(v, 256), 16000);
+  return std::min(std::max(v, 256), 40000);  // <= 160 KB LDS
 }
 
 template <int RNG, int FLUSH>
@@ -241,13 +254,17 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
   wayne_ctx* c = new (std::nothrow) wayne_ctx();
   if (!c) { set(WAYNE_E_NOMEM); return nullptr; }
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete c;
-    set(WAYNE_E_HIP);
-    return nullptr;
-  }
+  for (int i = 0; i < kStreams; ++i)
+    if (hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipStreamDestroy(c->streams[j]);
+      delete c;
+      set(WAYNE_E_HIP);
+      return nullptr;
+    }
+  c->stream = c->streams[0];
+  if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
   if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
-    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
     delete c;
     set(WAYNE_E_NOMEM);
     return nullptr;
@@ -259,7 +276,7 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
 void wayne_ctx_destroy(wayne_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)sync_all(c);
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& s : c->slots) s.release();
@@ -268,7 +285,7 @@ void wayne_ctx_destroy(wayne_ctx* c) {
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
-  (void)hipStreamDestroy(c->stream);
+  for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
   delete c;
 }
 
@@ -276,11 +293,10 @@ const char* wayne_last_error(const wayne_ctx* c) { return c ? c->err.c_str() : "
 
 int wayne_ctx_synchronize(wayne_ctx* c) {
   if (!c) return WAYNE_E_INVALID;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return WAYNE_OK;
+  return sync_all(c);
 }
 
-void* wayne_ctx_stream(wayne_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* wayne_ctx_stream(wayne_ctx* c) { return c ? (void*)c->streams[0] : nullptr; }
 
 int wayne_ctx_slots(const wayne_ctx*) { return kSlots; }
 
@@ -304,6 +320,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     return fail(c, WAYNE_E_INVALID, "psf_apply: threads_compat must be >= 1 in replay mode");
   const int N = nr;
   (void)hipSetDevice(c->device);
+  c->stream = c->streams[0];
 
   // A1: ssum, with the reference's silent int overflows turned into errors
   long long total = 0;
@@ -342,7 +359,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     si.electrons = run;
     si.read = 0;
     si.replay_seed = (int)seed;
-    const int margin = 20;
+    const int margin = 24;
     if (xmax >= xmin) {
       auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
       int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
@@ -399,6 +416,7 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   if (g->n_sens < 0 || (g->n_sens > 0 && (!g->sens_wl_um || !g->sens_val)))
     return fail(c, WAYNE_E_INVALID, "set_grism: sensitivity table");
   (void)hipSetDevice(c->device);
+  c->stream = c->streams[0];
   int rc;
   if ((rc = upload(c, c->sens_wl, g->sens_wl_um, (size_t)g->n_sens))) return rc;
   if ((rc = upload(c, c->sens_val, g->sens_val, (size_t)g->n_sens))) return rc;
@@ -425,6 +443,8 @@ int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
     return fail(c, WAYNE_E_INVALID, "set_calibration: SUBARRAY must be 64,128,256,512 or 1024");
   if (k->n_reads < 1 || k->n_reads > kMaxReads) return fail(c, WAYNE_E_INVALID, "set_calibration: n_reads must be 1..15");
   (void)hipSetDevice(c->device);
+  { int rc0 = sync_all(c); if (rc0) return rc0; }   // no exposure may be in flight while planes change
+  c->stream = c->streams[0];
   const int N = side_of(sub), S = N + 2 * kBorder;
   const size_t NN = (size_t)N * N, SS = (size_t)S * S;
   int rc;
@@ -483,6 +503,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     if (d->sample_read[k] < 0 || d->sample_read[k] >= R) return fail(c, WAYNE_E_INVALID, "upload: sample_read out of range");
   if ((long long)K * W > 0x7FFFFFFFLL) return fail(c, WAYNE_E_INVALID, "upload: K*W too large");
   (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
   Slot& s = c->slots[slot];
   int rc;
   const size_t KW = (size_t)K * W;
@@ -532,6 +553,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   Slot& s = c->slots[slot];
   if (!s.uploaded) return fail(c, WAYNE_E_STATE, "run: slot not uploaded");
   (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
   const wayne_exposure_desc& d = s.d;
   const int W = s.W, K = s.K, R = s.R, N = c->N, S = c->S;
   const size_t SS = (size_t)S * S;
@@ -555,7 +577,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.g = c->g;
     a.W = W; a.K = K; a.N = N;
     a.sub_scale = d.sub_scale;
-    a.margin = d.thrower_margin > 0 ? d.thrower_margin : 20;
+    a.margin = d.thrower_margin > 0 ? d.thrower_margin : 24;   // ~4 sigma_h: sweep in scripts/sweep_throw.py
     a.max_tile = lds_ints;
     a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
     a.scale_factor = d.scale_factor;
@@ -580,7 +602,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     int splits = d.thrower_splits;
     if (splits <= 0) {
       const char* e = std::getenv("WAYNE_THROW_WGS");
-      const int target = e ? std::max(std::atoi(e), 1) : 1024;  // ~4 workgroups per CU
+      const int target = e ? std::max(std::atoi(e), 1) : 1536;  // ~6 workgroups per CU (measured optimum)
       splits = std::max(1, (target + K - 1) / K);
     }
     a.splits = std::min(splits, 4096);
@@ -619,6 +641,7 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   Slot& s = c->slots[slot];
   if (!s.uploaded || !s.front_done) return fail(c, WAYNE_E_STATE, "run_back: run_front first");
   (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
   const wayne_exposure_desc& d = s.d;
   const int S = c->S;
   RampArgs a{};
@@ -673,6 +696,7 @@ int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
   Slot& s = c->slots[slot];
   if (!s.uploaded) return fail(c, WAYNE_E_STATE, "download: slot not uploaded");
   (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
   const size_t SS = (size_t)c->S * c->S;
   const size_t out_elem = (s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
   HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
@@ -698,6 +722,7 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
   Slot& s = c->slots[slot];
   if (!s.uploaded) return fail(c, WAYNE_E_STATE, "debug_fetch: slot not uploaded");
   (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
   const size_t KW = (size_t)s.K * s.W;
   if (counts) HIP_TRY(c, hipMemcpyAsync(counts, s.counts.p, KW * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   if (x_pos) HIP_TRY(c, hipMemcpyAsync(x_pos, s.xpos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -727,9 +752,8 @@ int wayne_profile_reset(wayne_ctx* c) {
   if (rc) return rc;
   for (int i = 0; i < WAYNE_PROF_KERNELS; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; }
   c->electrons = 0;
-  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return WAYNE_OK;
+  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->streams[0]));
+  return sync_all(c);
 }
 
 int wayne_profile_get(wayne_ctx* c, wayne_profile* out) {
