@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 1
+#define WAYNE_ABI_VERSION 2
 
 /* status codes */
 #define WAYNE_OK 0
@@ -184,6 +184,16 @@ typedef struct wayne_exposure_desc {
 
   int thrower_margin; /* LDS tile margin in px around the trace; 0 = default   */
   int thrower_splits; /* workgroups per sub-sample; 0 = auto                   */
+
+  /* Device light curves (replaces the W pylightcurve calls per exposure of
+   * Observation.generate_lightcurves, observation.py:293-357).  When lc_z is
+   * not NULL, `depth` must be NULL and the K x W transit-depth matrix is
+   * computed on the device by k_lightcurve:
+   *   depth[k][w] = (1 - transit(z_k, rp_w, ld)) + (1 - eclipse(rp_w^2, hidden_k))      */
+  const double *lc_z;      /* [K] projected separation in stellar radii (>= 10: planet behind the star) */
+  const double *lc_hidden; /* [K] fraction of the planet's disk hidden by the star (eclipse), or NULL   */
+  const double *lc_rp;     /* [W] Rp/R* per bin = sqrt(planet_spectrum)                                  */
+  double lc_ld[4];         /* Claret 4-coefficient limb darkening                                        */
 } wayne_exposure_desc;
 
 /* Stage an exposure's inputs in HBM slot `slot` (0 <= slot < wayne_ctx_slots). */
@@ -213,6 +223,9 @@ int wayne_exposure_synthesize(wayne_ctx *ctx, const wayne_exposure_desc *d,
  * wayne_exposure_run_back (the ramp kernel clears it). */
 int wayne_exposure_debug_fetch(wayne_ctx *ctx, int slot, int32_t *counts,
                                double *x_pos, double *y_pos, double *acc_e);
+/* The K*W transit-depth matrix of `slot` (as uploaded, or as computed by k_lightcurve
+ * in the last run_front), for parity tests. */
+int wayne_exposure_debug_depth(wayne_ctx *ctx, int slot, double *depth);
 /* The two halves of wayne_exposure_run: front = prep + thrower + cosmic rays,
  * back = the fused up-the-ramp kernel. */
 int wayne_exposure_run_front(wayne_ctx *ctx, int slot);

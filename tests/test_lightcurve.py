@@ -1,0 +1,109 @@
+"""Light curves.  pylightcurve is not installed, so the model is
+pinned by the analytic uniform-disk formula, a brute-force 2-D integration and known limits."""
+import numpy as np
+import pytest
+
+from wayne_amd import lightcurve as lc
+
+LD = [0.800627, -0.757066, 0.897268, -0.384804]      # examples/...parameters.yml:26
+
+
+def test_uniform_star_matches_lens_formula():
+    for p in (0.05, 0.12, 0.3):
+        z = np.linspace(0, 1.4, 141)
+        num = lc.transit_flux(z, p, [0, 0, 0, 0])
+        ana = 1 - lc.uniform_overlap_fraction(z, p) * p * p
+        np.testing.assert_allclose(num, ana, rtol=0, atol=2e-9)   # 24-node rule; worst at exact internal contact
+
+
+def test_limb_darkened_against_brute_force():
+    def brute(z, p, n=1500):
+        xs = (np.arange(n) + 0.5) / n * 2 * p - p
+        X, Y = np.meshgrid(xs, xs)
+        r2 = (X + z) ** 2 + Y ** 2
+        ok = (X * X + Y * Y <= p * p) & (r2 < 1)
+        mu = np.sqrt(np.clip(1 - r2, 0, 1))
+        return 1 - (lc.claret_intensity(mu, LD) * ok).sum() * (2 * p / n) ** 2 / lc.stellar_flux_total(LD)
+    for z in (0.0, 0.4, 0.9, 1.0, 1.09):
+        assert abs(lc.transit_flux(z, 0.12, LD) - brute(z, 0.12)) < 5e-7
+
+
+def test_limits_and_node_convergence():
+    assert lc.transit_flux(1.2, 0.12, LD) == 1.0                       # no contact
+    assert lc.transit_flux(0.0, 1.0, LD) == pytest.approx(0.0, abs=1e-9)   # planet covers the star
+    z = np.linspace(0, 1.2, 61)
+    a = lc.transit_flux(z, 0.1215, LD)
+    x, w, d = lc.tanh_sinh_nodes(200, 4.0)
+    old = (lc._X, lc._W, lc._D)
+    lc._X, lc._W, lc._D = x, w, d
+    try:
+        b = lc.transit_flux(z, 0.1215, LD)
+    finally:
+        lc._X, lc._W, lc._D = old
+    assert np.abs(a - b).max() < 5e-10                                  # 24 nodes are converged
+    assert np.all(np.diff(a[z < 1.12]) >= -1e-12)                        # monotone from centre to limb
+
+
+def test_orbit_and_transit_timing():
+    P, a, inc, T0 = 3.524746, 0.047309 / (1.155 * 0.00465047), 86.71, 2456196.28836
+    t = T0 + np.linspace(-0.12, 0.12, 2001)
+    z, los = lc.planet_orbit(P, a, 0.0, inc, 0.0, T0, t)
+    assert abs(t[np.argmin(z)] - T0) < 2e-4 and los[1000] > 0
+    assert abs(z.min() - a * np.cos(np.radians(inc))) < 1e-9             # impact parameter
+    f = lc.transit(LD, 0.1209, P, a, 0.0, inc, 0.0, T0, t)
+    in_tr = t[f < 1 - 1e-9]
+    assert 0.11 < in_tr.max() - in_tr.min() < 0.14                       # T14 of HD 209458 b ~ 3 h
+    assert 0.0150 < 1 - f.min() < 0.0175
+    # half an orbit later the planet is behind the star: eclipse, no transit
+    t2 = t + P / 2
+    assert np.all(lc.transit(LD, 0.1209, P, a, 0.0, inc, 0.0, T0, t2) == 1.0)
+    e = lc.eclipse(1e-3, 0.1209, P, a, 0.0, inc, 0.0, T0, t2)
+    assert e.min() == pytest.approx(1 / 1.001, abs=1e-9) and e.max() == 1.0
+    # eccentric orbit: mid-transit still at T0
+    z, los = lc.planet_orbit(P, a, 0.3, inc, 40.0, T0, t)
+    assert abs(t[np.argmin(np.where(los > 0, z, 99))] - T0) < 5e-4
+
+
+def test_planet_depths_matrix():
+    spec = np.array([0.0144, 0.0146, 0.0149])
+    z_tr, hidden = np.array([0.3, 1.05, 11.0]), np.array([0.0, 0.0, 1.0])
+    d = lc.planet_depths(LD, spec, z_tr, hidden)
+    assert d.shape == (3, 3)
+    np.testing.assert_allclose(d[0], 1 - lc.transit_flux(0.3, np.sqrt(spec), LD))
+    np.testing.assert_allclose(d[2], spec / (1 + spec))                  # fully eclipsed planet
+    assert np.all(d[0] > d[1]) and np.all(np.diff(d[0]) > 0)
+
+
+@pytest.mark.gpu
+def test_device_depth_matrix_matches_numpy(gpu_ctx):
+    import helpers
+    from wayne_amd import _lib
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0)
+    K = len(v.sample_mid_points)
+    rng = np.random.RandomState(3)
+    z_tr = np.concatenate([np.linspace(0.2, 1.2, K - 2), [0.0, 12.0]])
+    hidden = np.where(z_tr > 10, rng.uniform(0, 1, K), 0.0)
+    dd = lc.DeviceDepths(z_tr, hidden, v.depth0 * (1 + 0.3 * rng.uniform(-1, 1, v.depth0.size)), LD)
+    pg = helpers.product_generator(v, 0)
+    from wayne_amd import engine
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    desc = pg.build_descriptor(eng, **dict(kw, planet_signal=dd))
+    eng.ctx.upload(0, desc)
+    eng.ctx.run_front(0)
+    got = eng.ctx.debug_depth(0)
+    eng.ctx.run_back(0)
+    from wayne_amd import tools
+    i0, i1 = tools.crop_spectrum_ind(v.grism.wl_limits[0], v.grism.wl_limits[1], v.wl)
+    want = dd.host_matrix()[:, i0:i1]
+    assert got.shape == want.shape
+    # float32 integrand on the device: a few 1e-9 of the flux
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-8)
+    # and the exposure built from it equals the one built from the uploaded matrix (replay thrower, noise off)
+    off = dict(add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False)
+    a = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                  **dict(kw, planet_signal=dd, **off)).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                  **dict(kw, planet_signal=dd.host_matrix(), **off)).reads])
+    assert np.abs(a - b).max() < 0.5     # counts may round differently for a handful of bins (depth differs by 1e-9)
+    assert np.median(np.abs(a - b)) < 1e-6

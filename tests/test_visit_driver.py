@@ -1,0 +1,135 @@
+"""The visit driver: FITS reader / writer, visit planner,
+Observation + YAML front end.  CPU tests cover the host logic; the GPU test runs the
+CLI on a small visit and checks the files against direct ExposureGenerator calls."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from wayne_amd import detector, fitsio, observation, run_visit, tools, visit_planner
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MINI = os.path.join(HERE, "fixtures", "mini_visit")
+
+
+def test_fits_roundtrip_all_types(tmp_path):
+    rng = np.random.RandomState(0)
+    arrays = [rng.normal(size=(7, 5)), rng.normal(size=(3, 4)).astype(np.float32),
+              rng.randint(-1000, 1000, (4, 6)).astype(np.int16), rng.randint(0, 255, (2, 3)).astype(np.uint8),
+              rng.randint(-10 ** 6, 10 ** 6, (5, 2)).astype(np.int32)]
+    hdus = [fitsio.HDU(fitsio.Header([("WMIN", 10600.0, "angstrom"), ("NAME", "it's", ""), ("FLAG", True, "")]), None)]
+    hdus += [fitsio.HDU(fitsio.Header([("SAMPNUM", i, "")]), a, name="SCI") for i, a in enumerate(arrays)]
+    p = str(tmp_path / "t.fits")
+    fitsio.write(p, hdus)
+    assert os.path.getsize(p) % 2880 == 0
+    back = fitsio.read(p)
+    assert back[0].header["WMIN"] == 10600.0 and back[0].header["NAME"] == "it's" and back[0].header["FLAG"] is True
+    for i, a in enumerate(arrays):
+        assert back[i + 1].name == "SCI" and back[i + 1].header["SAMPNUM"] == i
+        np.testing.assert_array_equal(back[i + 1].data, a)
+        assert back[i + 1].data.dtype.kind == a.dtype.kind and back[i + 1].data.dtype.itemsize == a.dtype.itemsize
+
+
+def test_fits_reads_reference_data_files():
+    # the reference's own small FITS data files, when its tree is present (not on the GPU box)
+    ref = "/root/reference/wayne/data"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    bias = fitsio.read(os.path.join(ref, "wfc3_ir_initial_bias_256.fits"))[1].data
+    np.testing.assert_array_equal(bias, np.load(detector.WFC3_IR().initial_bias))
+    tab = fitsio.read(os.path.join(ref, "wfc3_ir_g141_src_004_syn.fits"))[1].data
+    assert tab.dtype.names[:2] == ("WAVELENGTH", "THROUGHPUT") and len(tab) == 87
+    assert 9000 < tab["WAVELENGTH"].min() < tab["WAVELENGTH"].max() < 20000 and np.all(np.diff(tab["WAVELENGTH"]) > 0)
+
+
+def test_calibration_from_directory_roundtrip(tmp_path):
+    from wayne_amd import calibration
+    syn = calibration.CalibrationSet.synthetic(5, grisms=("G141",))
+    d = str(tmp_path)
+    H, hdr = fitsio.HDU, fitsio.Header
+    fitsio.write(os.path.join(d, calibration.FLAT_FILES["G141"]),
+                 [H(hdr([("WMIN", 10600.0, ""), ("WMAX", 17000.0, "")]), syn.flat["G141"][0])] +
+                 [H(hdr(), syn.flat["G141"][i]) for i in (1, 2, 3)])
+    fitsio.write(os.path.join(d, calibration.SKY_FILES["G141"]), [H(hdr(), syn.sky["G141"])])
+    pfl = np.ones((1024, 1024), dtype=np.float32)
+    pfl[5:-5, 5:-5] = syn.pfl
+    fitsio.write(os.path.join(d, calibration.PFL_FILE), [H(hdr(), None), H(hdr(), pfl)])
+    fitsio.write(os.path.join(d, calibration.LIN_FILE), [H(hdr(), None)] + [H(hdr(), syn.lin[i]) for i in range(4)])
+    got = calibration.CalibrationSet.from_directory(d)
+    np.testing.assert_array_equal(got.flat["G141"], syn.flat["G141"])
+    assert got.flat_wl["G141"] == (10600.0, 17000.0)
+    np.testing.assert_array_equal(got.sky["G141"], syn.sky["G141"])
+    np.testing.assert_array_equal(got.pfl, syn.pfl)
+    np.testing.assert_array_equal(got.lin, syn.lin)
+
+
+def test_detect_orbits_and_helpers():
+    assert tools.detect_orbits([1.001, 1.002, 1.032]) == [0, 2]            # tests/test_tools.py:85-89
+    g = tools.wl_at_resolution(130, 1.0, 1.7)
+    assert abs(np.diff(g)[0] - 1.35 / 130) < 1e-12 and g[0] == 1.0 and g[-1] >= 1.7
+    wl = np.linspace(1, 2, 2001)
+    new = np.linspace(1.1, 1.9, 17)
+    np.testing.assert_allclose(tools.rebin_spec(wl, 3 + 2 * wl, new), 3 + 2 * new, rtol=1e-9)   # linear: exact
+    flat = tools.rebin_spec(wl, np.full(wl.size, 7.0), new)
+    np.testing.assert_allclose(flat, 7.0)
+    bb = tools.blackbody_lambda(np.array([0.5, 1.0, 2.0]), 6100.0)
+    assert bb[0] > bb[1] > bb[2] > 0                                        # Wien peak at 0.475 um
+
+
+def test_visit_planner():
+    det = detector.WFC3_IR()
+    vp = visit_planner.VisitPlanner(det, 5, "SPARS10", 256, num_orbits=3)
+    t = vp["exp_times"]
+    assert vp["num_exp"] == len(t) and vp["orbit_start_index"][0] == 0 and len(vp["orbit_start_index"]) == 3
+    assert t[0] == 6.0 and t[vp["orbit_start_index"][1]] == 95.0 + 5.0      # guide-star acquisition 6 / 5 min
+    step = det.exptime(5, 256, "SPARS10") / 60.0 + 1.0
+    assert abs(t[1] - t[0] - step) < 1e-12
+    assert np.all(t[:vp["orbit_start_index"][1]] < 54.0)                    # visibility window
+    assert det.num_exp_per_buffer(5, 256) == 21                              # floor(2*16*4 / 6)
+
+
+def test_build_observation_from_yaml():
+    cfg = yaml.safe_load(open(os.path.join(MINI, "params.yml")))
+    obs = run_visit.build_observation(cfg, MINI)
+    assert len(obs.exp_start_times) == 6 and obs.visit_plan["orbit_start_index"] == [0, 2, 5]
+    assert obs.NSAMP == 4 and obs.SUBARRAY == 128 and obs.grism.name == "G141"
+    assert obs.transmission_spectroscopy and obs.ssv_gen.stddev == 1.5
+    assert obs.wl.min() >= 0.9 and obs.wl.max() <= 1.8                       # run_visit.py:152-153 pre-crop
+    assert obs._visit_trend.scale_factors.shape == (6,)
+    t, model = obs.show_lightcurve()
+    assert model[0] > 0.995 and model[3] < 0.986 and model[5] > 0.99         # ingress, mid-transit, out
+    dd = obs.device_depths(obs.exp_start_times[3] + np.array([0.0, 1e-4]))
+    m = dd.host_matrix()
+    assert m.shape == (2, obs.wl.size) and 0.015 < m.mean() < 0.0175
+
+
+def test_example_yaml_of_the_reference_parses():
+    ex = "/root/reference/examples"
+    if not os.path.exists(ex):
+        pytest.skip("reference tree not present")
+    cfg = yaml.safe_load(open(os.path.join(ex, "hd209458b_12181_simulation_parameters.yml")))
+    obs = run_visit.build_observation(cfg, ex)
+    assert len(obs.exp_start_times) == 121 and obs.SUBARRAY == 256 and obs.sample_rate == 10
+    assert obs.x_ref.shape == (121,) and obs.sky_background.shape == (121,)
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
+    import shutil
+    work = str(tmp_path / "visit")
+    shutil.copytree(MINI, work)
+    obs = run_visit.run(["-p", os.path.join(work, "params.yml"), "--max-exposures", "3"])
+    files = sorted(os.listdir(obs.outdir))
+    assert files == ["0000_flt.fits", "0001_raw.fits", "0002_raw.fits", "0003_raw.fits", "params.yml", "visit_plan.txt"]
+    h = fitsio.read(os.path.join(obs.outdir, "0002_raw.fits"))
+    assert len(h) == 1 + 5 * 4 and h[0].header["NSAMP"] == 4 and h[0].header["SCAN"] is True
+    sci = [x for x in h if x.name == "SCI"]
+    assert [x.header["SAMPNUM"] for x in sci] == [3, 2, 1, 0] and sci[0].data.shape == (138, 138)
+    assert sci[0].header["SAMPTIME"] == pytest.approx(detector.WFC3_IR().exptime(4, 128, "RAPID"))
+    assert sci[0].data.max() > sci[-1].data.max() - 1e4                    # last read holds the most flux... (zero read has the bias)
+    # regenerate exposure 2 directly: identical (counter-based RNG, no dependence on run order)
+    frame = obs._generate_exposure(obs.exp_start_times[1], 2, write_fits=False)
+    np.testing.assert_array_equal(np.asarray(frame.reads[3][0], dtype=np.float64), sci[0].data)
+    di = fitsio.read(os.path.join(obs.outdir, "0000_flt.fits"))
+    assert abs(di[1].data.max() - 10000.0) < 700                           # the 2-D gaussian direct image

@@ -65,7 +65,8 @@ class ExposureDesc(C.Structure):
                 ("n_reads", C.c_int), ("read_dt_s", _dp),
                 ("sky_ct_s", C.c_double), ("cosmic_rate", C.c_double), ("scale_factor", C.c_double),
                 ("noise_mean", C.c_double), ("noise_std", C.c_double),
-                ("thrower_margin", C.c_int), ("thrower_splits", C.c_int)]
+                ("thrower_margin", C.c_int), ("thrower_splits", C.c_int),
+                ("lc_z", _dp), ("lc_hidden", _dp), ("lc_rp", _dp), ("lc_ld", C.c_double * 4)]
 
 
 class Profile(C.Structure):
@@ -95,6 +96,7 @@ SYMBOLS = {
     "wayne_exposure_device_reads": (_vp, [_vp, C.c_int]),
     "wayne_exposure_synthesize": (C.c_int, [_vp, C.POINTER(ExposureDesc), _vp]),
     "wayne_exposure_debug_fetch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "wayne_exposure_debug_depth": (C.c_int, [_vp, C.c_int, _vp]),
     "wayne_exposure_run_front": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_run_back": (C.c_int, [_vp, C.c_int]),
     "wayne_profile_enable": (C.c_int, [_vp, C.c_int]),
@@ -122,7 +124,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
-        if L.wayne_abi_version() != 1:
+        if L.wayne_abi_version() != 2:
             raise ImportError("libwayne_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -287,6 +289,12 @@ class Context(object):
         self.run(0)
         return self.download(0)
 
+    def debug_depth(self, slot):
+        K, W, R, _ = self._slot_meta[slot]
+        out = np.empty((K, W), dtype=np.float64)
+        self.check(self._L.wayne_exposure_debug_depth(self._h, int(slot), ptr(out)))
+        return out
+
     def debug_fetch(self, slot, acc=False):
         K, W, R, _ = self._slot_meta[slot]
         counts = np.empty((K, W), dtype=np.int32)
@@ -316,7 +324,7 @@ class Context(object):
 def make_desc(seed, exposure_index, flags, sub_scale, wl_um, flux, depth, x_ref, y_ref, dur_ms,
               sample_read, read_dt_s, replay_seed=None, rng_mode=RNG_PHILOX, threads_compat=1,
               sky_ct_s=0.0, cosmic_rate=-1.0, scale_factor=1.0, noise_mean=0.0, noise_std=0.0,
-              thrower_margin=0, thrower_splits=0):
+              thrower_margin=0, thrower_splits=0, lc_z=None, lc_hidden=None, lc_rp=None, lc_ld=None):
     d = ExposureDesc()
     keep = []
 
@@ -350,6 +358,17 @@ def make_desc(seed, exposure_index, flags, sub_scale, wl_um, flux, depth, x_ref,
     d.sky_ct_s, d.cosmic_rate = float(sky_ct_s), float(cosmic_rate)
     d.scale_factor, d.noise_mean, d.noise_std = float(scale_factor), float(noise_mean), float(noise_std)
     d.thrower_margin, d.thrower_splits = int(thrower_margin), int(thrower_splits)
+    if lc_z is not None:
+        if depth is not None:
+            raise ValueError("give either depth or lc_z")
+        lc_z, lc_rp = arr(lc_z, f64), arr(lc_rp, f64)
+        if lc_z.size != K or lc_rp.size != W:
+            raise ValueError("lc_z must have K and lc_rp W elements")
+        d.lc_z, d.lc_rp = ptr(lc_z, C.c_double), ptr(lc_rp, C.c_double)
+        if lc_hidden is not None:
+            lc_hidden = arr(lc_hidden, f64)
+            d.lc_hidden = ptr(lc_hidden, C.c_double)
+        d.lc_ld[:] = [float(v) for v in lc_ld]
     d._keep = keep
     return d
 

@@ -110,6 +110,83 @@ __global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlAr
 }
 
 // ---------------------------------------------------------------------------
+// k_lightcurve : transit-depth matrix depth[K][W] on the device
+// ---------------------------------------------------------------------------
+// Replaces Observation.generate_lightcurves (observation.py:293-357: one
+// pylightcurve.transit + one pylightcurve.eclipse call per wavelength element
+// per exposure).  Star with Claret limb darkening I(mu) = 1 - sum a_n (1 - mu^(n/2))
+// occulted by a disk of radius p at separation z:
+//   dF = int_0^{p-z} I 2 pi r dr  +  int_{|z-p|}^{min(1,z+p)} I(r) r theta(r) dr,
+//   theta = 4 atan2(sqrt(p^2 - (r-z)^2), sqrt((r+z)^2 - p^2))
+// with a 24-node tanh-sinh rule (wayne_amd/lightcurve.py states the same model
+// in numpy).  float32 integrand in cancellation-free form, float64 sum.
+constexpr int kLcNodes = 24;
+struct LcArgs {
+  int K, W;
+  const double* z;        // [K]
+  const double* hidden;   // [K] or null
+  const double* rp;       // [W]
+  double ld[4];
+  double f0;              // pi (1 - sum a_n n/(n+4))
+  float x[kLcNodes], w[kLcNodes], d[kLcNodes];   // node, weight, distance to the nearer end
+  double* depth;          // [K*W]
+};
+
+__device__ __forceinline__ double lc_prim(const double* a, double m) {
+  // int I(m) m dm = m^2/2 (1 - sum a_n) + a1 m^2.5/2.5 + a2 m^3/3 + a3 m^3.5/3.5 + a4 m^4/4
+  const double s = sqrt(m);
+  const double m2 = m * m;
+  return (m2 / 2.) * (1. - a[0] - a[1] - a[2] - a[3]) + a[0] * m2 * s / 2.5 + a[1] * m2 * m / 3. +
+         a[2] * m2 * m * s / 3.5 + a[3] * m2 * m2 / 4.;
+}
+
+__global__ __launch_bounds__(256) void k_lightcurve(LcArgs a) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (w >= a.W) return;
+  const double z = a.z[k], p = a.rp[w];
+  double deficit = 0.;   // 1 - transit
+  if (z < 1. + p) {
+    const double r_full = fmin(fmax(p - z, 0.), 1.);
+    const double mu_f = sqrt(1. - r_full * r_full);
+    double dF = 2. * kPi * (lc_prim(a.ld, 1.) - lc_prim(a.ld, mu_f));
+    const double ra = fabs(z - p), rb = fmin(1., z + p);
+    if (rb > ra) {
+      const float L = (float)(rb - ra), raf = (float)ra, zf = (float)z, pf = (float)p;
+      const float gap = (float)(1. - rb);            // 1 - rb >= 0
+      const float a1 = (float)a.ld[0], a2 = (float)a.ld[1], a3 = (float)a.ld[2], a4 = (float)a.ld[3];
+      double sum = 0.;
+#pragma unroll 4
+      for (int i = 0; i < kLcNodes; ++i) {
+        const float x = a.x[i], dn = a.d[i];
+        const float lo = L * (x < 0.5f ? dn : 1.f - dn);    // r - ra
+        const float hi = L * (x < 0.5f ? 1.f - dn : dn);    // rb - r
+        const float r = raf + lo;
+        // p^2 - (r - z)^2 and (r + z)^2 - p^2 without cancellation:
+        //   |z - p| = ra  =>  p^2 - (r-z)^2 = (p - |r - z|)(p + |r - z|), and p - |r-z| vanishes at r = ra only
+        const float rmz = r - zf;
+        const float num = fmaxf((pf - fabsf(rmz)) * (pf + fabsf(rmz)), 0.f);
+        const float den = fmaxf((r + zf - pf) * (r + zf + pf), 0.f);
+        const float theta = 4.f * atan2f(sqrtf(num), sqrtf(den));
+        const float mu = sqrtf(fmaxf((gap + hi) * (1.f + r), 0.f));   // sqrt((1-r)(1+r))
+        const float sm = sqrtf(mu);
+        const float I = 1.f - a1 * (1.f - sm) - a2 * (1.f - mu) - a3 * (1.f - mu * sm) - a4 * (1.f - mu * mu);
+        sum += (double)(I * r * theta * a.w[i]);
+      }
+      dF += sum * (double)L;
+    }
+    deficit = dF / a.f0;
+  }
+  // eclipse term: (1 - eclipse) = f hidden / (1 + f), f = planet_spectrum = p^2 (observation.py:352-355)
+  double ecl = 0.;
+  if (a.hidden) {
+    const double f = p * p;
+    ecl = f * a.hidden[k] / (1. + f);
+  }
+  a.depth[(size_t)k * a.W + w] = deficit + ecl;
+}
+
+// ---------------------------------------------------------------------------
 // k_prep_sub : one workgroup per sub-sample
 // ---------------------------------------------------------------------------
 struct PrepArgs {

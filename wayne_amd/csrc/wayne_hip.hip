@@ -19,9 +19,9 @@ using namespace wayne;
 
 namespace {
 
-enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_OTHER };
+enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE };
 const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub", "k_throw",
-                                                    "k_cosmic",  "k_ramp",     "other"};
+                                                    "k_cosmic",  "k_ramp",     "k_lightcurve"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -51,13 +51,13 @@ struct Slot {
   bool acc_init = false;
   wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
   int W = 0, K = 0, R = 0;
-  bool has_depth = false, has_replay_seed = false;
-  DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt;
+  bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
+  DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;
   DevBuf ratio, sigl, sigh, sens, dlam;
   DevBuf counts, nwide, prefix, xpos, ypos, sub;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   void release() {
-    for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &ratio, &sigl,
+    for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &prefix, &xpos, &ypos, &sub, &acc, &out,
                       &misc})
       b->release();
@@ -509,8 +509,18 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   const size_t KW = (size_t)K * W;
   if ((rc = upload(c, s.wl, d->wl_um, (size_t)W))) return rc;
   if ((rc = upload(c, s.flux, d->flux, (size_t)W))) return rc;
-  s.has_depth = d->depth != nullptr;
-  if (s.has_depth && (rc = upload(c, s.depth, d->depth, KW))) return rc;
+  s.has_lc = d->lc_z != nullptr;
+  if (s.has_lc) {
+    if (d->depth) return fail(c, WAYNE_E_INVALID, "upload: give either depth or lc_z, not both");
+    if (!d->lc_rp) return fail(c, WAYNE_E_INVALID, "upload: lc_z needs lc_rp");
+    if ((rc = upload(c, s.lc_z, d->lc_z, (size_t)K))) return rc;
+    if ((rc = upload(c, s.lc_rp, d->lc_rp, (size_t)W))) return rc;
+    s.has_lc_hidden = d->lc_hidden != nullptr;
+    if (s.has_lc_hidden && (rc = upload(c, s.lc_hidden, d->lc_hidden, (size_t)K))) return rc;
+    HIP_TRY(c, s.depth.reserve(KW * sizeof(double)));
+  }
+  s.has_depth = d->depth != nullptr || s.has_lc;
+  if (d->depth && (rc = upload(c, s.depth, d->depth, KW))) return rc;
   if ((rc = upload(c, s.xref, d->x_ref, (size_t)K))) return rc;
   if ((rc = upload(c, s.yref, d->y_ref, (size_t)K))) return rc;
   if ((rc = upload(c, s.dur, d->dur_ms, (size_t)K))) return rc;
@@ -541,6 +551,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d = *d;
   s.d.wl_um = s.d.flux = s.d.depth = s.d.x_ref = s.d.y_ref = s.d.dur_ms = s.d.read_dt_s = nullptr;
   s.d.replay_seed = s.d.sample_read = nullptr;
+  s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.uploaded = true;
   s.front_done = false;
@@ -562,6 +573,29 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     s.acc_dirty = false;
   }
   HIP_TRY(c, hipMemsetAsync(s.misc.p, 0, 64, c->stream));
+
+  if (s.has_lc) {
+    LcArgs a{};
+    a.K = K; a.W = W;
+    a.z = s.lc_z.as<double>();
+    a.hidden = s.has_lc_hidden ? s.lc_hidden.as<double>() : nullptr;
+    a.rp = s.lc_rp.as<double>();
+    double sum = 0.;
+    for (int i = 0; i < 4; ++i) { a.ld[i] = d.lc_ld[i]; sum += d.lc_ld[i] * (i + 1) / (i + 5.0); }
+    a.f0 = kPi * (1.0 - sum);
+    // tanh-sinh rule on (0, 1): t in [-3, 3], u = pi/2 sinh t, x = (1 + tanh u)/2 (wayne_amd/lightcurve.py)
+    const double h = 6.0 / (kLcNodes - 1);
+    for (int i = 0; i < kLcNodes; ++i) {
+      const double t = -3.0 + h * i, u = 0.5 * kPi * std::sinh(t);
+      a.x[i] = (float)(0.5 * (1.0 + std::tanh(u)));
+      a.w[i] = (float)(h * 0.25 * kPi * std::cosh(t) / (std::cosh(u) * std::cosh(u)));
+      a.d[i] = (float)(0.5 * std::exp(-std::fabs(u)) / std::cosh(u));
+    }
+    a.depth = s.depth.as<double>();
+    ProfScope ps(c, PK_LIGHTCURVE);
+    hipLaunchKernelGGL(k_lightcurve, dim3((W + 255) / 256, K), dim3(256), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+  }
 
   WlArrays wa{s.ratio.as<double>(), s.sigl.as<double>(), s.sigh.as<double>(), s.sens.as<double>(),
               s.dlam.as<double>()};
@@ -735,6 +769,18 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
     for (size_t i = 0; i < n; ++i) acc_e[i] = (double)tmp[i] * kInvQ;
   }
   return check_status(c, s);
+}
+
+int wayne_exposure_debug_depth(wayne_ctx* c, int slot, double* depth) {
+  if (!c || !depth) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "debug_depth: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded || !s.has_depth) return fail(c, WAYNE_E_STATE, "debug_depth: no depth matrix in this slot");
+  (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
+  HIP_TRY(c, hipMemcpyAsync(depth, s.depth.p, (size_t)s.K * s.W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WAYNE_OK;
 }
 
 // ---------------------------------------------------------------------------

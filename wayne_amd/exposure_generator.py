@@ -26,7 +26,7 @@ import warnings
 
 import numpy as np
 
-from . import _lib, engine as _engine, exposure, tools
+from . import _lib, engine as _engine, exposure, lightcurve, tools
 from .trend_generators import scan_speed_varations
 
 MS_PER_YEAR = 365.25 * 86400. * 1000.
@@ -209,7 +209,12 @@ class ExposureGenerator(object):
         s_wl = wl[i0:i1]
         flux = stellar_flux[i0:i1]
         depth = None
-        if planet_signal is not None:
+        lc = {}
+        if isinstance(planet_signal, lightcurve.DeviceDepths):
+            # the K x W matrix is computed on the device from K + W + 4 numbers
+            lc = dict(lc_z=planet_signal.z_tr, lc_hidden=planet_signal.hidden,
+                      lc_rp=np.sqrt(planet_signal.planet_spectrum[i0:i1]), lc_ld=planet_signal.ld)
+        elif planet_signal is not None:
             depth = np.ascontiguousarray(np.asarray(planet_signal, dtype=float)[:, i0:i1])
 
         # the read that closes each sub-sample (`if i in read_index`, :361)
@@ -243,7 +248,7 @@ class ExposureGenerator(object):
             cosmic_rate=-1.0 if cosmic_rate is None else float(cosmic_rate),
             scale_factor=1.0 if scale_factor is None else float(scale_factor),
             noise_mean=float(noise_mean) if noise_mean else 0.0,
-            noise_std=float(noise_std) if noise_std else 0.0)
+            noise_std=float(noise_std) if noise_std else 0.0, **lc)
 
     def direct_image(self, x_ref, y_ref):
         """The unscaled 2-D gaussian direct image used to calibrate x_ref / y_ref

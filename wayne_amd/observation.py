@@ -1,0 +1,230 @@
+"""Observation: a whole visit of exposures.
+
+Same class and `setup_*` / `run_observation` methods as the reference's
+wayne/observation.py:24-538, with plain floats (days, micron, seconds, px/s,
+counts/s) instead of astropy / quantities objects and a small `Planet` record
+instead of an exodata object.  What changed underneath:
+
+  * light curves: the reference calls pylightcurve once per wavelength element
+    per exposure (observation.py:349-355); here the K x W depth matrix of an
+    exposure is computed on the GPU from the orbit (wayne_amd/lightcurve.py,
+    k_lightcurve);
+  * exposures are independent (counter-based RNG), so `run_observation` can
+    take a (rank, world) pair and generate only its round-robin share.
+"""
+import os
+
+import numpy as np
+
+from . import lightcurve, tools
+from .exposure_generator import ExposureGenerator
+from .trend_generators import visit_trends
+from .visit_planner import VisitPlanner
+
+R_SUN_AU = 0.00465047      # solar radius in au
+
+
+class Planet(object):
+    """Orbital elements needed for the light curve (what the reference reads off an
+    exodata Planet, observation.py:317-324)."""
+
+    def __init__(self, name="planet", period=None, sma_au=None, stellar_radius_rsun=None, inclination=None,
+                 eccentricity=0.0, periastron=0.0, transittime=None, rp_over_rs=None, star_temperature=None):
+        self.name = name
+        self.P, self.a, self.Rs = period, sma_au, stellar_radius_rsun
+        self.i, self.e, self.periastron = inclination, eccentricity, periastron
+        self.transittime = transittime
+        self.rp_over_rs = rp_over_rs
+        self.star_temperature = star_temperature
+
+    @property
+    def sma_over_rs(self):
+        return self.a / (self.Rs * R_SUN_AU)
+
+
+class Observation(object):
+    def __init__(self, outdir="", calibration=None, device=0, seed=0):
+        self.scanning = True
+        self.outdir = outdir
+        self.calibration = calibration
+        self.device, self.seed = device, seed
+        self._visit_trend = False
+        self.ssv_gen = None
+        self.noise_mean = self.noise_std = False
+
+    # -- setup_* (observation.py:46-291) ----------------------------------------
+    def setup_observation(self, x_ref, y_ref, spatial_scan=False, scan_speed=False):
+        self.x_ref, self.y_ref = x_ref, y_ref
+        self.spatial_scan, self.scan_speed = spatial_scan, scan_speed
+
+    def setup_simulator(self, sample_rate=False, clip_values_det_limits=True, threads=2):
+        self.sample_rate = sample_rate
+        self.clip_values_det_limits = clip_values_det_limits
+        self.threads = threads
+
+    def setup_target(self, planet, wavelengths, planet_spectrum, stellar_flux, transittime=None, ldcoeffs=None,
+                     period=None, rp=None, sma=None, inclination=None, eccentricity=None, periastron=None,
+                     stellar_radius=None):
+        self.wl = np.asarray(wavelengths, dtype=float)
+        self.stellar_flux = np.asarray(stellar_flux, dtype=float)
+        self.planet_spectrum = None if planet_spectrum is None else np.asarray(planet_spectrum, dtype=float)
+        assert len(self.wl) == len(self.stellar_flux)
+        if not isinstance(planet, Planet):
+            planet = Planet(name=str(planet))
+        self.planet = planet
+        if planet_spectrum is not None:
+            assert len(self.wl) == len(self.planet_spectrum)
+            self.transmission_spectroscopy = True
+            for attr, val in (("P", period), ("a", sma), ("i", inclination), ("Rs", stellar_radius),
+                              ("transittime", transittime)):
+                if val:
+                    setattr(planet, attr, val)
+            if eccentricity or eccentricity == 0:
+                planet.e = eccentricity
+            if periastron or periastron == 0:
+                planet.periastron = periastron
+            if rp:
+                planet.rp_over_rs = rp
+            if not ldcoeffs:
+                raise ValueError("ldcoeffs are required (the reference looks them up with pylightcurve.clablimb, "
+                                 "tools.py:220-230, which is not available)")
+            self.ldcoeffs = list(ldcoeffs)
+        else:
+            self.transmission_spectroscopy = False
+
+    def setup_detector(self, detector, NSAMP, SAMPSEQ, SUBARRAY):
+        self.detector, self.NSAMP, self.SAMPSEQ, self.SUBARRAY = detector, NSAMP, SAMPSEQ, SUBARRAY
+
+    def setup_grism(self, grism):
+        self.grism = grism
+        if self.calibration is None:
+            self.calibration = grism.calibration
+
+    def setup_visit(self, start_JD, num_orbits, exp_start_times=False):
+        self.start_JD, self.num_orbits = start_JD, num_orbits
+        if exp_start_times is not False and exp_start_times is not None and len(np.atleast_1d(exp_start_times)):
+            self.exp_start_times = np.asarray(exp_start_times, dtype=float)
+            self.visit_plan = {"exp_start_times": self.exp_start_times,
+                               "orbit_start_index": tools.detect_orbits(self.exp_start_times)}
+        else:
+            self.visit_plan = VisitPlanner(self.detector, self.NSAMP, self.SAMPSEQ, self.SUBARRAY, self.num_orbits,
+                                           exp_overhead=3.0)            # observation.py:229-233
+            self.exp_start_times = self.visit_plan["exp_times"] / (24. * 60.) + self.start_JD
+            self.visit_plan["exp_start_times"] = self.exp_start_times
+
+    def setup_reductions(self, add_dark=True, add_flat=True, add_gain_variations=True, add_non_linear=True,
+                         add_initial_bias=True):
+        self.add_dark, self.add_flat = add_dark, add_flat
+        self.add_gain_variations, self.add_non_linear = add_gain_variations, add_non_linear
+        self.add_initial_bias = add_initial_bias
+
+    def setup_trends(self, ssv_gen, x_shifts=0, x_jitter=0.0000001, y_shifts=0, y_jitter=0.0000001):
+        self.ssv_gen = ssv_gen
+        self.x_shifts, self.x_jitter, self.y_shifts, self.y_jitter = x_shifts, x_jitter, y_shifts, y_jitter
+
+    def setup_noise_sources(self, sky_background=1.0, cosmic_rate=11., add_read_noise=True, add_stellar_noise=True):
+        self.sky_background, self.cosmic_rate = sky_background, cosmic_rate
+        self.add_read_noise, self.add_stellar_noise = add_read_noise, add_stellar_noise
+
+    def setup_gaussian_noise(self, noise_mean=False, noise_std=False):
+        self.noise_mean, self.noise_std = noise_mean, noise_std
+
+    def setup_visit_trend(self, visit_trend_coeffs):
+        self._visit_trend = visit_trends.HookAndLongTermRamp(self.visit_plan, visit_trend_coeffs)
+
+    # -- light curves ---------------------------------------------------------------
+    def _orbit_args(self):
+        p = self.planet
+        W = p.periastron
+        if W is None or (isinstance(W, float) and np.isnan(W)):
+            W = 0.0
+        return (float(p.P), float(p.sma_over_rs), float(p.e or 0.0), float(p.i), float(W), float(p.transittime))
+
+    def generate_lightcurves(self, time_array, depth=False):
+        """Normalised flux, shape (len(time_array), n_depths) (observation.py:293-357).
+        The reference converts JD to HJD with ephem (tools.py:233-271), which is not
+        available: times are used as given."""
+        spectrum = np.array([depth]) if depth else self.planet_spectrum
+        rp_white = self.planet.rp_over_rs or float(np.sqrt(np.mean(self.planet_spectrum)))
+        z_tr, hidden = lightcurve.depth_inputs(*(self._orbit_args() + (time_array, rp_white)))
+        return 1.0 - lightcurve.planet_depths(self.ldcoeffs, spectrum, z_tr, hidden)
+
+    def device_depths(self, time_array):
+        """The same per-sub-sample depths, as the recipe the GPU evaluates."""
+        rp_white = self.planet.rp_over_rs or float(np.sqrt(np.mean(self.planet_spectrum)))
+        z_tr, hidden = lightcurve.depth_inputs(*(self._orbit_args() + (time_array, rp_white)))
+        return lightcurve.DeviceDepths(z_tr, hidden, self.planet_spectrum, self.ldcoeffs)
+
+    def show_lightcurve(self):
+        """White light curve of the planned visit -> (times, model); the reference also plots it."""
+        t = self.exp_start_times
+        if self.transmission_spectroscopy:
+            depth = self.planet.rp_over_rs ** 2 if self.planet.rp_over_rs else float(np.mean(self.planet_spectrum))
+            lc_model = self.generate_lightcurves(t, depth).T[0]
+        else:
+            lc_model = np.ones_like(t)
+        if self._visit_trend:
+            lc_model = np.asarray(self._visit_trend.scale_factors)[:len(lc_model)] * lc_model
+        return t, lc_model
+
+    # -- running ----------------------------------------------------------------------
+    @staticmethod
+    def _try_index(value, index):
+        try:
+            return value[index]
+        except (TypeError, IndexError):
+            return value
+
+    def run_observation(self, rank=0, world=1, write_fits=True):
+        """Generate the direct image and every exposure (observation.py:388-413); with
+        world > 1 only the exposures i = rank, rank + world, ... (round-robin sharding)."""
+        if write_fits and self.outdir and not os.path.exists(self.outdir):
+            os.makedirs(self.outdir)
+        frames = {}
+        if rank == 0:
+            frames[0] = self._generate_direct_image(write_fits)
+        for i in range(rank, len(self.exp_start_times), world):
+            frames[i + 1] = self._generate_exposure(self.exp_start_times[i], i + 1, write_fits)
+        return frames
+
+    def _generate_exposure(self, expstart, number, write_fits=True):
+        """observation.py:415-504."""
+        index_number = number - 1
+        filename = "{:04d}_raw.fits".format(number)
+        exp_gen = ExposureGenerator(self.detector, self.grism, self.NSAMP, self.SAMPSEQ, self.SUBARRAY, self.planet,
+                                    filename, expstart, calibration=self.calibration, device=self.device,
+                                    seed=self.seed, exposure_index=index_number)
+        sample_rate = self.sample_rate if self.spatial_scan else 365.25 * 86400. * 1000.
+        _, sample_mid_points, sample_durations, read_index = exp_gen._gen_scanning_sample_times(sample_rate)
+        time_array = expstart + sample_mid_points / (86400. * 1000.)
+        planet_depths = self.device_depths(time_array) if self.transmission_spectroscopy else None
+        x_ref = self._try_index(self.x_ref, index_number) + self.x_shifts * index_number
+        y_ref = self._try_index(self.y_ref, index_number) + self.y_shifts * index_number
+        sky_background = self._try_index(self.sky_background, index_number)
+        scale_factor = self._visit_trend.get_scale_factor(index_number) if self._visit_trend else None
+        common = dict(noise_mean=self.noise_mean, noise_std=self.noise_std, add_flat=self.add_flat,
+                      add_dark=self.add_dark, scale_factor=scale_factor, sky_background=sky_background,
+                      cosmic_rate=self.cosmic_rate, add_gain_variations=self.add_gain_variations,
+                      add_non_linear=self.add_non_linear, clip_values_det_limits=self.clip_values_det_limits,
+                      add_read_noise=self.add_read_noise, add_stellar_noise=self.add_stellar_noise,
+                      add_initial_bias=self.add_initial_bias, threads=self.threads)
+        if self.spatial_scan:
+            exp_frame = exp_gen.scanning_frame(x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux,
+                                               planet_depths, self.scan_speed, sample_rate, sample_mid_points,
+                                               sample_durations, read_index, ssv_generator=self.ssv_gen, **common)
+        else:
+            exp_frame = exp_gen.staring_frame(x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux,
+                                              planet_depths, sample_mid_points, sample_durations, read_index, **common)
+        if write_fits:
+            exp_frame.generate_fits(self.outdir, filename)
+        return exp_frame
+
+    def _generate_direct_image(self, write_fits=True):
+        """observation.py:516-538."""
+        di_start_JD = self.exp_start_times[0] - 1.0 / (24. * 60.)
+        gen = ExposureGenerator(self.detector, self.grism, self.NSAMP, self.SAMPSEQ, self.SUBARRAY, self.planet,
+                                "0000_flt.fits", di_start_JD, calibration=self.calibration, device=self.device)
+        exp = gen.direct_image(self._try_index(self.x_ref, 0), self._try_index(self.y_ref, 0))
+        if write_fits:
+            exp.generate_fits(self.outdir, "0000_flt.fits")
+        return exp

@@ -72,3 +72,68 @@ def crop_central_box(array, size):
         raise ValueError("cannot crop a %d box out of a %d array" % (size, n))
     i = (n - size) // 2
     return array[i:n - i, i:n - i]
+
+
+def detect_orbits(exp_start_times, separation=0.028):
+    """Indices at which a new HST orbit starts: gaps of >= `separation` days
+    (~40 min) between consecutive exposure starts (tools.py:274-300)."""
+    t = np.asarray(exp_start_times, dtype=float)
+    orbit_index = [0]
+    for i in range(1, len(t)):
+        if t[i] - t[i - 1] >= separation:
+            orbit_index.append(i)
+    return orbit_index
+
+
+def wl_at_resolution(R, wl_min, wl_max):
+    """Evenly spaced grid at resolution R about the mid wavelength (tools.py:303-314)."""
+    mid_wl = (wl_max - wl_min) / 2 + wl_min
+    delta_wl = mid_wl / R
+    return np.arange(wl_min, wl_max + delta_wl, delta_wl)
+
+
+def order_flux_grid(wavelength, spectrum):
+    """Sort a spectrum by wavelength (tools.py:203-217)."""
+    order = np.argsort(wavelength, kind="stable")
+    return np.asarray(wavelength, dtype=float)[order], np.asarray(spectrum, dtype=float)[order]
+
+
+def load_and_sort_spectrum(file_path):
+    """Two-column text file: wavelength, flux or depth (tools.py:182-200)."""
+    data = np.loadtxt(file_path)
+    return order_flux_grid(data[:, 0], data[:, 1])
+
+
+def load_pheonix_stellar_grid_fits(fits_file):
+    """PHOENIX grid spectrum in a FITS binary table with columns Wavelength, Flux
+    (tools.py:152-170): sorted, duplicate wavelengths removed."""
+    from . import fitsio
+    tab = fitsio.read(fits_file)[1].data
+    names = {n.lower(): n for n in tab.dtype.names}
+    wl, flux = order_flux_grid(tab[names["wavelength"]], tab[names["flux"]])
+    keep = np.nonzero(np.diff(wl))
+    return wl[keep], flux[keep]
+
+
+def rebin_spec(wavelength, spectrum, new_wavelength):
+    """Flux-conserving rebin onto the bins centred on `new_wavelength`.
+
+    The reference delegates this to pysynphot (tools.py:131-149), which is not
+    available: here the input spectrum is integrated (trapezoid rule on the
+    cumulative integral) over each output bin, the bin edges lying half-way
+    between output centres.  Parity with pysynphot is unpinned."""
+    wl = np.asarray(wavelength, dtype=float)
+    sp = np.asarray(spectrum, dtype=float)
+    new = np.asarray(new_wavelength, dtype=float)
+    edges = bin_centers_to_edges(new)
+    cum = np.concatenate([[0.0], np.cumsum(0.5 * (sp[1:] + sp[:-1]) * np.diff(wl))])
+    at_edges = np.interp(edges, wl, cum)
+    return np.diff(at_edges) / np.diff(edges)
+
+
+def blackbody_lambda(wl_um, T):
+    """Planck B_lambda in erg / (s cm^2 A sr) at wavelengths in micron."""
+    h, c, k = 6.62607015e-27, 2.99792458e10, 1.380649e-16      # cgs
+    lam = np.asarray(wl_um, dtype=float) * 1e-4                  # cm
+    b = 2 * h * c * c / lam ** 5 / np.expm1(h * c / (lam * k * T))   # per cm of wavelength
+    return b * 1e-8                                              # per angstrom
