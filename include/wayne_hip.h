@@ -205,6 +205,14 @@ int wayne_exposure_run(wayne_ctx *ctx, int slot);
 /* Copy the NSAMP reads (read 0 = zero read) of `slot` to the host:
  * NSAMP*S*S float32, or float64 when WAYNE_F_OUT_F64 was set.  Synchronises. */
 int wayne_exposure_download(wayne_ctx *ctx, int slot, void *out_reads);
+/* Pinned-host delivery for pipelines: wayne_exposure_fetch_async enqueues, on the
+ * slot's stream (i.e. after its kernels), the copy of the reads into a pinned host
+ * buffer owned by the library and returns at once; wayne_exposure_wait blocks until
+ * that slot's work is done and returns the buffer (NSAMP*S*S float32 / float64), which
+ * stays valid until the slot is uploaded again.  With two slots on the two streams the
+ * copy of one exposure overlaps the kernels of the next. */
+int wayne_exposure_fetch_async(wayne_ctx *ctx, int slot);
+int wayne_exposure_wait(wayne_ctx *ctx, int slot, void **host_reads);
 /* Device pointer of that buffer (for zero-copy consumers). */
 void *wayne_exposure_device_reads(wayne_ctx *ctx, int slot);
 /* upload + run + download in one call: the batched drop-in for one

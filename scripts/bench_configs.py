@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Exposures/s of every BASELINE.json configuration on one MI355X:
+device-complete (reads left in HBM) and delivered (reads copied to host memory)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wayne_amd import calibration, detector, engine, grism, synthetic, visit  # noqa: E402
+from wayne_amd.exposure_generator import ExposureGenerator  # noqa: E402
+
+cal = calibration.CalibrationSet.synthetic(11)
+det = detector.WFC3_IR()
+out = {}
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for name in ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
+    gr = grism.G141(cal) if synthetic.CONFIGS[name]["grism"] == "G141" else grism.G102(cal)
+    v = synthetic.Visit(name, det, gr, cal, n_exposures=n + 2)
+    eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    ctx = eng.ctx
+    for j in range(n + 2):
+        eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
+        ctx.upload(2 * j, eg.build_descriptor(eng, **v.frame_kwargs(j)))
+    for j in range(2):
+        ctx.run(2 * j)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for j in range(2, n + 2):
+        ctx.run(2 * j)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    p = ctx.profile_get()
+    ctx.profile_enable(False)
+    # delivered: the visit runner (host prep + upload + kernels + download), exposures returned as numpy arrays
+    runner = visit.VisitRunner(v, 0)
+    runner.run([0, 1])
+    t1 = time.perf_counter()
+    runner.run(range(2, n + 2))
+    dt2 = time.perf_counter() - t1
+    out[name] = {"device_complete_exp_s": n / dt, "delivered_exp_s": n / dt2, "electrons_per_exposure": p["electrons"] / n,
+                 "ms": {k: p[k]["ms"] / n for k in p if k != "electrons"}, "K": v.K, "W": int(np.sum((v.wl >= gr.wl_limits[0]) & (v.wl <= gr.wl_limits[1]))),
+                 "frame": eng.N, "NSAMP": v.NSAMP}
+    print(name, json.dumps(out[name]), flush=True)
+    engine.close_all()
+print(json.dumps(out))

@@ -1,0 +1,110 @@
+"""GPU: the BASELINE.json configurations at FULL size (1014x1014 / 256x256 frames,
+NSAMP 15-16, 1e7-1e9 electrons), checked through size-independent properties --
+the oracle needs minutes per exposure at these sizes:
+
+  * conservation: with flat / gain variations off and no noise, electrons that
+    reach the accumulators = electrons thrown - those falling off the frame, and
+    the last read * 2.35 equals their sum;
+  * the cumulative reads never decrease (noise off);
+  * determinism and independence of launch geometry (bit-exact);
+  * linearity of the expected counts in scale_factor;
+  * statistics of the noisy production run (read noise on reference pixels, sky level).
+"""
+import numpy as np
+import pytest
+
+import helpers
+from wayne_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+QUIET = dict(add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False,
+             add_flat=False, add_gain_variations=False, add_non_linear=False, clip_values_det_limits=False,
+             add_initial_bias=False)
+
+
+def frames(v, i=0, record=None, **over):
+    pg = helpers.product_generator(v, i)
+    exp = pg.scanning_frame(out_dtype=np.float64, record=record, **v.frame_kwargs(i, **over))
+    return np.stack([r[0] for r in exp.reads])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"])
+def test_conservation_and_monotone_ramp(name):
+    v = helpers.make_visit(name)
+    rec = {}
+    reads = frames(v, record=rec, **QUIET)
+    thrown = int(rec["counts"].astype(np.int64).sum())
+    on_frame = rec["acc"].sum()
+    assert abs(thrown - v.E) < 0.02 * v.E                       # the flux scaling hits the configured E
+    lost = thrown - on_frame
+    assert 0 <= lost < 0.02 * thrown                            # only PSF wings leave the frame
+    assert abs(on_frame - round(on_frame)) < 1e-3               # integer electrons (no flat): exact accumulation
+    np.testing.assert_allclose(reads[-1].sum() * 2.35, on_frame, rtol=1e-12)
+    assert reads.shape == (v.NSAMP, v.detector.full_size(v.SUBARRAY), v.detector.full_size(v.SUBARRAY))
+    assert not reads[0].any()                                    # zero read without bias / noise
+    assert np.all(np.diff(reads, axis=0) >= -1e-9)               # up-the-ramp: cumulative
+    # every read interval received its sub-samples' electrons
+    per_read = rec["acc"].reshape(len(v.read_times), -1).sum(axis=1)
+    assert np.all(per_read > 0)
+    if v.scan_speed > 0:                                          # the scan moves the spectrum up the frame
+        rows = [np.average(np.arange(a.shape[0]), weights=a.sum(axis=1) + 1e-30) for a in rec["acc"]]
+        assert np.all(np.diff(rows) > 0)
+
+
+def test_cfg4_deterministic_and_geometry_invariant():
+    import os
+    v = helpers.make_visit("cfg4")
+    a = frames(v)
+    b = frames(v)
+    np.testing.assert_array_equal(a, b)
+    os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"] = "700", "5000"
+    try:
+        c = frames(v)
+    finally:
+        del os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"]
+    np.testing.assert_array_equal(a, c)
+
+
+def test_cfg3_linearity_in_scale_factor():
+    v = helpers.make_visit("cfg3")
+    r1, r2 = {}, {}
+    frames(v, record=r1, **dict(QUIET, scale_factor=1.0, planet_signal=None))
+    frames(v, record=r2, **dict(QUIET, scale_factor=2.0, planet_signal=None))
+    c1, c2 = r1["counts"].astype(np.int64), r2["counts"].astype(np.int64)
+    assert np.abs(c2 - 2 * c1).max() <= 1                        # round(2 lam) vs 2 round(lam)
+    # the frame doubles up to Monte-Carlo noise of the thrower
+    a1, a2 = r1["acc"].sum(axis=0), r2["acc"].sum(axis=0)
+    bright = a1 > 2000
+    assert bright.sum() > 1000
+    assert abs(np.median(a2[bright] / a1[bright]) - 2.0) < 0.01
+
+
+def test_cfg4_production_statistics():
+    v = helpers.make_visit("cfg4")
+    reads = frames(v)
+    border = np.concatenate([reads[:, :5, :].ravel(), reads[:, -5:, :].ravel()])
+    assert abs(border.mean()) < 0.05 and abs(border.std() - 14.1 / 2.35) < 0.03    # reference pixels: read noise only
+    # a corner the scan never reaches: sky + dark, linear in time
+    t = v.read_times
+    corner = reads[1:, 900:1000, 20:400].mean(axis=(1, 2))
+    rate = np.polyfit(t, corner, 1)[0]
+    assert abs(rate - (v.sky[0] / 2.35 + 0.05)) < 0.08                             # DN/s: sky/gain + synthetic dark
+    assert reads[-1].max() > 2000 and np.isfinite(reads).all()
+
+
+def test_cfg5_cosmic_rays_and_ssv():
+    v = helpers.make_visit("cfg5")
+    rec = {}
+    frames(v, record=rec, **dict(QUIET, cosmic_rate=11.0))
+    # cosmic hits are the only thing in a region the spectrum never touches
+    acc = rec["acc"]
+    quiet = acc[:, 850:1000, 5:300]
+    hits = quiet[quiet > 0]
+    assert hits.size > 20 and hits.min() >= 10000 and np.all(hits == np.round(hits))
+    expect = 11.0 * (150 * 295) / 1024 ** 2 * v.read_times[-1]
+    assert 0.5 * expect < hits.size < 1.7 * expect
+    # SSVSine modulates the sub-sample durations by +-1.5 %
+    assert abs(rec["dur"].sum() - v.sample_durations.sum()) < 0.01 * v.sample_durations.sum()
+    ratio = rec["dur"] / v.sample_durations
+    assert 0.984 < ratio.min() < 0.99 and 1.01 < ratio.max() < 1.016

@@ -133,3 +133,19 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
     np.testing.assert_array_equal(np.asarray(frame.reads[3][0], dtype=np.float64), sci[0].data)
     di = fitsio.read(os.path.join(obs.outdir, "0000_flt.fits"))
     assert abs(di[1].data.max() - 10000.0) < 700                           # the 2-D gaussian direct image
+
+
+@pytest.mark.gpu
+def test_pipelined_visit_runner_matches_direct_calls(tmp_path):
+    import helpers
+    from wayne_amd import visit as wv
+    v = helpers.make_visit("small256", n_exposures=5)
+    runner = wv.VisitRunner(v, 0, out_dir=str(tmp_path))
+    seen = []
+    got = runner.run(wv.shard(5, 1, 2) + wv.shard(5, 0, 2), keep=True, on_reads=lambda i, r: seen.append((i, float(r[-1].max()))))
+    assert sorted(got) == [0, 1, 2, 3, 4] and [i for i, _ in seen] == [1, 3, 0, 2, 4]
+    for i in (0, 3):
+        direct = np.stack([r[0] for r in helpers.product_generator(v, i).scanning_frame(**v.frame_kwargs(i)).reads])
+        np.testing.assert_array_equal(got[i], direct)          # order of generation and slot / stream do not matter
+        h = fitsio.read(os.path.join(str(tmp_path), "%04d_raw.fits" % (i + 1)))
+        np.testing.assert_array_equal(h[1].data, direct[-1].astype(np.float64))

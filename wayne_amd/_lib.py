@@ -93,6 +93,8 @@ SYMBOLS = {
     "wayne_exposure_upload": (C.c_int, [_vp, C.c_int, C.POINTER(ExposureDesc)]),
     "wayne_exposure_run": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_download": (C.c_int, [_vp, C.c_int, _vp]),
+    "wayne_exposure_fetch_async": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_wait": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "wayne_exposure_device_reads": (_vp, [_vp, C.c_int]),
     "wayne_exposure_synthesize": (C.c_int, [_vp, C.POINTER(ExposureDesc), _vp]),
     "wayne_exposure_debug_fetch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
@@ -283,6 +285,21 @@ class Context(object):
         out = np.empty((R + 1, self.S, self.S), dtype=np.float64 if f64out else np.float32)
         self.check(self._L.wayne_exposure_download(self._h, int(slot), ptr(out)))
         return out
+
+    def fetch_async(self, slot):
+        """Enqueue the copy of the slot's reads into its pinned host buffer (returns at once)."""
+        self.check(self._L.wayne_exposure_fetch_async(self._h, int(slot)))
+
+    def wait(self, slot):
+        """Block until the slot's work is done -> its reads as a numpy VIEW of the pinned buffer
+        (valid until the slot is uploaded again; copy it to keep it)."""
+        K, W, R, f64out = self._slot_meta[slot]
+        p = C.c_void_p()
+        self.check(self._L.wayne_exposure_wait(self._h, int(slot), C.byref(p)))
+        ct = C.c_double if f64out else C.c_float
+        n = (R + 1) * self.S * self.S
+        buf = (ct * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.float64 if f64out else np.float32).reshape(R + 1, self.S, self.S)
 
     def synthesize(self, desc):
         self.upload(0, desc)

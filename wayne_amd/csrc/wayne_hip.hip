@@ -56,11 +56,17 @@ struct Slot {
   DevBuf ratio, sigl, sigh, sens, dlam;
   DevBuf counts, nwide, prefix, xpos, ypos, sub;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
+  void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait)
+  size_t pinned_cap = 0;
+  struct { unsigned long long electrons; int status; int pad; } misc_host{};
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &prefix, &xpos, &ypos, &sub, &acc, &out,
                       &misc})
       b->release();
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_cap = 0;
   }
 };
 
@@ -735,6 +741,42 @@ int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
   const size_t out_elem = (s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
   HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
   return check_status(c, s);
+}
+
+int wayne_exposure_fetch_async(wayne_ctx* c, int slot) {
+  if (!c) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "fetch_async: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "fetch_async: slot not uploaded");
+  (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
+  const size_t SS = (size_t)c->S * c->S;
+  const size_t bytes = (size_t)(s.R + 1) * SS * ((s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float));
+  if (s.pinned_cap < bytes) {
+    if (s.pinned) (void)hipHostFree(s.pinned);
+    s.pinned = nullptr;
+    s.pinned_cap = 0;
+    if (hipHostMalloc(&s.pinned, bytes, hipHostMallocDefault) != hipSuccess)
+      return fail(c, WAYNE_E_NOMEM, "fetch_async: pinned host allocation failed");
+    s.pinned_cap = bytes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&s.misc_host, s.misc.p, sizeof s.misc_host, hipMemcpyDeviceToHost, c->stream));
+  return WAYNE_OK;
+}
+
+int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
+  if (!c || !host_reads) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "wait: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded || !s.pinned) return fail(c, WAYNE_E_STATE, "wait: fetch_async first");
+  (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *host_reads = s.pinned;
+  if (s.misc_host.status != 0)
+    return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  return WAYNE_OK;
 }
 
 void* wayne_exposure_device_reads(wayne_ctx* c, int slot) {

@@ -62,37 +62,38 @@ class VisitRunner(object):
         return self.generator(i).build_descriptor(eng, out_dtype=self.out_dtype,
                                                   **self.visit.frame_kwargs(i, **self.frame_overrides))
 
-    def run(self, indices, keep=False):
-        """Synthesise the given exposures.  The next exposure's host preparation and
-        upload overlap the current one's kernels (two HBM slots, asynchronous launch).
-        Returns {index: reads} when keep=True; writes FITS files when out_dir is set."""
+    def run(self, indices, keep=False, on_reads=None):
+        """Synthesise the given exposures as a pipeline over the context's two HIP streams and
+        pinned host buffers: while exposure n's kernels and its device-to-host copy run, the host
+        prepares and uploads exposure n+1 into the other slot.  `on_reads(i, reads)` is called with
+        a view of the pinned buffer (copy it to keep it); keep=True returns {index: copy};
+        FITS files are written when out_dir is set."""
         eng = self.engine()
         ctx = eng.ctx
         results = {}
-        indices = list(indices)
-        pending = None
+        pending = []                       # [(index, slot, generator)] in flight, oldest first
         for n, i in enumerate(indices):
             slot = n % 2
             gen = self.generator(i)
             desc = gen.build_descriptor(eng, out_dtype=self.out_dtype,
                                         **self.visit.frame_kwargs(i, **self.frame_overrides))
-            if pending is not None and pending[1] == slot:
-                self._finish(ctx, pending, results, keep)
-                pending = None
+            if len(pending) == 2:          # the slot about to be reused must be drained first
+                self._finish(ctx, pending.pop(0), results, keep, on_reads)
             ctx.upload(slot, desc)
-            ctx.run(slot)                       # asynchronous
-            if pending is not None:
-                self._finish(ctx, pending, results, keep)
-            pending = (i, slot, gen)
-        if pending is not None:
-            self._finish(ctx, pending, results, keep)
+            ctx.run(slot)                  # asynchronous on the slot's stream
+            ctx.fetch_async(slot)          # ... followed by its copy to pinned host memory
+            pending.append((i, slot, gen))
+        while pending:
+            self._finish(ctx, pending.pop(0), results, keep, on_reads)
         return results
 
-    def _finish(self, ctx, pending, results, keep):
+    def _finish(self, ctx, pending, results, keep, on_reads=None):
         i, slot, gen = pending
-        reads = ctx.download(slot)
+        reads = ctx.wait(slot)
+        if on_reads is not None:
+            on_reads(i, reads)
         if keep:
-            results[i] = reads
+            results[i] = reads.copy()
         if self.out_dir is not None:
             os.makedirs(self.out_dir, exist_ok=True)
             exp = Exposure(gen.detector, gen.grism, None, gen.exp_info)
