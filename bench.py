@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-f64", action="store_true", help="float64 reads (the reference's dtype)")
+    ap.add_argument("--thrower", default="split", choices=["split", "electron"],
+                    help="split: narrow PSF component drawn as a multinomial (WAYNE_RNG_SPLIT, same distribution); "
+                         "electron: every electron thrown individually (WAYNE_RNG_PHILOX)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams in the timed region (1: kernels never co-run, so per-kernel event times are "
                          "clean; the 2-stream rate is reported separately as two_streams)")
@@ -168,12 +171,13 @@ def main():
 
     from wayne_amd.exposure_generator import ExposureGenerator
     out_dtype = np.float64 if args.out_f64 else np.float32
+    rng_mode = _lib.RNG_SPLIT if args.thrower == "split" else _lib.RNG_PHILOX
     W = None
     for j in range(total):
         i = rank + j * n_gpus
         eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                device=local_rank, seed=visit.seed, exposure_index=i)
-        desc = eg.build_descriptor(eng, out_dtype=out_dtype, **visit.frame_kwargs(i))
+        desc = eg.build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode, **visit.frame_kwargs(i))
         ctx.upload(j * (1 if args.streams == 2 else 2), desc)      # inputs resident in HBM before the timed region
         W = desc.n_wl
     ctx.synchronize()
@@ -217,7 +221,7 @@ def main():
         for j in range(total):
             ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                             device=local_rank, seed=visit.seed, exposure_index=rank + j * n_gpus
-                                            ).build_descriptor(eng, out_dtype=out_dtype,
+                                            ).build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode,
                                                                **visit.frame_kwargs(rank + j * n_gpus)))
         for j in range(args.warmup):
             ctx.run(j)
@@ -255,9 +259,11 @@ def main():
             "config": {"workload": "%s: %s spatial scan %g px/s, SUBARRAY=%d (frame %dx%d), %s NSAMP=%d, "
                                    "K=%d sub-samples, W=%d bins, %.3g electrons/exposure, all detector effects on "
                                    "(flat, sky, cosmic rays, gain, dark, non-linearity, clip, read noise), "
-                                   "Philox thrower, device-complete reads in HBM" % (
+                                   "thrower=%s, device-complete reads in HBM" % (
                                        args.config, gr.name, visit.scan_speed, visit.SUBARRAY, N, N, visit.SAMPSEQ,
-                                       visit.NSAMP, K, W, electrons),
+                                       visit.NSAMP, K, W, electrons,
+                                       "split (wide component per electron, narrow component multinomial)"
+                                       if args.thrower == "split" else "per-electron"),
                        "exposures_per_rank": args.steps, "sharding": "round-robin exposures, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_ramp", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -265,8 +271,11 @@ def main():
                          "survey_formula_bytes_per_exposure": sb,
                          "achieved_survey_formula": sb / (ramp_ms * 1e-3) / 1e9},
             "kernels_ms_per_exposure": {k: v["ms"] / max(args.steps, 1) for k, v in prof.items() if k != "electrons"},
-            "thrower": {"electrons_per_exposure": electrons, "ms": throw_ms,
-                        "electrons_per_s": electrons / (throw_ms * 1e-3) if throw_ms > 0 else None},
+            "thrower": {"mode": args.thrower, "electrons_per_exposure": electrons,
+                        "ms": throw_ms + prof["k_narrow"]["ms"] / max(prof["k_narrow"]["launches"], 1),
+                        "electrons_per_s": electrons / ((throw_ms + prof["k_narrow"]["ms"] /
+                                                         max(prof["k_narrow"]["launches"], 1)) * 1e-3)
+                        if throw_ms > 0 else None},
             "two_streams": None if two is None else {"value": two, "unit": "exposures/s",
                                                      "note": "same exposures alternating over two HIP streams"},
         }

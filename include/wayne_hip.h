@@ -40,7 +40,10 @@ extern "C" {
 
 /* rng_mode */
 #define WAYNE_RNG_REPLAY 0 /* glibc rand_r streams + OpenMP partition of the reference: bit-exact */
-#define WAYNE_RNG_PHILOX 1 /* Philox4x32-10 counters (production)             */
+#define WAYNE_RNG_PHILOX 1 /* Philox-keyed streams, every electron thrown individually */
+#define WAYNE_RNG_SPLIT 2  /* as 1 for the wide PSF component; the narrow component of each
+                              well-populated bin is drawn as one multinomial (binomial chains):
+                              the same distribution of the frame, several times less work      */
 
 /* wayne_exposure_desc.flags -- the keyword switches of
  * ExposureGenerator.scanning_frame (exposure_generator.py:178-192) */
@@ -241,7 +244,7 @@ int wayne_exposure_run_back(wayne_ctx *ctx, int slot);
 
 /* ---- measurement ------------------------------------------------------- */
 
-#define WAYNE_PROF_KERNELS 6
+#define WAYNE_PROF_KERNELS 7
 typedef struct wayne_profile {
   /* per kernel: launches and total milliseconds measured with HIP events on
    * the context stream since wayne_profile_reset */

@@ -1,0 +1,139 @@
+"""GPU: rng_mode WAYNE_RNG_SPLIT -- the narrow PSF component drawn as a multinomial
+(k_narrow) -- must give the SAME DISTRIBUTION of frames as throwing every electron
+(rng_mode WAYNE_RNG_PHILOX), and conserve electrons exactly.
+
+There is no per-electron correspondence between the two modes, so the checks are
+statistical, each against an analytic expectation:
+  * a lone bin with n narrow electrons: pixel counts ~ multinomial(n; p_ij) with
+    p_ij from the gaussian cdf (scipy) -> chi-square over the populated cells;
+  * thousands of isolated identical bins in one call: the count of the central
+    pixel ~ Binomial(n, p_c) -> chi-square of its histogram, plus exact totals;
+  * whole exposures in the two modes: pixel differences scaled by their Poisson
+    error have zero mean and unit variance.
+"""
+import numpy as np
+import pytest
+from scipy import special, stats
+
+import helpers
+from wayne_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+P_SIGL = [0.69245668, -2.1043046, 2.22284446, -0.29689335]
+
+
+def cell_probs(pos, sigma, lo, hi):
+    edges = np.arange(lo, hi + 1)
+    cdf = special.ndtr((edges - pos) / sigma)
+    return np.diff(cdf)
+
+
+@pytest.mark.parametrize("sigma,fx,fy", [(0.55, 0.5, 0.5), (0.8, 0.07, 0.93), (0.89, 0.999, 0.001), (0.51, 0.3, 0.6)])
+def test_lone_bin_is_multinomial(gpu_ctx, sigma, fx, fy):
+    n, N = 3_000_000, 64
+    x, y = 30 + fx, 33 + fy
+    f = gpu_ctx.psf_apply([n], [x], [y], [0.0], [sigma], [5.0], N, N, 11, rng_mode=_lib.RNG_SPLIT).reshape(N, N)
+    assert f.sum() == n                                              # nothing lost, nothing invented
+    px, py = cell_probs(x, sigma, 0, N), cell_probs(y, sigma, 0, N)
+    expect = n * np.outer(py, px)
+    big = expect > 25
+    assert big.sum() >= 9
+    chi2 = ((f[big] - expect[big]) ** 2 / expect[big]).sum() + (f[~big].sum() - expect[~big].sum()) ** 2 / max(expect[~big].sum(), 1)
+    dof = big.sum()
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), "chi2 %.1f for %d dof" % (chi2, dof)
+    # the same check on the per-electron thrower, as a control of the test itself
+    g = gpu_ctx.psf_apply([n], [x], [y], [0.0], [sigma], [5.0], N, N, 11, rng_mode=_lib.RNG_PHILOX).reshape(N, N)
+    chi2g = ((g[big] - expect[big]) ** 2 / expect[big]).sum()
+    assert chi2g < dof + 5 * np.sqrt(2 * dof) + 20                   # fp32 positions: slightly looser
+
+
+def test_isolated_bins_binomial_marginals(gpu_ctx):
+    n, N, step = 1000, 1014, 14
+    gx, gy = np.meshgrid(np.arange(70), np.arange(70))
+    x = (12 + step * gx + 0.37).ravel().astype(float)
+    y = (12 + step * gy + 0.81).ravel().astype(float)
+    W = x.size
+    sigma = 0.62
+    counts = np.full(W, n, dtype=np.int32)
+    f = gpu_ctx.psf_apply(counts, x, y, np.zeros(W), np.full(W, sigma), np.full(W, 5.0), N, N, 5,
+                          rng_mode=_lib.RNG_SPLIT).reshape(N, N)
+    assert f.sum() == n * W
+    cx, cy = np.floor(x).astype(int), np.floor(y).astype(int)
+    # every bin's own 13 x 13 window holds exactly its n electrons
+    tot = np.array([f[j - 6:j + 7, i - 6:i + 7].sum() for i, j in zip(cx, cy)])
+    assert np.all(tot == n)
+    for dx, dy in [(0, 0), (1, 0), (0, -1), (-1, 1)]:
+        p = cell_probs(x[0], sigma, cx[0] + dx, cx[0] + dx + 1)[0] * cell_probs(y[0], sigma, cy[0] + dy, cy[0] + dy + 1)[0]
+        k = f[cy + dy, cx + dx]
+        assert abs(k.mean() - n * p) < 5 * np.sqrt(n * p * (1 - p) / W)
+        assert abs(k.var() / (n * p * (1 - p)) - 1) < 0.08
+        lo, hi = int(stats.binom.ppf(1e-3, n, p)), int(stats.binom.ppf(1 - 1e-3, n, p))
+        edges = np.arange(lo, hi + 2)
+        obs = np.histogram(k, bins=np.concatenate([[-1], edges, [n + 1]]))[0]
+        cdf = stats.binom.cdf(np.concatenate([[-1], edges - 1, [n]]) , n, p)
+        exp = W * np.diff(np.concatenate([[0.0], cdf[1:]]))
+        ok = exp > 5
+        chi2 = ((obs[ok] - exp[ok]) ** 2 / exp[ok]).sum()
+        assert chi2 < ok.sum() + 5 * np.sqrt(2 * ok.sum()), "cell (%d,%d): chi2 %.1f / %d" % (dx, dy, chi2, ok.sum())
+
+
+def test_spectrum_both_modes_agree_statistically(gpu_ctx):
+    from conftest import load_golden_psf
+    k = load_golden_psf("s256_t4")
+    counts = (k["counts"].astype(np.int64) * 60).astype(np.int32)      # ~1e7 electrons: most bins split
+    a = np.zeros(256 * 256)
+    b = np.zeros(256 * 256)
+    reps = 6
+    for s in range(reps):
+        a += gpu_ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 256, 256, 100 + s, rng_mode=_lib.RNG_PHILOX)
+        b += gpu_ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 256, 256, 200 + s, rng_mode=_lib.RNG_SPLIT)
+    assert a.sum() == b.sum() == reps * counts.sum()                    # this spectrum stays on the frame
+    bright = (a + b) > 400
+    z = (a[bright] - b[bright]) / np.sqrt(a[bright] + b[bright])
+    assert bright.sum() > 3000
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and 0.93 < z.std() < 1.04   # (multinomial: a touch below Poisson)
+    # faint wings too: summed over rows far from the trace
+    prof_a, prof_b = a.reshape(256, 256).sum(axis=1), b.reshape(256, 256).sum(axis=1)
+    far = np.abs(np.arange(256) - 80) > 12
+    assert abs(prof_a[far].sum() - prof_b[far].sum()) < 5 * np.sqrt(prof_a[far].sum() + prof_b[far].sum())
+
+
+def test_split_mode_deterministic_sparse_and_edges(gpu_ctx):
+    from conftest import load_golden_psf
+    k = load_golden_psf("edge_low")                                      # spectrum running off the frame
+    counts = (k["counts"].astype(np.int64) * 20).astype(np.int32)
+    args = (counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 64, 64, 9)
+    a = gpu_ctx.psf_apply(*args, rng_mode=_lib.RNG_SPLIT)
+    b = gpu_ctx.psf_apply(*args, rng_mode=_lib.RNG_SPLIT)
+    np.testing.assert_array_equal(a, b)
+    f = a.reshape(64, 64)
+    assert f[0, :].sum() == 0 and f[:, 0].sum() == 0                     # row / column 0 never populated (:93)
+    ref = np.mean([gpu_ctx.psf_apply(*args[:-1], 50 + s, rng_mode=_lib.RNG_PHILOX).sum() for s in range(4)])
+    assert abs(a.sum() - ref) < 6 * np.sqrt(ref)                         # same loss off the edges
+    # sparse bins (< 32 narrow electrons) are thrown one by one: modes coincide exactly
+    small = load_golden_psf("s64_t1")
+    s1 = gpu_ctx.psf_apply(small["counts"] // 3, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3,
+                           rng_mode=_lib.RNG_PHILOX)
+    s2 = gpu_ctx.psf_apply(small["counts"] // 3, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3,
+                           rng_mode=_lib.RNG_SPLIT)
+    assert (small["counts"] // 3).max() < 32
+    np.testing.assert_array_equal(s1, s2)
+
+
+def test_exposure_split_vs_per_electron():
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0, add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False,
+                        add_read_noise=False, add_non_linear=False)
+    pg = helpers.product_generator(v, 0)
+    ra, rb = {}, {}
+    a = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_PHILOX, out_dtype=np.float64, record=ra, **kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, record=rb, **kw).reads])
+    np.testing.assert_array_equal(ra["counts"], rb["counts"])
+    ea, eb = ra["acc"].sum(axis=0), rb["acc"].sum(axis=0)
+    assert abs(ea.sum() - eb.sum()) < 1e-3 * ea.sum()                    # only the flat weights differ per electron
+    bright = ea + eb > 600
+    z = (ea[bright] - eb[bright]) / np.sqrt(ea[bright] + eb[bright])
+    assert bright.sum() > 500 and abs(z.mean()) < 0.15 and 0.85 < z.std() < 1.08
+    c = np.stack([r[0] for r in pg.scanning_frame(rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, **kw).reads])
+    np.testing.assert_array_equal(b, c)                                   # deterministic

@@ -13,7 +13,7 @@ from . import build as _build
 
 # status codes (wayne_hip.h)
 OK, E_INVALID, E_NEGATIVE, E_OVERFLOW, E_NOMEM, E_HIP, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
-RNG_REPLAY, RNG_PHILOX = 0, 1
+RNG_REPLAY, RNG_PHILOX, RNG_SPLIT = 0, 1, 2
 F_ADD_FLAT = 1 << 0
 F_ADD_GAIN_VARIATIONS = 1 << 1
 F_ADD_NON_LINEAR = 1 << 2
@@ -24,7 +24,7 @@ F_ADD_DARK = 1 << 6
 F_ADD_INITIAL_BIAS = 1 << 7
 F_OUT_F64 = 1 << 16
 F_EXACT_SAMPLERS = 1 << 17
-PROF_KERNELS = 6
+PROF_KERNELS = 7
 
 
 class WayneError(RuntimeError):

@@ -197,6 +197,7 @@ struct PrepArgs {
   int max_tile;              // LDS tile capacity (ints)
   uint32_t seed, exposure;
   uint32_t flags;
+  int split_min;             // > 0: WAYNE_RNG_SPLIT -- bins with >= split_min narrow electrons go to k_narrow
   double scale_factor;
   const double* wl;          // [W]
   const double* flux;        // [W]
@@ -210,7 +211,8 @@ struct PrepArgs {
   // outputs
   int32_t* counts;           // [K*W]
   int32_t* nwide;            // [K*W]
-  uint32_t* prefix;          // [K*(W+1)] exclusive prefix of counts
+  int32_t* nsplit;           // [K*W] narrow electrons handed to k_narrow (split mode), else 0
+  uint32_t* prefix;          // [K*(W+1)] exclusive prefix of the electrons k_throw throws one by one
   double* xpos;              // [K*W] frame coords (x_sub)
   double* ypos;              // [K*W]
   SubInfo* sub;              // [K]
@@ -219,6 +221,7 @@ struct PrepArgs {
 };
 
 constexpr int kPrepThreads = 512;
+constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 
 __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
   const int k = blockIdx.x;
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
 
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
   bool overflow = false;
+  unsigned long long n_split_total = 0;   // per thread
 
   // Chunks of kPrepThreads bins, in order, so the prefix is bin-major.
   for (int base = 0; base < W; base += kPrepThreads) {
@@ -307,6 +311,17 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
         xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
         ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
       }
+      // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one
+      // multinomial by k_narrow; k_throw keeps the wide electrons (and whole sparse bins)
+      if (a.nsplit) {
+        const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
+        const uint32_t narrow = c - wide;
+        const double sl = a.wa.sigl[w];
+        const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
+                           sl * 6.5 <= (double)kNarrowR;
+        a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
+        if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
+      }
     }
     // block-wide exclusive scan of c: shuffle scan inside each wave, then the
     // 16 wave totals through LDS
@@ -348,6 +363,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     s_red[2][wave] = ymin; s_red[3][wave] = ymax;
   }
   if (overflow) atomicExch(a.status, 1);
+  if (n_split_total) atomicAdd(a.total_electrons, n_split_total);
   __syncthreads();
   if (tid == 0) {
     for (int i = 1; i < NW; ++i) {
@@ -429,6 +445,7 @@ struct ThrowArgs {
   const SubInfo* sub;      // [K]
   const uint32_t* prefix;  // [K*(W+1)]
   const int32_t* nwide;    // [K*W]
+  const int32_t* nsplit;   // [K*W] (k_narrow)
   const double* xpos;      // [K*W]
   const double* ypos;      // [K*W]
   const double* sigl;      // [W]
@@ -616,6 +633,132 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   __syncthreads();
   // flush the tile
   for (int i = tid; i < tarea; i += kThrowThreads) {
+    const int n = tile[i];
+    if (n > 0) {
+      const int ly = i / tw, lx = i - ly * tw;
+      deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, n);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_narrow : the narrow PSF component of a bin as ONE multinomial draw
+// ---------------------------------------------------------------------------
+// Throwing n electrons independently at pixels with probabilities p_ij is the
+// multinomial(n; p_ij) distribution of the pixel counts.  For the narrow
+// gaussian (sigma_l = 0.5-0.9 px, ~80 % of the electrons, pyparallel_menu.c:99-107)
+// nearly all of the mass sits in a 5 x 5 block, so the counts are drawn
+// directly: x and y are independent, so first the column counts (a chain of
+// conditional binomials, centre column outwards), then each non-empty column's
+// row counts.  Cell probabilities are differences of gaussian upper tails
+// (pixel i holds positions [i, i+1): the reference's (int) truncation, which is
+// floor() wherever a pixel is kept, :91-93).  ~30-40 binomial draws replace
+// ~1400 electron throws per bin; the distribution of the frame is the same.
+//
+// One lane per bin, 256 consecutive bins per workgroup, cells visited in
+// lockstep with wave-level skipping (a cell is processed only while some lane
+// still holds electrons).  Random words: the bin's STAGE_NARROW stream.
+constexpr int kNarrowThreads = 256;
+constexpr int kNarrowCells = 2 * kNarrowR + 1;
+constexpr int kNarrowTile = 4096;       // ints of LDS for the workgroup's tile
+
+__device__ __forceinline__ float upper_tail(float t) { return 0.5f * erfcf(t * 0.70710678118654752f); }
+
+template <int FLUSH, bool FAST>
+__global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
+  typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
+  __shared__ int tile[kNarrowTile];
+  __shared__ float s_q[kNarrowCells][kNarrowThreads];   // row probabilities of each lane's bin
+  __shared__ int s_box[4];
+  const int k = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int w = blockIdx.x * kNarrowThreads + tid;
+  const SubInfo si = a.sub[k];
+  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;
+  if (!__syncthreads_or(n0 > 0)) return;
+
+  float x = 0.f, y = 0.f, sg = 1.f;
+  int ic0 = 0, jc0 = 0;
+  if (n0 > 0) {
+    x = (float)a.xpos[(size_t)k * a.W + w];
+    y = (float)a.ypos[(size_t)k * a.W + w];
+    sg = (float)a.sigl[w];
+    ic0 = (int)floorf(x);
+    jc0 = (int)floorf(y);
+  }
+  // workgroup tile = bounding box of its bins' windows, clipped to [1, N)
+  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
+  __syncthreads();
+  if (n0 > 0) {
+    atomicMin(&s_box[0], ic0 - kNarrowR); atomicMax(&s_box[1], ic0 + kNarrowR + 1);
+    atomicMin(&s_box[2], jc0 - kNarrowR); atomicMax(&s_box[3], jc0 + kNarrowR + 1);
+  }
+  __syncthreads();
+  int tx0 = max(s_box[0], 1), tx1 = min(s_box[1], a.N), ty0 = max(s_box[2], 1), ty1 = min(s_box[3], a.N);
+  int tw = max(tx1 - tx0, 0), th = max(ty1 - ty0, 0);
+  if ((long long)tw * th > kNarrowTile) { th = min(th, kNarrowTile / max(tw, 1)); if (th < 1) { th = 0; tw = 0; } }
+  const int tarea = tw * th;
+  for (int i = tid; i < tarea; i += kNarrowThreads) tile[i] = 0;
+
+  const float inv_s = 1.f / sg;
+  // row probabilities, centre-out: c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)
+  {
+    const float f = y - (float)jc0;
+    float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
+    s_q[0][tid] = 1.f - up - lo;
+    for (int c = 1; c < kNarrowCells; ++c) {
+      const int d = (c + 1) >> 1;
+      if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); s_q[c][tid] = up - nx; up = nx; }
+      else       { const float nx = upper_tail(((float)d + f) * inv_s);       s_q[c][tid] = lo - nx; lo = nx; }
+    }
+  }
+  __syncthreads();
+
+  SeededStream rng(a.seed, STAGE_NARROW, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
+  const float fx = x - (float)ic0;
+  float up = upper_tail((1.f - fx) * inv_s), lo = upper_tail(fx * inv_s);
+  float n_rem = (float)n0;
+  for (int c = 0; c < kNarrowCells; ++c) {
+    if (!__any(n_rem > 0.f)) break;
+    // this column's mass and the mass of everything not yet visited (before it)
+    const int d = (c + 1) >> 1;
+    const int ci = (c == 0) ? ic0 : ((c & 1) ? ic0 + d : ic0 - d);
+    float P, rem;
+    if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
+    else if (c & 1) { const float nx = upper_tail(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
+    else            { const float nx = upper_tail(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
+    float n_col = 0.f;
+    if (n_rem > 0.f) {
+      const float pc = fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
+      n_col = binomial<M>(n_rem, pc, rng);
+      n_rem -= n_col;
+    }
+    if (!__any(n_col > 0.f)) continue;
+    // rows of this column
+    float m_rem = n_col, qrem = 1.f;
+    for (int r = 0; r < kNarrowCells; ++r) {
+      if (!__any(m_rem > 0.f)) break;
+      const float Q = s_q[r][tid];
+      float m = 0.f;
+      if (m_rem > 0.f) {
+        const float qc = fminf(fmaxf(M::div_(Q, qrem), 0.f), 1.f);
+        m = binomial<M>(m_rem, qc, rng);
+        m_rem -= m;
+      }
+      qrem -= Q;
+      if (m > 0.f) {
+        const int e = (r + 1) >> 1;
+        const int rj = (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e);
+        const int lx = ci - tx0, ly = rj - ty0;
+        if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+          atomicAdd(&tile[ly * tw + lx], (int)m);
+        else if (ci > 0 && ci < a.N && rj > 0 && rj < a.N)       // (:93)
+          deposit_global<FLUSH>(a, si, ci, rj, (int)m);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < tarea; i += kNarrowThreads) {
     const int n = tile[i];
     if (n > 0) {
       const int ly = i / tw, lx = i - ly * tw;

@@ -34,6 +34,8 @@ enum Stage : uint32_t {
   STAGE_READ = 6,     // seeded stream (pixel, 0, 0, exposure): words 2i, 2i+1 -> (dark, read-noise) normals of read i (0 = zero read)
   STAGE_NOISE = 7,    // seeded stream (pixel, 0, 0, exposure): words 2r, 2r+1 -> optional gaussian noise of read interval r
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
+  STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's
+                      //   narrow-PSF electrons over pixels (k_narrow, rng_mode WAYNE_RNG_SPLIT)
 };
 constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 

@@ -32,6 +32,7 @@ template <> struct ExactMath<float> {
   static WAYNE_HD float floor_(float x) { return floorf(x); }
   static WAYNE_HD float abs_(float x) { return fabsf(x); }
   static WAYNE_HD float div_(float a, float b) { return a / b; }
+  static WAYNE_HD float log1m_(float p) { return log1pf(-p); }   // ln(1 - p) without losing a small p
   // PTRS acceptance: log V + log(1/alpha) - log(a/us^2 + b) <= rhs
   static WAYNE_HD bool accept(float V, float invalpha, float den, float rhs) {
     return logf(V) + logf(invalpha) - logf(den) <= rhs;
@@ -46,6 +47,7 @@ template <> struct ExactMath<double> {
   static WAYNE_HD double floor_(double x) { return floor(x); }
   static WAYNE_HD double abs_(double x) { return fabs(x); }
   static WAYNE_HD double div_(double a, double b) { return a / b; }
+  static WAYNE_HD double log1m_(double p) { return log1p(-p); }
   static WAYNE_HD bool accept(double V, double invalpha, double den, double rhs) {
     return log(V) + log(invalpha) - log(den) <= rhs;
   }
@@ -61,6 +63,9 @@ struct FastMath {
   static __device__ __forceinline__ float floor_(float x) { return floorf(x); }
   static __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
   static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float log1m_(float p) {
+    return p < 0.01f ? -p * (1.f + p * (0.5f + p * (0.33333334f + 0.25f * p))) : log_(1.f - p);
+  }
   // the three logs folded into one: log(V * invalpha / den)
   static __device__ __forceinline__ bool accept(float V, float invalpha, float den, float rhs) {
     return log_(V * invalpha * __builtin_amdgcn_rcpf(den)) <= rhs;
@@ -146,6 +151,81 @@ WAYNE_HD typename M::type poisson(typename M::type lam, RNG& rng) {
     if (ps.trial(w1, w2, k)) return k;
   }
   return M::floor_(lam + (T)0.5);
+}
+
+// ---------------------------------------------------------------------------
+// Binomial(n, p): exact.  Inversion by sequential search (Kachitvichyanukul &
+// Schmeiser's BINV) when n min(p, 1-p) < 10, Hoermann's BTRS transformed
+// rejection otherwise ("The generation of binomial random variates", J. Stat.
+// Comput. Simul. 46, 1993) -- the binomial sibling of the PTRS sampler above.
+// Used to split the electrons of a bin over pixels as ONE multinomial draw
+// instead of throwing them one by one (k_narrow).
+// ---------------------------------------------------------------------------
+// ln k! - [ln sqrt(2 pi) + (k + 1/2) ln(k + 1) - (k + 1)]
+template <class M>
+WAYNE_HD typename M::type stirling_tail(typename M::type k) {
+  typedef typename M::type T;
+  if (k < (T)10) {
+    const int i = (int)k;
+    // exact values for k = 0..9
+    return i == 0 ? (T)0.0810614667953272 : i == 1 ? (T)0.0413406959554092 : i == 2 ? (T)0.0276779256849983
+         : i == 3 ? (T)0.02079067210376509 : i == 4 ? (T)0.0166446911898211 : i == 5 ? (T)0.0138761288230707
+         : i == 6 ? (T)0.0118967099458917 : i == 7 ? (T)0.0104112652619720 : i == 8 ? (T)0.00925546218271273
+                  : (T)0.00833056343336287;
+  }
+  const T kp1 = k + (T)1;
+  const T kp1sq = kp1 * kp1;
+  return M::div_((T)(1.0 / 12) - M::div_((T)(1.0 / 360) - M::div_((T)(1.0 / 1260), kp1sq), kp1sq), kp1);
+}
+
+template <class M, class RNG>
+WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& rng) {
+  typedef typename M::type T;
+  if (!(n > (T)0) || !(p > (T)0)) return (T)0;
+  if (p >= (T)1) return n;
+  const bool flip = p > (T)0.5;
+  if (flip) p = (T)1 - p;
+  const T q = (T)1 - p;
+  T x = (T)0;
+  if (n * p < (T)10) {
+    // BINV: walk the pmf from 0 with f(x) = f(x-1) ((n+1) s / x - s), s = p/q
+    const T s = M::div_(p, q);
+    const T a = (n + (T)1) * s;
+    T r = M::exp_(n * M::log1m_(p));
+    T u = M::u01(rng.next());
+    for (int it = 0; it < 256; ++it) {
+      if (u <= r) break;
+      u = u - r;
+      x = x + (T)1;
+      r = r * (M::div_(a, x) - s);
+      if (x >= n) { x = n; break; }
+    }
+  } else {
+    const T spq = M::sqrt_(n * p * q);
+    const T b = (T)1.15 + (T)2.53 * spq;
+    const T a = (T)-0.0873 + (T)0.0248 * b + (T)0.01 * p;
+    const T c = n * p + (T)0.5;
+    const T vr = (T)0.92 - M::div_((T)4.2, b);
+    const T alpha = ((T)2.83 + M::div_((T)5.1, b)) * spq;
+    const T m = M::floor_((n + (T)1) * p);
+    const T r = M::div_(p, q);
+    x = M::floor_(n * p + (T)0.5);   // returned only if the (unreachable) iteration cap is hit
+    for (int it = 0; it < 256; ++it) {
+      const T U = M::u01(rng.next()) - (T)0.5;
+      const T V = M::u01(rng.next());
+      const T us = (T)0.5 - M::abs_(U);
+      const T k = M::floor_((M::div_((T)2 * a, us) + b) * U + c);
+      if (us >= (T)0.07 && V <= vr) { x = k; break; }
+      if (k < (T)0 || k > n) continue;
+      const T v = M::log_(M::div_(V * alpha, M::div_(a, us * us) + b));
+      const T nm = n - m + (T)1, nk = n - k + (T)1;
+      const T ub = (m + (T)0.5) * M::log_(M::div_(m + (T)1, r * nm)) + (n + (T)1) * M::log_(M::div_(nm, nk)) +
+                   (k + (T)0.5) * M::log_(M::div_(r * nk, k + (T)1)) + stirling_tail<M>(m) +
+                   stirling_tail<M>(n - m) - stirling_tail<M>(k) - stirling_tail<M>(n - k);
+      if (v <= ub) { x = k; break; }
+    }
+  }
+  return flip ? n - x : x;
 }
 
 }  // namespace wayne

@@ -19,9 +19,9 @@ using namespace wayne;
 
 namespace {
 
-enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE };
+enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE, PK_NARROW };
 const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub", "k_throw",
-                                                    "k_cosmic",  "k_ramp",     "k_lightcurve"};
+                                                    "k_cosmic",  "k_ramp",     "k_lightcurve", "k_narrow"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -54,14 +54,14 @@ struct Slot {
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
   DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;
   DevBuf ratio, sigl, sigh, sens, dlam;
-  DevBuf counts, nwide, prefix, xpos, ypos, sub;
+  DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait)
   size_t pinned_cap = 0;
   struct { unsigned long long electrons; int status; int pad; } misc_host{};
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
-                      &sigh, &sens, &dlam, &counts, &nwide, &prefix, &xpos, &ypos, &sub, &acc, &out,
+                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &acc, &out,
                       &misc})
       b->release();
     if (pinned) (void)hipHostFree(pinned);
@@ -102,7 +102,7 @@ struct wayne_ctx {
        has_zero = false;
   Slot slots[kSlots];
   // psf_apply scratch
-  DevBuf pa_prefix, pa_nwide, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
+  DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -216,6 +216,17 @@ int launch_throw(wayne_ctx* c, const ThrowArgs& a, int lds_ints) {
   return WAYNE_OK;
 }
 
+constexpr int kSplitMin = 32;   // bins with fewer narrow electrons are thrown one by one
+
+template <int FLUSH>
+int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
+  const dim3 grid((unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads), (unsigned)a.K);
+  if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_narrow<FLUSH, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return WAYNE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -287,7 +298,7 @@ void wayne_ctx_destroy(wayne_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& s : c->slots) s.release();
   for (DevBuf* b : {&c->counters, &c->sens_wl, &c->sens_val, &c->pfl, &c->sky, &c->dark_sci, &c->dark_err, &c->zero_read,
-                    &c->pa_prefix, &c->pa_nwide, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
+                    &c->pa_prefix, &c->pa_nwide, &c->pa_nsplit, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
@@ -320,7 +331,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
                 "psf_apply: only square frames (the reference indexes ypos*nc+xpos but bounds xpos by nr)");
   if (size > 0 && (!counts || !x_pos || !y_pos || !psf_ratio || !psf_sigmal || !psf_sigmah))
     return fail(c, WAYNE_E_INVALID, "psf_apply: null input");
-  if (rng_mode != WAYNE_RNG_REPLAY && rng_mode != WAYNE_RNG_PHILOX)
+  if (rng_mode != WAYNE_RNG_REPLAY && rng_mode != WAYNE_RNG_PHILOX && rng_mode != WAYNE_RNG_SPLIT)
     return fail(c, WAYNE_E_INVALID, "psf_apply: rng_mode");
   if (rng_mode == WAYNE_RNG_REPLAY && threads_compat <= 0)
     return fail(c, WAYNE_E_INVALID, "psf_apply: threads_compat must be >= 1 in replay mode");
@@ -343,17 +354,28 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
 
   if (total > 0) {
     std::vector<uint32_t> prefix((size_t)size + 1);
-    std::vector<int32_t> nwide((size_t)size);
+    std::vector<int32_t> nwide((size_t)size), nsplit((size_t)size, 0);
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     uint32_t run = 0;
+    bool any_split = false;
     for (int i = 0; i < size; ++i) {
       prefix[i] = run;
-      run += (uint32_t)counts[i];
       const double nw = (double)counts[i] * psf_ratio[i];  // N = counts*ratio (:89)
       nwide[i] = (nw >= 2147483647.) ? 2147483647
                  : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1)
                  : (!(nw == nw))        ? (int32_t)(-2147483647 - 1)
                                         : (int32_t)nw;
+      uint32_t thrown = (uint32_t)counts[i];
+      if (rng_mode == WAYNE_RNG_SPLIT) {      // same rule as k_prep_sub
+        const uint32_t wide = (uint32_t)std::min<int64_t>(std::max(nwide[i], 0), counts[i]);
+        const uint32_t narrow = (uint32_t)counts[i] - wide;
+        if (narrow >= (uint32_t)kSplitMin && psf_sigmal[i] > 0.05 && psf_sigmal[i] * 6.5 <= (double)kNarrowR) {
+          nsplit[i] = (int32_t)narrow;
+          thrown = wide;
+          any_split = true;
+        }
+      }
+      run += thrown;
       if (counts[i] > 0 && std::isfinite(x_pos[i]) && std::isfinite(y_pos[i])) {
         xmin = std::min(xmin, x_pos[i]); xmax = std::max(xmax, x_pos[i]);
         ymin = std::min(ymin, y_pos[i]); ymax = std::max(ymax, y_pos[i]);
@@ -380,6 +402,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     int rc;
     if ((rc = upload(c, c->pa_prefix, prefix.data(), prefix.size()))) return rc;
     if ((rc = upload(c, c->pa_nwide, nwide.data(), nwide.size()))) return rc;
+    if ((rc = upload(c, c->pa_nsplit, nsplit.data(), nsplit.size()))) return rc;
     if ((rc = upload(c, c->pa_x, x_pos, (size_t)size))) return rc;
     if ((rc = upload(c, c->pa_y, y_pos, (size_t)size))) return rc;
     if ((rc = upload(c, c->pa_sl, psf_sigmal, (size_t)size))) return rc;
@@ -396,17 +419,22 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.sub = c->pa_sub.as<SubInfo>();
     a.prefix = c->pa_prefix.as<uint32_t>();
     a.nwide = c->pa_nwide.as<int32_t>();
+    a.nsplit = c->pa_nsplit.as<int32_t>();
     a.xpos = c->pa_x.as<double>(); a.ypos = c->pa_y.as<double>();
     a.sigl = c->pa_sl.as<double>(); a.sigh = c->pa_sh.as<double>();
     for (int i = 0; i < 4; ++i) a.flat[i] = nullptr;
     a.acc = nullptr;
     a.frame = c->pa_frame.as<int32_t>();
-    {
+    if (run > 0) {
       ProfScope ps(c, PK_THROW);
       rc = (rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 0>(c, a, lds_ints) : launch_throw<1, 0>(c, a, lds_ints);
       if (rc) return rc;
     }
-    c->electrons += run;
+    if (any_split) {
+      ProfScope ps(c, PK_NARROW);
+      if ((rc = launch_narrow<0>(c, a, false))) return rc;
+    }
+    c->electrons += (uint64_t)total;
   }
   HIP_TRY(c, hipMemcpyAsync(out, c->pa_frame.p, (size_t)N * N * sizeof(int32_t), hipMemcpyDeviceToHost,
                             c->stream));
@@ -501,7 +529,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   if (R != c->cal_R) return fail(c, WAYNE_E_INVALID, "upload: n_reads differs from the calibration's");
   if (!d->wl_um || !d->flux || !d->x_ref || !d->y_ref || !d->dur_ms || !d->sample_read || !d->read_dt_s)
     return fail(c, WAYNE_E_INVALID, "upload: null array");
-  if (d->rng_mode != WAYNE_RNG_REPLAY && d->rng_mode != WAYNE_RNG_PHILOX)
+  if (d->rng_mode != WAYNE_RNG_REPLAY && d->rng_mode != WAYNE_RNG_PHILOX && d->rng_mode != WAYNE_RNG_SPLIT)
     return fail(c, WAYNE_E_INVALID, "upload: rng_mode");
   if (d->rng_mode == WAYNE_RNG_REPLAY && (d->threads_compat <= 0 || !d->replay_seed))
     return fail(c, WAYNE_E_INVALID, "upload: replay mode needs threads_compat >= 1 and replay_seed");
@@ -537,6 +565,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   for (DevBuf* b : {&s.ratio, &s.sigl, &s.sigh, &s.sens, &s.dlam}) HIP_TRY(c, b->reserve((size_t)W * sizeof(double)));
   HIP_TRY(c, s.counts.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.nwide.reserve(KW * sizeof(int32_t)));
+  HIP_TRY(c, s.nsplit.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.prefix.reserve((size_t)K * (W + 1) * sizeof(uint32_t)));
   HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
@@ -628,6 +657,8 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.sample_read = s.sread.as<int32_t>();
     a.wa = wa;
     a.counts = s.counts.as<int32_t>(); a.nwide = s.nwide.as<int32_t>();
+    a.nsplit = s.nsplit.as<int32_t>();
+    a.split_min = (d.rng_mode == WAYNE_RNG_SPLIT) ? kSplitMin : 0;
     a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sub = s.sub.as<SubInfo>();
     a.total_electrons = c->counters.as<unsigned long long>();
@@ -652,15 +683,23 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.flat_off = (1014 - N) / 2;  // grism.py:363 (0 for the full array)
     a.flat_wmin = c->g.flat_wmin; a.flat_wmax = c->g.flat_wmax;
     a.sub = s.sub.as<SubInfo>(); a.prefix = s.prefix.as<uint32_t>(); a.nwide = s.nwide.as<int32_t>();
+    a.nsplit = s.nsplit.as<int32_t>();
     a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sigl = s.sigl.as<double>(); a.sigh = s.sigh.as<double>();
     for (int i = 0; i < 4; ++i) a.flat[i] = c->has_flat ? c->flat[i].as<float>() : nullptr;
     a.acc = s.acc.as<long long>();
     a.frame = nullptr;
     if ((d.flags & WAYNE_F_ADD_FLAT) && !c->has_flat) return fail(c, WAYNE_E_STATE, "run: add_flat without a flat cube");
-    ProfScope ps(c, PK_THROW);
-    int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
-    if (rc) return rc;
+    {
+      ProfScope ps(c, PK_THROW);
+      int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
+      if (rc) return rc;
+    }
+    if (d.rng_mode == WAYNE_RNG_SPLIT) {
+      ProfScope ps(c, PK_NARROW);
+      int rc = launch_narrow<1>(c, a, (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0);
+      if (rc) return rc;
+    }
   }
   s.acc_dirty = true;
   if (d.cosmic_rate >= 0.) {
