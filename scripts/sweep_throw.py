@@ -17,10 +17,11 @@ v = synthetic.Visit(name, det, gr, cal, n_exposures=1)
 eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
 ctx = eng.ctx
 eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
-for wgs, tile, margin in itertools.product([256, 512, 768, 1024, 1536], [10240, 12288, 16384, 20000], [24]):
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+for wgs, tile, margin in itertools.product([256, 384, 512, 768, 1024, 1536], [12288], [20, 24, 28]):
     os.environ["WAYNE_THROW_WGS"] = str(wgs)
     os.environ["WAYNE_TILE_INTS"] = str(tile)
-    desc = eg.build_descriptor(eng, **v.frame_kwargs(0))
+    desc = eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(0))
     desc.thrower_margin = margin
     ctx.upload(0, desc)
     ctx.run(0)
@@ -31,5 +32,5 @@ for wgs, tile, margin in itertools.product([256, 512, 768, 1024, 1536], [10240, 
         ctx.run(0)
     p = ctx.profile_get()
     ctx.profile_enable(False)
-    print("wgs=%5d tile=%6d margin=%2d  throw=%.3f ms" % (wgs, tile, margin, p["k_throw"]["ms"] / p["k_throw"]["launches"]),
+    print("wgs=%5d tile=%6d margin=%2d  throw=%.3f ms narrow=%.3f" % (wgs, tile, margin, p["k_throw"]["ms"] / p["k_throw"]["launches"], p["k_narrow"]["ms"] / max(p["k_narrow"]["launches"], 1)),
           flush=True)

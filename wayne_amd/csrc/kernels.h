@@ -51,6 +51,7 @@ struct SubInfo {
   int pad_;
   double x_ref, y_ref;     // star position of the sub-sample (full-frame coords)
   double a_t_i, a_w, b_w;  // 1/m_t, m_w, c_w for the flat (grism.py:365-372)
+  double inv_norm;         // 1 / sqrt(a_t_i^2 + 1)
 };
 
 struct WlArrays {   // all [W]
@@ -218,27 +219,18 @@ struct PrepArgs {
   SubInfo* sub;              // [K]
   unsigned long long* total_electrons;  // += E_k
   int* status;               // set non-zero on overflow
+  uint32_t* chunk_total;     // [K * n_chunks] electrons (for k_throw) per chunk of kPrepThreads bins
+  double* chunk_box;         // [K * n_chunks * 4] xmin, xmax, ymin, ymax of the chunk's populated bins
 };
 
 constexpr int kPrepThreads = 512;
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 
-__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
-  const int k = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int W = a.W;
-  constexpr int NW = kPrepThreads / 64;
-  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
-  __shared__ uint32_t s_wsum[NW];   // per-wave totals of the current chunk
-  __shared__ double s_red[4][NW];
-  __shared__ uint32_t s_carry;
-
-  const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
-  if (tid == 0) {
+__device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
+  // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
     // wavelength_calibration_coeffs (grism.py:779-803)
-    const double* t = a.g.trace;
-    const double* b = a.g.wlsol;
+    const double* t = g.trace;
+    const double* b = g.wlsol;
     const double m_t = t[3] + t[4] * x_ref + t[5] * y_ref + t[6] * (x_ref * x_ref) +
                        t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);
     const double c_t = t[0] + t[1] * x_ref + t[2] * y_ref;
@@ -256,9 +248,25 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     const double wb_ = (m_w * db + c_w) * 1e-4;
     const double m_wl = (wb_ - wa_) / (xb - xa);
     const double c_wl = wa_ - m_wl * xa;
-    s_tr[0] = m_t; s_tr[1] = c_t; s_tr[2] = m_w; s_tr[3] = c_w; s_tr[4] = m_wl; s_tr[5] = c_wl;
-    s_carry = 0;
-  }
+    o[0] = m_t; o[1] = c_t; o[2] = m_w; o[3] = c_w; o[4] = m_wl; o[5] = c_wl;
+}
+
+// One workgroup per (sub-sample, chunk of kPrepThreads bins): positions, counts,
+// sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the
+// chunk offsets.  K * ceil(W / 512) workgroups instead of K: the whole chip works.
+__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
+  const int k = blockIdx.x;
+  const int ch = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int W = a.W;
+  constexpr int NW = kPrepThreads / 64;
+  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
+  __shared__ uint32_t s_wsum[NW];   // per-wave totals
+  __shared__ double s_red[4][NW];
+
+  const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+  if (tid == 0) trace_coeffs(a.g, x_ref, y_ref, s_tr);
   __syncthreads();
   const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
   const double dur = a.dur_ms[k];
@@ -268,90 +276,68 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
   bool overflow = false;
   unsigned long long n_split_total = 0;   // per thread
 
-  // Chunks of kPrepThreads bins, in order, so the prefix is bin-major.
-  for (int base = 0; base < W; base += kPrepThreads) {
-    const int w = base + tid;
-    uint32_t c = 0;
-    if (w < W) {
+  const int w = ch * kPrepThreads + tid;
+  uint32_t c = 0;
+  if (w < W) {
       const double wl = a.wl[w];
-      // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
-      // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
-      const double x = (wl - c_wl) / m_wl;
-      const double y = m_t * (x - x_ref) + c_t + y_ref;
-      const double xs = x - (double)a.sub_scale;
-      const double ys = y - (double)a.sub_scale;
-      a.xpos[(size_t)k * W + w] = xs;
-      a.ypos[(size_t)k * W + w] = ys;
-      // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
-      //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
-      double f = a.flux[w];
-      if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
-      double lam = f * a.wa.sens[w];
-      lam = lam * a.wa.dlam[w];
-      lam = lam * 1e4;
-      lam = lam * dur;
-      lam = lam * 1e-3;
-      lam = lam * a.scale_factor;
-      double cnt;
-      if (noisy) {
-        PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
-        cnt = poisson<ExactMath<double> >(lam, rng);   // np.random.poisson (:626)
-      } else {
-        cnt = rint(lam);                      // np.round, half to even (:628)
-      }
-      if (!(cnt >= 0.)) cnt = 0.;             // negative / NaN flux throws no electrons
-      if (cnt > 2147483647.) { cnt = 2147483647.; overflow = true; }
-      c = (uint32_t)cnt;
-      a.counts[(size_t)k * W + w] = (int32_t)c;
-      // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
-      double nw = (double)(int32_t)c * a.wa.ratio[w];
-      int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
-      a.nwide[(size_t)k * W + w] = nwi;
-      if (c > 0) {
-        xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
-        ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
-      }
-      // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one
-      // multinomial by k_narrow; k_throw keeps the wide electrons (and whole sparse bins)
-      if (a.nsplit) {
-        const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
-        const uint32_t narrow = c - wide;
-        const double sl = a.wa.sigl[w];
-        const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
-                           sl * 6.5 <= (double)kNarrowR;
-        a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
-        if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
-      }
+    // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
+    // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
+    const double x = (wl - c_wl) / m_wl;
+    const double y = m_t * (x - x_ref) + c_t + y_ref;
+    const double xs = x - (double)a.sub_scale;
+    const double ys = y - (double)a.sub_scale;
+    a.xpos[(size_t)k * W + w] = xs;
+    a.ypos[(size_t)k * W + w] = ys;
+    // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
+    //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
+    double f = a.flux[w];
+    if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
+    double lam = f * a.wa.sens[w];
+    lam = lam * a.wa.dlam[w];
+    lam = lam * 1e4;
+    lam = lam * dur;
+    lam = lam * 1e-3;
+    lam = lam * a.scale_factor;
+    double cnt;
+    if (noisy) {
+      PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
+      cnt = poisson<ExactMath<double> >(lam, rng);   // np.random.poisson (:626)
+    } else {
+      cnt = rint(lam);                      // np.round, half to even (:628)
     }
-    // block-wide exclusive scan of c: shuffle scan inside each wave, then the
-    // 16 wave totals through LDS
-    uint32_t incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
+    if (!(cnt >= 0.)) cnt = 0.;             // negative / NaN flux throws no electrons
+    if (cnt > 2147483647.) { cnt = 2147483647.; overflow = true; }
+    c = (uint32_t)cnt;
+    a.counts[(size_t)k * W + w] = (int32_t)c;
+    // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
+    double nw = (double)(int32_t)c * a.wa.ratio[w];
+    int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
+    a.nwide[(size_t)k * W + w] = nwi;
+    if (c > 0) {
+      xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
+      ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
     }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, chunk_total = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const uint32_t t = s_wsum[i];
-      if (i < wave) wave_off += t;
-      chunk_total += t;
+    // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one
+    // multinomial by k_narrow; k_throw keeps the wide electrons (and whole sparse bins)
+    if (a.nsplit) {
+      const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
+      const uint32_t narrow = c - wide;
+      const double sl = a.wa.sigl[w];
+      const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
+                         sl * 6.5 <= (double)kNarrowR;
+      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
+      if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
     }
-    const uint32_t carry = s_carry;
-    if (w < W) {
-      const uint64_t ex = (uint64_t)carry + wave_off + incl - c;
-      if (ex + c > 0xFFFFFFFFull) overflow = true;
-      a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)ex;
-    }
-    __syncthreads();
-    if (tid == 0) s_carry = carry + chunk_total;
-    __syncthreads();
   }
-
-  // reduce the bounding box of populated bins
+  // exclusive scan of c inside the chunk: shuffle scan per wave, wave totals through LDS
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  // bounding box of populated bins
   for (int off = 32; off > 0; off >>= 1) {
     xmin = fmin(xmin, __shfl_down(xmin, off));
     xmax = fmax(xmax, __shfl_down(xmax, off));
@@ -362,15 +348,71 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     s_red[0][wave] = xmin; s_red[1][wave] = xmax;
     s_red[2][wave] = ymin; s_red[3][wave] = ymax;
   }
+  __syncthreads();
+  uint64_t wave_off = 0, chunk_total = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t t = s_wsum[i];
+    if (i < wave) wave_off += t;
+    chunk_total += t;
+  }
+  if (chunk_total > 0xFFFFFFFFull) overflow = true;
+  if (w < W) a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)(wave_off + incl - c);   // chunk-local for now
   if (overflow) atomicExch(a.status, 1);
-  if (n_split_total) atomicAdd(a.total_electrons, n_split_total);
+  // electrons handed to k_narrow: one atomic per workgroup (wave shuffle, then LDS)
+  for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
+  __shared__ unsigned long long s_split[NW];
+  if (lane == 0) s_split[wave] = n_split_total;
   __syncthreads();
   if (tid == 0) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < NW; ++i) tot += s_split[i];
+    if (tot) atomicAdd(a.total_electrons, tot);
     for (int i = 1; i < NW; ++i) {
       xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
       ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
     }
-    const uint32_t E = s_carry;
+    const size_t ci = (size_t)k * gridDim.y + ch;
+    a.chunk_total[ci] = (uint32_t)chunk_total;
+    a.chunk_box[4 * ci + 0] = xmin; a.chunk_box[4 * ci + 1] = xmax;
+    a.chunk_box[4 * ci + 2] = ymin; a.chunk_box[4 * ci + 3] = ymax;
+  }
+}
+
+// One workgroup per sub-sample: chunk offsets -> global exclusive prefix, E_k,
+// bounding box -> LDS tile rectangle, SubInfo.
+__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks) {
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int W = a.W;
+  __shared__ uint32_t s_off[64];
+  __shared__ uint32_t s_E;
+  __shared__ int s_over;
+  if (tid == 0) {
+    uint64_t run = 0;
+    int over = 0;
+    for (int i = 0; i < n_chunks; ++i) {
+      s_off[i] = (uint32_t)run;
+      run += a.chunk_total[(size_t)k * n_chunks + i];
+      if (run > 0xFFFFFFFFull) over = 1;
+    }
+    s_E = (uint32_t)run;
+    s_over = over;
+  }
+  __syncthreads();
+  for (int w = tid; w < W; w += kPrepThreads) a.prefix[(size_t)k * (W + 1) + w] += s_off[w / kPrepThreads];
+  if (tid == 0) {
+    if (s_over) atomicExch(a.status, 1);
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int i = 0; i < n_chunks; ++i) {
+      const size_t ci = (size_t)k * n_chunks + i;
+      xmin = fmin(xmin, a.chunk_box[4 * ci + 0]); xmax = fmax(xmax, a.chunk_box[4 * ci + 1]);
+      ymin = fmin(ymin, a.chunk_box[4 * ci + 2]); ymax = fmax(ymax, a.chunk_box[4 * ci + 3]);
+    }
+    const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+    double tr[6];
+    trace_coeffs(a.g, x_ref, y_ref, tr);
+    const uint32_t E = s_E;
     a.prefix[(size_t)k * (W + 1) + W] = E;
     SubInfo si;
     si.electrons = E;
@@ -378,8 +420,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
     si.replay_seed = a.replay_seed ? a.replay_seed[k] : 0;
     si.pad_ = 0;
     si.x_ref = x_ref; si.y_ref = y_ref;
-    si.a_t_i = 1. / m_t;            // grism.py:367
-    si.a_w = s_tr[2]; si.b_w = s_tr[3];
+    si.a_t_i = 1. / tr[0];            // grism.py:367
+    si.a_w = tr[2]; si.b_w = tr[3];
+    si.inv_norm = 1. / sqrt(si.a_t_i * si.a_t_i + 1.);
     // LDS tile: bounding box of the populated trace + margin, clipped to the
     // frame's populated range [1, N) (pixel row / column 0 is never hit,
     // pyparallel_menu.c:93), shrunk symmetrically if it exceeds the LDS budget
@@ -441,7 +484,7 @@ struct ThrowArgs {
   uint32_t seed, exposure, subsample0;
   uint32_t flags;
   int flat_off;            // (1014 - N) / 2  (grism.py:363)
-  double flat_wmin, flat_wmax;
+  double flat_wmin, flat_wmax, flat_inv_range;   // inv_range = 1 / (wmax - wmin)
   const SubInfo* sub;      // [K]
   const uint32_t* prefix;  // [K*(W+1)]
   const int32_t* nwide;    // [K*W]
@@ -481,9 +524,11 @@ __device__ __forceinline__ double flat_value(const ThrowArgs& a, const SubInfo& 
   // grism.py:362-385, evaluated for frame pixel (y, x)
   const int xf = x + a.flat_off, yf = y + a.flat_off;
   const double arr = si.y_ref - (double)yf + si.a_t_i * si.x_ref - si.a_t_i * (double)xf;
-  const double d = sqrt((arr * arr) / (si.a_t_i * si.a_t_i + 1));
+  // d = sqrt(arr^2 / (a_t_i^2 + 1)) = |arr| / sqrt(a_t_i^2 + 1); the reciprocals are per
+  // sub-sample constants (1 ulp of fp64 from the reference's form, then rounded to float32)
+  const double d = fabs(arr) * si.inv_norm;
   const double wl = si.a_w * d + si.b_w;
-  const double t = (wl - a.flat_wmin) / (a.flat_wmax - a.flat_wmin);
+  const double t = (wl - a.flat_wmin) * a.flat_inv_range;
   const double t2 = t * t, t3 = t2 * t;
   const size_t i = (size_t)y * a.N + x;
   const double f = (double)a.flat[0][i] + ((double)a.flat[1][i] * t) + ((double)a.flat[2][i] * t2) +

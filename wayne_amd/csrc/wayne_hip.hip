@@ -54,14 +54,14 @@ struct Slot {
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
   DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;
   DevBuf ratio, sigl, sigh, sens, dlam;
-  DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub;
+  DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait)
   size_t pinned_cap = 0;
   struct { unsigned long long electrons; int status; int pad; } misc_host{};
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
-                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &acc, &out,
+                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
                       &misc})
       b->release();
     if (pinned) (void)hipHostFree(pinned);
@@ -415,7 +415,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.splits = (int)std::min<long long>(512, std::max<long long>(1, total / (64LL * kThrowThreads)));
     a.threads_compat = threads_compat;
     a.seed = seed; a.exposure = exposure; a.subsample0 = subsample;
-    a.flags = 0; a.flat_off = 0; a.flat_wmin = 0; a.flat_wmax = 1;
+    a.flags = 0; a.flat_off = 0; a.flat_wmin = 0; a.flat_wmax = 1; a.flat_inv_range = 1;
     a.sub = c->pa_sub.as<SubInfo>();
     a.prefix = c->pa_prefix.as<uint32_t>();
     a.nwide = c->pa_nwide.as<int32_t>();
@@ -570,6 +570,12 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.sub.reserve((size_t)K * sizeof(SubInfo)));
+  {
+    const size_t n_chunks = (size_t)(W + kPrepThreads - 1) / kPrepThreads;
+    if (n_chunks > 64) return fail(c, WAYNE_E_INVALID, "upload: more than 32768 wavelength bins");
+    HIP_TRY(c, s.chunk_total.reserve((size_t)K * n_chunks * sizeof(uint32_t)));
+    HIP_TRY(c, s.chunk_box.reserve((size_t)K * n_chunks * 4 * sizeof(double)));
+  }
   HIP_TRY(c, s.misc.reserve(64));
   const size_t SS = (size_t)c->S * c->S;
   const size_t acc_bytes = (size_t)R * SS * sizeof(long long);
@@ -663,8 +669,13 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.sub = s.sub.as<SubInfo>();
     a.total_electrons = c->counters.as<unsigned long long>();
     a.status = (int*)(s.misc.as<char>() + 8);
+    const int n_chunks = (W + kPrepThreads - 1) / kPrepThreads;
+    a.chunk_total = s.chunk_total.as<uint32_t>();
+    a.chunk_box = s.chunk_box.as<double>();
     ProfScope ps(c, PK_PREP_SUB);
-    hipLaunchKernelGGL(k_prep_sub, dim3(K), dim3(kPrepThreads), 0, c->stream, a);
+    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
     HIP_TRY(c, hipGetLastError());
   }
   {
@@ -673,7 +684,9 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     int splits = d.thrower_splits;
     if (splits <= 0) {
       const char* e = std::getenv("WAYNE_THROW_WGS");
-      const int target = e ? std::max(std::atoi(e), 1) : 1536;  // ~6 workgroups per CU (measured optimum)
+      // measured optima (scripts/sweep_throw.py): ~6 workgroups per CU when every electron is thrown,
+      // ~4 when only the wide component is (fewer electrons per tile flush)
+      const int target = e ? std::max(std::atoi(e), 1) : (d.rng_mode == WAYNE_RNG_SPLIT ? 1024 : 1536);
       splits = std::max(1, (target + K - 1) / K);
     }
     a.splits = std::min(splits, 4096);
@@ -682,6 +695,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.flags = d.flags;
     a.flat_off = (1014 - N) / 2;  // grism.py:363 (0 for the full array)
     a.flat_wmin = c->g.flat_wmin; a.flat_wmax = c->g.flat_wmax;
+    a.flat_inv_range = 1.0 / (c->g.flat_wmax - c->g.flat_wmin);
     a.sub = s.sub.as<SubInfo>(); a.prefix = s.prefix.as<uint32_t>(); a.nwide = s.nwide.as<int32_t>();
     a.nsplit = s.nsplit.as<int32_t>();
     a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
