@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams in the timed region (1: kernels never co-run, so per-kernel event times are "
                          "clean; the 2-stream rate is reported separately as two_streams)")
+    ap.add_argument("--no-extra-pass", action="store_true",
+                    help="skip the additional two-stream pass (use under rocprofv3 so that the kernel statistics "
+                         "cover the timed region only)")
     args = ap.parse_args()
     os.environ["WAYNE_STREAMS"] = "2"        # the context always owns two streams; slots select them
 
@@ -217,7 +220,7 @@ def main():
     # extra pass: the same exposures alternating over the context's two HIP streams
     # (prep / ramp of one exposure co-run with the thrower of another)
     two = None
-    if args.streams == 1 and n_gpus == 1:
+    if args.streams == 1 and n_gpus == 1 and not args.no_extra_pass:
         for j in range(total):
             ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                             device=local_rank, seed=visit.seed, exposure_index=rank + j * n_gpus
