@@ -150,13 +150,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; WAYNE_BENCH_SHARE_GPU=1 lets several ranks share device 0 (a rehearsal of the
+    # multi-process path on a one-GPU box, with the gloo backend since RCCL refuses duplicate devices)
+    share = os.environ.get("WAYNE_BENCH_SHARE_GPU") == "1"
+    device = 0 if share else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            # "nccl" is RCCL on ROCm; used for the barrier and the max-over-ranks of the elapsed time only
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device))
 
     from wayne_amd import _lib, calibration, detector, engine, grism, synthetic
 
@@ -167,7 +175,7 @@ def main():
     total = args.warmup + args.steps
     # exposure j of this rank is exposure index rank + j * n_gpus of the visit (round-robin)
     visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=total * n_gpus)
-    eng = engine.get_engine(local_rank, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
+    eng = engine.get_engine(device, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
     ctx = eng.ctx
     if total > 125:
         raise SystemExit("at most 125 exposures (HBM slots) per rank per run")
@@ -179,7 +187,7 @@ def main():
     for j in range(total):
         i = rank + j * n_gpus
         eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
-                               device=local_rank, seed=visit.seed, exposure_index=i)
+                               device=device, seed=visit.seed, exposure_index=i)
         desc = eg.build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode, **visit.frame_kwargs(i))
         ctx.upload(j * (1 if args.streams == 2 else 2), desc)      # inputs resident in HBM before the timed region
         W = desc.n_wl
@@ -210,7 +218,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -223,7 +231,7 @@ def main():
     if args.streams == 1 and n_gpus == 1 and not args.no_extra_pass:
         for j in range(total):
             ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
-                                            device=local_rank, seed=visit.seed, exposure_index=rank + j * n_gpus
+                                            device=device, seed=visit.seed, exposure_index=rank + j * n_gpus
                                             ).build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode,
                                                                **visit.frame_kwargs(rank + j * n_gpus)))
         for j in range(args.warmup):
