@@ -108,6 +108,14 @@ CONFIGS = {
                       x_ref=404.5 + 379, y_ref=80.0, ssv=(1.5, 1.1, 0.0), cosmic_rate=11.0),
     "tiny": dict(grism="G141", SUBARRAY=64, SAMPSEQ="RAPID", NSAMP=4, K=6, E=3e4, scan_speed=40.0,
                  x_ref=440.0, y_ref=490.0, n_wl=600),
+    "tiny_g102": dict(grism="G102", SUBARRAY=64, SAMPSEQ="RAPID", NSAMP=3, K=4, E=2e4, scan_speed=25.0,
+                      x_ref=455.0, y_ref=492.0, n_wl=500),
+    "tiny128": dict(grism="G141", SUBARRAY=128, SAMPSEQ="RAPID", NSAMP=5, K=8, E=1e5, scan_speed=60.0,
+                    x_ref=400.0, y_ref=460.0, n_wl=900),
+    "tiny512": dict(grism="G141", SUBARRAY=512, SAMPSEQ="RAPID", NSAMP=3, K=5, E=3e5, scan_speed=8.0,
+                    x_ref=330.0, y_ref=420.0, n_wl=1500),
+    "stare256": dict(grism="G141", SUBARRAY=256, SAMPSEQ="SPARS10", NSAMP=4, K=3, E=1e6, scan_speed=0.0,
+                     x_ref=404.5, y_ref=500.0),
     "small256": dict(grism="G141", SUBARRAY=256, SAMPSEQ="SPARS10", NSAMP=4, K=9, E=3e6, scan_speed=3.0,
                      x_ref=404.5, y_ref=420.0),
 }
