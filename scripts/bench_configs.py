@@ -17,14 +17,15 @@ cal = calibration.CalibrationSet.synthetic(11)
 det = detector.WFC3_IR()
 out = {}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for name in ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2     # 2 = split thrower (default), 1 = every electron
+for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     gr = grism.G141(cal) if synthetic.CONFIGS[name]["grism"] == "G141" else grism.G102(cal)
     v = synthetic.Visit(name, det, gr, cal, n_exposures=n + 2)
     eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
     ctx = eng.ctx
     for j in range(n + 2):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
-        ctx.upload(2 * j, eg.build_descriptor(eng, **v.frame_kwargs(j)))
+        ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(j)))
     for j in range(2):
         ctx.run(2 * j)
     ctx.synchronize()
@@ -38,7 +39,8 @@ for name in ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     p = ctx.profile_get()
     ctx.profile_enable(False)
     # delivered: the visit runner (host prep + upload + kernels + download), exposures returned as numpy arrays
-    runner = visit.VisitRunner(v, 0)
+    runner = visit.VisitRunner(v, 0, frame_overrides={})
+    runner.rng_mode = mode
     runner.run([0, 1])
     t1 = time.perf_counter()
     runner.run(range(2, n + 2))

@@ -29,14 +29,18 @@ def frames(v, i=0, record=None, **over):
     return np.stack([r[0] for r in exp.reads])
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"])
 def test_conservation_and_monotone_ramp(name):
     v = helpers.make_visit(name)
     rec = {}
     reads = frames(v, record=rec, **QUIET)
     thrown = int(rec["counts"].astype(np.int64).sum())
     on_frame = rec["acc"].sum()
-    assert abs(thrown - v.E) < 0.02 * v.E                       # the flux scaling hits the configured E
+    if name == "cfg1":
+        assert v.K == 2233 and rec["counts"].shape == (2233, 4494)   # 10 ms sampling of the example visit
+    # the flux scaling hits the configured E (cfg1: ~2.5 e- per bin per 10 ms sub-sample, and np.round
+    # of such small expectations (exposure_generator.py:628) does not conserve the sum to better than a few %)
+    assert abs(thrown - v.E) < (0.05 if name == "cfg1" else 0.02) * v.E
     lost = thrown - on_frame
     assert 0 <= lost < 0.02 * thrown                            # only PSF wings leave the frame
     assert abs(on_frame - round(on_frame)) < 1e-3               # integer electrons (no flat): exact accumulation

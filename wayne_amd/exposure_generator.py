@@ -106,13 +106,15 @@ class ExposureGenerator(object):
                        scale_factor=None, add_gain_variations=True, add_non_linear=True,
                        clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                        add_initial_bias=True, progress_bar=None, threads=2,
-                       rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False,
+                       rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
                        record=None, exact_samplers=False):
         """Generate a spatially scanned exposure (exposure_generator.py:178-405).
 
-        Extra keywords (not in the reference): `rng_mode` (RNG_PHILOX production
-        streams, or RNG_REPLAY = the reference's rand_r streams in the thrower,
-        with `threads` selecting its OpenMP partition); `out_dtype` float32 or
+        Extra keywords (not in the reference): `rng_mode` -- RNG_SPLIT (default:
+        Philox-keyed streams, wide PSF component thrown per electron, narrow
+        component drawn as one multinomial per bin), RNG_PHILOX (every electron
+        thrown), or RNG_REPLAY (the reference's rand_r streams in the thrower,
+        with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` float32 or
         float64 reads; `reference_quirks` keeps the reference's -5 px frame
         offset at SUBARRAY=1024 (exposure_generator.py:630); `record`, if a dict,
         receives the device's intermediate products (counts, x, y per bin and
@@ -158,7 +160,7 @@ class ExposureGenerator(object):
                          scale_factor=None, add_gain_variations=True, add_non_linear=True,
                          clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                          add_initial_bias=True, progress_bar=None, threads=2,
-                         rng_mode=_lib.RNG_PHILOX, out_dtype=np.float32, reference_quirks=False,
+                         rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
                          exact_samplers=False):
         """The host half of scanning_frame: sample timing, scan positions, SSV,
         jitter / seed draws, spectrum crop (exposure_generator.py:247-334) ->

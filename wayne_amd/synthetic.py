@@ -96,6 +96,10 @@ def distribute_samples(read_times_s, K):
 
 
 CONFIGS = {
+    # BASELINE.json configs[0]: the shape of the reference's example visit (examples/...parameters.yml:30-47):
+    # 10 ms sampling of a 22.3 s exposure -> K = 2233 sub-samples
+    "cfg1": dict(grism="G141", SUBARRAY=256, SAMPSEQ="SPARS10", NSAMP=5, E=2.5e7, scan_speed=7.4325,
+                 x_ref=404.0, y_ref=457.3 - 70.0, sample_rate=10.0, ssv=(1.5, 1.1, 0.0), cosmic_rate=11.0),
     "cfg2": dict(grism="G141", SUBARRAY=1024, SAMPSEQ="SPARS10", NSAMP=16, K=15, E=2.5e7, scan_speed=0.0,
                  x_ref=404.5 + 379, y_ref=500.0),
     "cfg3": dict(grism="G141", SUBARRAY=256, SAMPSEQ="SPARS10", NSAMP=15, K=64, E=4e8, scan_speed=1.6,
@@ -131,18 +135,24 @@ class Visit(object):
         self.seed = seed
         self.n_exposures = n_exposures
         self.NSAMP, self.SAMPSEQ, self.SUBARRAY = cfg["NSAMP"], cfg["SAMPSEQ"], cfg["SUBARRAY"]
-        self.K = K or cfg["K"]
         self.E = E or cfg["E"]
         self.scan_speed = cfg["scan_speed"]
         self.read_times = detector.get_read_times(self.NSAMP, self.SUBARRAY, self.SAMPSEQ)
+        if "sample_rate" in cfg:    # the reference's fixed-rate sampling
+            self.sample_mid_points, self.sample_durations, self.read_index = sample_times(
+                self.read_times, sample_rate_ms=cfg["sample_rate"])
+            self.K = len(self.sample_mid_points)
+        else:
+            self.K = K or cfg["K"]
         wl = wavelength_grid()
         if "n_wl" in cfg:   # thinner grid for tiny cases
             i0, i1 = tools.crop_spectrum_ind(grism.wl_limits[0], grism.wl_limits[1], wl)
             sel = np.linspace(i0, i1 - 1, cfg["n_wl"]).astype(int)
             wl = wl[np.unique(sel)]
         self.wl = wl
-        n_per_read = distribute_samples(self.read_times, self.K)
-        self.sample_mid_points, self.sample_durations, self.read_index = sample_times(self.read_times, n_per_read)
+        if "sample_rate" not in cfg:
+            n_per_read = distribute_samples(self.read_times, self.K)
+            self.sample_mid_points, self.sample_durations, self.read_index = sample_times(self.read_times, n_per_read)
         # scale the black body so that one exposure throws E electrons
         i0, i1 = tools.crop_spectrum_ind(grism.wl_limits[0], grism.wl_limits[1], wl)
         cw = wl[i0:i1]

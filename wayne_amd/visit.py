@@ -43,6 +43,7 @@ class VisitRunner(object):
         self.visit, self.device, self.out_dir = visit, device, out_dir
         self.out_dtype = out_dtype
         self.frame_overrides = frame_overrides or {}
+        self.rng_mode = 2            # WAYNE_RNG_SPLIT
         self._eng = None
 
     def engine(self):
@@ -59,7 +60,7 @@ class VisitRunner(object):
                                  filename="%04d_raw.fits" % (i + 1))
 
     def descriptor(self, i, eng=None):
-        return self.generator(i).build_descriptor(eng, out_dtype=self.out_dtype,
+        return self.generator(i).build_descriptor(eng, out_dtype=self.out_dtype, rng_mode=self.rng_mode,
                                                   **self.visit.frame_kwargs(i, **self.frame_overrides))
 
     def run(self, indices, keep=False, on_reads=None):
@@ -75,7 +76,7 @@ class VisitRunner(object):
         for n, i in enumerate(indices):
             slot = n % 2
             gen = self.generator(i)
-            desc = gen.build_descriptor(eng, out_dtype=self.out_dtype,
+            desc = gen.build_descriptor(eng, out_dtype=self.out_dtype, rng_mode=self.rng_mode,
                                         **self.visit.frame_kwargs(i, **self.frame_overrides))
             if len(pending) == 2:          # the slot about to be reused must be drained first
                 self._finish(ctx, pending.pop(0), results, keep, on_reads)
