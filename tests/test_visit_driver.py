@@ -149,3 +149,56 @@ def test_pipelined_visit_runner_matches_direct_calls(tmp_path):
         np.testing.assert_array_equal(got[i], direct)          # order of generation and slot / stream do not matter
         h = fitsio.read(os.path.join(str(tmp_path), "%04d_raw.fits" % (i + 1)))
         np.testing.assert_array_equal(h[1].data, direct[-1].astype(np.float64))
+
+
+def test_ssv_modulated_sine_preserves_read_times():
+    from wayne_amd.trend_generators.scan_speed_varations import SSVModulatedSine, SSVSine
+    det = detector.WFC3_IR()
+    rt = det.get_read_times(5, 256, "SPARS10")
+    for seed in (1, 2, 3):
+        g = SSVModulatedSine(10, 1.1, 100, rng_seed=seed)
+        d, br = g.get_subsample_exposure_times(None, None, rt, 10.0)
+        assert len(d) == 2232 and len(br) == 4 and br[-1] == 2231          # one sample fewer than the 2233 mid-points
+        assert abs(d.sum() / 1000 - rt[-1]) < 2e-6
+        for b, t in zip(br, rt):
+            assert abs(d[:b + 1].sum() / 1000 - t) < 2e-6                   # every read lands on its table time
+        assert 6.5 < d.min() and d.max() < 13.5                            # 10 ms +- 10 % x (1 + slow sine + blip)
+        d2, br2 = SSVModulatedSine(10, 1.1, 100, rng_seed=seed).get_subsample_exposure_times(None, None, rt, 10.0)
+        np.testing.assert_array_equal(d, d2)
+    with pytest.raises(ValueError):
+        SSVSine(1.5, 1.1, "rand")                                           # broken in the reference (:49)
+    # through the exposure generator: host descriptor only (no GPU)
+    import helpers
+    from wayne_amd import visit as wv
+    v = helpers.make_visit("cfg1")
+    gen = wv.VisitRunner(v).generator(3)
+    kw = v.frame_kwargs(3, ssv_generator=SSVModulatedSine(10, 1.1, 1))
+    desc = gen.build_descriptor(None, **kw)
+    dur = np.ctypeslib.as_array(desc.dur_ms, shape=(desc.n_samples,))
+    sread = np.ctypeslib.as_array(desc.sample_read, shape=(desc.n_samples,))
+    assert desc.n_samples == 2233 and dur[-1] == 0.0 and abs(dur.sum() / 1000 - rt[-1]) < 2e-6
+    assert np.all(np.diff(sread) >= 0) and sread[0] == 0 and sread[-1] == 3
+    for r in range(4):
+        assert abs(dur[sread <= r].sum() / 1000 - rt[r]) < 2e-6
+
+
+@pytest.mark.gpu
+def test_exposure_with_modulated_sine_ssv():
+    import helpers
+    from wayne_amd.trend_generators.scan_speed_varations import SSVModulatedSine
+    v = helpers.make_visit("cfg1")
+    pg = helpers.product_generator(v, 0)
+    quiet = dict(add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False,
+                 add_flat=False, add_gain_variations=False, add_non_linear=False, clip_values_det_limits=False,
+                 add_initial_bias=False)
+    rec = {}
+    reads = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, record=rec,
+                                                      **v.frame_kwargs(0, ssv_generator=SSVModulatedSine(10, 1.1, 100),
+                                                                       **quiet)).reads])
+    assert rec["dur"].shape == (2233,) and abs(rec["dur"].sum() / 1000 - v.read_times[-1]) < 2e-6
+    np.testing.assert_allclose(reads[-1].sum() * 2.35, rec["acc"].sum(), rtol=1e-12)
+    assert np.all(np.diff(reads, axis=0) >= -1e-9)
+    # the electrons of a read interval scale with its (unchanged) length
+    per_read = rec["acc"].reshape(4, -1).sum(axis=1)
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    np.testing.assert_allclose(per_read / per_read.sum(), dt / dt.sum(), atol=0.01)

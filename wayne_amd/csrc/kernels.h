@@ -994,8 +994,10 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
   __syncthreads();
   if (!valid) return;
 
-  SeededStream rn(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
-  SeededStream rg(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
+  // per-pixel streams, seeded only when the stage is on (one Philox block each)
+  SeededStream rn, rg;
+  if (rdn || do_dark) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
 
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)

@@ -97,6 +97,7 @@ struct PhiloxStream {
 // xoshiro128+ seeded from one Philox block.
 struct SeededStream {
   uint32_t s0, s1, s2, s3;
+  WAYNE_HD SeededStream() : s0(0), s1(0), s2(0), s3(0) {}
   WAYNE_HD SeededStream(uint32_t seed, uint32_t stage, uint32_t c0, uint32_t c2, uint32_t c3) {
     const u32x4 b = philox4x32_10(c0, 0u, c2, c3, seed, stage);
     s0 = b.v[0]; s1 = b.v[1]; s2 = b.v[2]; s3 = b.v[3];

@@ -177,8 +177,18 @@ class ExposureGenerator(object):
 
         s_y_refs = self._gen_sample_yref(y_ref, sample_mid_points, scan_speed_ms)     # (:258)
         if ssv_generator is not None:
-            sample_durations = np.asarray(ssv_generator.get_subsample_exposure_times(
-                s_y_refs, sample_durations, self.read_times, sample_rate), dtype=float)   # (:262-273)
+            if isinstance(ssv_generator, scan_speed_varations.SSVModulatedSine):          # (:263-267)
+                # its scalar draws are keyed by (visit seed, exposure): order-independent
+                ssv_generator.rng_seed = (self.seed * 1000003 + self.exposure_index * 7919 + 12345) & 0x7FFFFFFF
+                sample_durations, read_index = ssv_generator.get_subsample_exposure_times(
+                    s_y_refs, sample_durations, self.read_times, sample_rate)
+                sample_durations = np.asarray(sample_durations, dtype=float)
+                # it yields len(tt) durations; samples without one expose for 0 ms (:337-342)
+                read_index = [min(int(b), len(sample_mid_points) - 1) for b in read_index]
+                read_index[-1] = len(sample_mid_points) - 1
+            else:
+                sample_durations = np.asarray(ssv_generator.get_subsample_exposure_times(
+                    s_y_refs, sample_durations, self.read_times, sample_rate), dtype=float)   # (:272-273)
 
         self.exp_info.update({
             "SCAN": True, "SCAN_DIR": 1, "samp_rate": sample_rate, "x_ref": x_ref, "y_ref": y_ref,

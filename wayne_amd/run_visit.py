@@ -96,9 +96,10 @@ def build_observation(cfg, base_dir=".", calibration=None, device=0):
     ssv_type = _get(obs_cfg, "ssv_type")
     ssv_gen = None
     if ssv_type:
-        if ssv_type != "sine":
-            raise WFC3SimConfigError("Invalid ssv_type given (only 'sine' is provided)")
-        ssv_gen = scan_speed_varations.SSVSine(*obs_cfg["ssv_coeffs"])
+        ssv_classes = {"sine": scan_speed_varations.SSVSine, "mod-sine": scan_speed_varations.SSVModulatedSine}
+        if ssv_type not in ssv_classes:
+            raise WFC3SimConfigError("Invalid ssv_type given")                 # run_visit.py:233-245
+        ssv_gen = ssv_classes[ssv_type](*obs_cfg["ssv_coeffs"])
 
     obs = observation.Observation(outdir if os.path.isabs(outdir) else os.path.join(base_dir, outdir),
                                   calibration=cal, device=device, seed=seed)
