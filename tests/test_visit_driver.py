@@ -170,7 +170,7 @@ def test_ssv_modulated_sine_preserves_read_times():
     # through the exposure generator: host descriptor only (no GPU)
     import helpers
     from wayne_amd import visit as wv
-    v = helpers.make_visit("cfg1")
+    v = helpers.make_visit("cfg1", n_exposures=4)
     gen = wv.VisitRunner(v).generator(3)
     kw = v.frame_kwargs(3, ssv_generator=SSVModulatedSine(10, 1.1, 1))
     desc = gen.build_descriptor(None, **kw)
