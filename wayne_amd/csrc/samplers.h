@@ -110,15 +110,26 @@ struct PtrsSetup {
     invalpha = (T)1.1239 + M::div_((T)1.1328, b - (T)3.4);
     vr = (T)0.9277 - M::div_((T)3.6224, b - (T)2);
   }
-  // One trial with uniforms (u1, u2): true and k set when accepted.
-  WAYNE_HD bool trial(uint32_t w1, uint32_t w2, T& k) const {
+  // The cheap part of a trial with uniforms (w1, w2): 1 = accepted (k set), 0 = rejected,
+  // 2 = undecided -- call slow(k, V, us).  ~87 % of trials end here.
+  WAYNE_HD int quick(uint32_t w1, uint32_t w2, T& k, T& V, T& us) const {
     const T U = M::u01(w1) - (T)0.5;
-    const T V = M::u01(w2);
-    const T us = (T)0.5 - M::abs_(U);
+    V = M::u01(w2);
+    us = (T)0.5 - M::abs_(U);
     k = M::floor_((M::div_((T)2 * a, us) + b) * U + lam + (T)0.43);
-    if (us >= (T)0.07 && V <= vr) return true;
-    if (k < (T)0 || (us < (T)0.013 && V > us)) return false;
+    if (us >= (T)0.07 && V <= vr) return 1;
+    if (k < (T)0 || (us < (T)0.013 && V > us)) return 0;
+    return 2;
+  }
+  // The log-density comparison of the undecided trials.
+  WAYNE_HD bool slow(T k, T V, T us) const {
     return M::accept(V, invalpha, M::div_(a, us * us) + b, -lam + k * loglam - loggam<M>(k + (T)1));
+  }
+  // One whole trial: true and k set when accepted.
+  WAYNE_HD bool trial(uint32_t w1, uint32_t w2, T& k) const {
+    T V, us;
+    const int q = quick(w1, w2, k, V, us);
+    return q == 1 || (q == 2 && slow(k, V, us));
   }
 };
 
