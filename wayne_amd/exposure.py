@@ -9,6 +9,8 @@ the fused k_ramp kernel, and the class only holds the finished reads (read 0 =
 zero read, exposure.py:47) and writes them out (exposure.py:133-214).
 """
 import os
+import queue
+import threading
 
 import numpy as np
 
@@ -82,3 +84,47 @@ class Exposure(object):
             os.remove(path)
         fitsio.write(path, hdus)
         return path
+
+
+class FitsWriterPool(object):
+    """Write finished exposures to disk on background threads.
+
+    Byte-swapping 16 float64 frames and writing the 134 MB file of a full-array exposure
+    takes ~0.2 s on one core -- 200x longer than synthesising it on the GPU -- so a visit
+    hands its exposures to this pool (numpy releases the GIL in astype / tobytes / write)
+    and keeps generating.  `close()` waits for the queue to drain and re-raises a writer error."""
+
+    def __init__(self, threads=None, max_pending=None):
+        if threads is None:
+            threads = min(16, os.cpu_count() or 4)
+        self._q = queue.Queue(maxsize=max_pending or 2 * threads)
+        self._errors = []
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, threads))]
+        for t in self._threads:
+            t.start()
+
+    def _work(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                self._q.task_done()
+                return
+            exposure, out_dir, filename = item
+            try:
+                exposure.generate_fits(out_dir, filename)
+            except Exception as e:      # surfaced by close()
+                self._errors.append(e)
+            finally:
+                self._q.task_done()
+
+    def submit(self, exposure, out_dir, filename):
+        """`exposure.reads` must own their data (not views of a buffer that will be reused)."""
+        self._q.put((exposure, out_dir, filename))
+
+    def close(self):
+        for _ in self._threads:
+            self._q.put(None)
+        for t in self._threads:
+            t.join()
+        if self._errors:
+            raise self._errors[0]

@@ -183,8 +183,20 @@ class Observation(object):
         frames = {}
         if rank == 0:
             frames[0] = self._generate_direct_image(write_fits)
-        for i in range(rank, len(self.exp_start_times), world):
-            frames[i + 1] = self._generate_exposure(self.exp_start_times[i], i + 1, write_fits)
+        # files are written by background threads while the GPU works on the next exposures
+        from .exposure import FitsWriterPool
+        pool = FitsWriterPool() if write_fits else None
+        try:
+            for i in range(rank, len(self.exp_start_times), world):
+                frame = self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False)
+                if pool is not None:
+                    pool.submit(frame, self.outdir, "{:04d}_raw.fits".format(i + 1))
+                    frames[i + 1] = None          # on disk; do not keep 64 MB per exposure alive
+                else:
+                    frames[i + 1] = frame
+        finally:
+            if pool is not None:
+                pool.close()
         return frames
 
     def _generate_exposure(self, expstart, number, write_fits=True):

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import engine as _engine
-from .exposure import Exposure
+from .exposure import Exposure, FitsWriterPool
 from .exposure_generator import ExposureGenerator
 
 
@@ -73,6 +73,16 @@ class VisitRunner(object):
         ctx = eng.ctx
         results = {}
         pending = []                       # [(index, slot, generator)] in flight, oldest first
+        self._pool = FitsWriterPool() if self.out_dir is not None else None
+        try:
+            self._run_pipeline(eng, ctx, indices, results, pending, keep, on_reads)
+        finally:
+            if self._pool is not None:
+                self._pool.close()
+                self._pool = None
+        return results
+
+    def _run_pipeline(self, eng, ctx, indices, results, pending, keep, on_reads):
         for n, i in enumerate(indices):
             slot = n % 2
             gen = self.generator(i)
@@ -86,7 +96,6 @@ class VisitRunner(object):
             pending.append((i, slot, gen))
         while pending:
             self._finish(ctx, pending.pop(0), results, keep, on_reads)
-        return results
 
     def _finish(self, ctx, pending, results, keep, on_reads=None):
         i, slot, gen = pending
@@ -99,8 +108,9 @@ class VisitRunner(object):
             os.makedirs(self.out_dir, exist_ok=True)
             exp = Exposure(gen.detector, gen.grism, None, gen.exp_info)
             read_dt = np.diff(np.concatenate([[0.0], gen.read_times]))
-            exp.add_read(reads[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
+            own = reads.copy()             # the pinned buffer is reused by the next exposure
+            exp.add_read(own[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
             for r in range(len(gen.read_times)):
-                exp.add_read(reads[r + 1], {"cumulative_exp_time": float(gen.read_times[r]),
-                                            "read_exp_time": float(read_dt[r]), "CRPIX1": 0})
-            exp.generate_fits(self.out_dir, gen.exp_info["filename"])
+                exp.add_read(own[r + 1], {"cumulative_exp_time": float(gen.read_times[r]),
+                                          "read_exp_time": float(read_dt[r]), "CRPIX1": 0})
+            self._pool.submit(exp, self.out_dir, gen.exp_info["filename"])
