@@ -18,9 +18,12 @@ eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
 ctx = eng.ctx
 eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-for wgs, tile, margin in itertools.product([256, 384, 512, 768, 1024, 1536], [12288], [20, 24, 28]):
+for wgs, tile, margin in itertools.product([512, 1024, 1536, 2048, 3072, 4096], [0], [16, 20, 24]):
     os.environ["WAYNE_THROW_WGS"] = str(wgs)
-    os.environ["WAYNE_TILE_INTS"] = str(tile)
+    if tile:
+        os.environ["WAYNE_TILE_INTS"] = str(tile)
+    else:
+        os.environ.pop("WAYNE_TILE_INTS", None)
     desc = eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(0))
     desc.thrower_margin = margin
     ctx.upload(0, desc)

@@ -483,6 +483,7 @@ struct ThrowArgs {
   int threads_compat;      // replay: emulated OpenMP team size
   uint32_t seed, exposure, subsample0;
   uint32_t flags;
+  int margin, lds_ints;    // per-workgroup tile: margin around its slice of the trace, LDS capacity
   int flat_off;            // (1014 - N) / 2  (grism.py:363)
   double flat_wmin, flat_wmax, flat_inv_range;   // inv_range = 1 / (wmax - wmin)
   const SubInfo* sub;      // [K]
@@ -566,23 +567,56 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   if (E == 0) return;
   const int W = a.W;
   const int tid = threadIdx.x;
-  const int tw = si.tw, th = si.th, tx0 = si.tx0, ty0 = si.ty0;
-  const int tarea = tw * th;
-  for (int i = tid; i < tarea; i += kThrowThreads) tile[i] = 0;
-  __syncthreads();
 
   const uint32_t* P = a.prefix + (size_t)k * (W + 1);
   const int32_t* NW = a.nwide + (size_t)k * W;
   const double* XP = a.xpos + (size_t)k * W;
   const double* YP = a.ypos + (size_t)k * W;
 
-  // slots: contiguous electron ranges, whole RNG blocks in Philox mode
+  // Slots: contiguous electron ranges (whole RNG blocks in Philox mode).  Workgroup s of the
+  // sub-sample owns the CONTIGUOUS run of T slots [s T, (s+1) T): a slice of the trace, so its
+  // LDS tile only spans that slice plus the PSF margin and few workgroups flush into any pixel.
+  // Inside the slice lane l / wave v takes slot l (T/64) + v: the 64 lanes of a wave stay spread.
   constexpr uint32_t UNIT = (RNG_MODE == 1) ? kThrowBlock : 1u;
   const uint64_t n_units = ((uint64_t)E + UNIT - 1) / UNIT;
   const uint64_t n_slots = (uint64_t)a.splits * kThrowThreads;
   const uint64_t L = (n_units + n_slots - 1) / n_slots;
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  const uint64_t slot = ((uint64_t)lane * (kThrowThreads / 64) + wave) * a.splits + s;
+  const uint64_t wg_begin = (uint64_t)s * kThrowThreads * L * UNIT;
+  if (wg_begin >= E) return;
+  uint64_t wg_end = (uint64_t)(s + 1) * kThrowThreads * L * UNIT;
+  if (wg_end > E) wg_end = E;
+
+  // the workgroup's tile: trace positions of its first and last bin +- margin, clipped to the
+  // sub-sample's rectangle (already inside [1, N)) and to the LDS budget
+  __shared__ int s_rect[4];
+  if (tid == 0) {
+    auto bin_of = [&](uint32_t e) {
+      int lo = 0, hi = W;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P[mid] <= e) lo = mid; else hi = mid; }
+      return lo;
+    };
+    const int b0 = bin_of((uint32_t)wg_begin), b1 = bin_of((uint32_t)(wg_end - 1));
+    const double xa = fmin(XP[b0], XP[b1]), xb = fmax(XP[b0], XP[b1]);
+    const double ya = fmin(YP[b0], YP[b1]), yb = fmax(YP[b0], YP[b1]);
+    const double lim = 1e6;
+    int x0 = (int)floor(fmax(xa, -lim)) - a.margin, x1 = (int)floor(fmin(xb, lim)) + a.margin + 1;
+    int y0 = (int)floor(fmax(ya, -lim)) - a.margin, y1 = (int)floor(fmin(yb, lim)) + a.margin + 1;
+    x0 = max(x0, si.tx0); y0 = max(y0, si.ty0);
+    x1 = min(x1, si.tx0 + si.tw); y1 = min(y1, si.ty0 + si.th);
+    int w_ = max(x1 - x0, 0), h_ = max(y1 - y0, 0);
+    while ((long long)w_ * h_ > a.lds_ints && h_ > 1) { y0 += 1; h_ = max(h_ - 2, 1); }
+    while ((long long)w_ * h_ > a.lds_ints && w_ > 1) { x0 += 1; w_ = max(w_ - 2, 1); }
+    if ((long long)w_ * h_ > a.lds_ints) { w_ = 0; h_ = 0; }
+    s_rect[0] = x0; s_rect[1] = y0; s_rect[2] = w_; s_rect[3] = h_;
+  }
+  __syncthreads();
+  const int tx0 = s_rect[0], ty0 = s_rect[1], tw = s_rect[2], th = s_rect[3];
+  const int tarea = tw * th;
+  for (int i = tid; i < tarea; i += kThrowThreads) tile[i] = 0;
+  __syncthreads();
+
+  const uint64_t slot = (uint64_t)s * kThrowThreads + (uint64_t)lane * (kThrowThreads / 64) + wave;
   const uint64_t e_begin64 = slot * L * UNIT;
   uint64_t e_end64 = (slot + 1) * L * UNIT;
   if (e_end64 > E) e_end64 = E;

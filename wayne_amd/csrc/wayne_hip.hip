@@ -198,10 +198,13 @@ std::vector<float> embed(const float* src, int N, int S, float fill) {
   return v;
 }
 
-int thrower_lds_ints(const wayne_ctx*) {
-  const char* e = std::getenv("WAYNE_TILE_INTS");
-  int v = e ? std::atoi(e) : 12288;  // 48 KiB: three 512-thread workgroups per CU
-  return std::min(std::max(v, 256), 40000);  // <= 160 KB LDS
+// LDS ints of a thrower workgroup's tile.  A workgroup covers 1/splits of a sub-sample's electrons,
+// i.e. a slice of the trace (first-order spectra are < ~260 px long) plus the PSF margin on each
+// side, by (margin on each side + the trace's small tilt) rows.  WAYNE_TILE_INTS overrides.
+int thrower_lds_ints(const wayne_ctx*, int splits, int margin) {
+  if (const char* e = std::getenv("WAYNE_TILE_INTS")) return std::min(std::max(std::atoi(e), 256), 40000);
+  const long long w = 260 / std::max(splits, 1) + 2 * margin + 4, h = 2 * margin + 12;
+  return (int)std::min<long long>(std::max<long long>(w * h, 1024), 12288);   // <= 48 KiB
 }
 
 template <int RNG, int FLUSH>
@@ -382,7 +385,6 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
       }
     }
     prefix[size] = run;
-    const int lds_ints = thrower_lds_ints(c);
     SubInfo si{};
     si.electrons = run;
     si.read = 0;
@@ -392,12 +394,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
       auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
       int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
       int y0 = std::max(clampi(std::floor(ymin)) - margin, 1), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
-      if (x1 > x0 && y1 > y0) {
-        int tw = x1 - x0, th = y1 - y0;
-        while ((long long)tw * th > lds_ints && th > 1) { y0 += 1; th = std::max(th - 2, 1); }
-        while ((long long)tw * th > lds_ints && tw > 1) { x0 += 1; tw = std::max(tw - 2, 1); }
-        si.tx0 = x0; si.ty0 = y0; si.tw = tw; si.th = th;
-      }
+      if (x1 > x0 && y1 > y0) { si.tx0 = x0; si.ty0 = y0; si.tw = x1 - x0; si.th = y1 - y0; }   // clip region of the tiles
     }
     int rc;
     if ((rc = upload(c, c->pa_prefix, prefix.data(), prefix.size()))) return rc;
@@ -414,6 +411,9 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     // enough workgroups to fill the chip when the call is big, one when small
     a.splits = (int)std::min<long long>(512, std::max<long long>(1, total / (64LL * kThrowThreads)));
     a.threads_compat = threads_compat;
+    a.margin = margin;
+    const int lds_ints = thrower_lds_ints(c, a.splits, margin);
+    a.lds_ints = lds_ints;
     a.seed = seed; a.exposure = exposure; a.subsample0 = subsample;
     a.flags = 0; a.flat_off = 0; a.flat_wmin = 0; a.flat_wmax = 1; a.flat_inv_range = 1;
     a.sub = c->pa_sub.as<SubInfo>();
@@ -646,14 +646,14 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
                        s.wl.as<double>(), wa);
     HIP_TRY(c, hipGetLastError());
   }
-  const int lds_ints = thrower_lds_ints(c);
+  const int margin = d.thrower_margin > 0 ? d.thrower_margin : 24;   // ~4 sigma_h: sweep in scripts/sweep_throw.py
   {
     PrepArgs a{};
     a.g = c->g;
     a.W = W; a.K = K; a.N = N;
     a.sub_scale = d.sub_scale;
-    a.margin = d.thrower_margin > 0 ? d.thrower_margin : 24;   // ~4 sigma_h: sweep in scripts/sweep_throw.py
-    a.max_tile = lds_ints;
+    a.margin = margin;
+    a.max_tile = 0x7FFFFFFF;      // the sub-sample rectangle is only the clip region of the workgroup tiles
     a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
     a.scale_factor = d.scale_factor;
     a.wl = s.wl.as<double>(); a.flux = s.flux.as<double>();
@@ -684,12 +684,15 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     int splits = d.thrower_splits;
     if (splits <= 0) {
       const char* e = std::getenv("WAYNE_THROW_WGS");
-      // measured optima (scripts/sweep_throw.py): ~6 workgroups per CU when every electron is thrown,
-      // ~4 when only the wide component is (fewer electrons per tile flush)
-      const int target = e ? std::max(std::atoi(e), 1) : (d.rng_mode == WAYNE_RNG_SPLIT ? 1024 : 1536);
+      // measured optimum (scripts/sweep_throw.py): ~12 workgroups per CU -- each covers a short slice of
+      // the trace, so tiles are small (zeroing / flushing them is cheap) and occupancy is not LDS-limited
+      const int target = e ? std::max(std::atoi(e), 1) : 3072;
       splits = std::max(1, (target + K - 1) / K);
     }
     a.splits = std::min(splits, 4096);
+    a.margin = margin;
+    const int lds_ints = thrower_lds_ints(c, a.splits, margin);
+    a.lds_ints = lds_ints;
     a.threads_compat = d.threads_compat;
     a.seed = d.seed; a.exposure = d.exposure_index; a.subsample0 = 0;
     a.flags = d.flags;
