@@ -1,6 +1,6 @@
 """ctypes access to the oracle's C libraries.  TEST INFRASTRUCTURE ONLY.
 
-  libwayne_oracle.so        this repo's C restatement (oracle/psf_oracle.c, noise_oracle.c)
+  libwayne_oracle.so        this repo's C restatement (oracle/psf_oracle.c, noise_oracle.c, split_oracle.c)
   _ref/libwayne_ref_psf.so  the reference's own wayne/pyparallel_menu.c compiled
                             unmodified by oracle/Makefile (present only where
                             /root/reference was available at build time, or
@@ -24,7 +24,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force=False):
     """(Re)build the oracle libraries with oracle/Makefile."""
-    srcs = [os.path.join(HERE, f) for f in ("psf_oracle.c", "noise_oracle.c", "Makefile")]
+    srcs = [os.path.join(HERE, f) for f in ("psf_oracle.c", "noise_oracle.c", "split_oracle.c", "Makefile")]
     stale = force or not os.path.exists(_ORACLE) or any(
         os.path.getmtime(s) > os.path.getmtime(_ORACLE) for s in srcs)
     if stale:
@@ -66,6 +66,11 @@ def lib():
         L.wayne_oracle_philox_blocks.restype = None
         L.wayne_oracle_philox_blocks.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_uint32, _u32p]
+        L.wayne_oracle_psf_split.restype = C.c_int
+        L.wayne_oracle_psf_split.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int,
+                                             C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
+        L.wayne_oracle_binomial_vec.restype = None
+        L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
         _lib = L
     return _lib
 
@@ -131,6 +136,26 @@ def psf_philox_oracle(counts, x, y, ratio, sl, sh, nr, nc, seed, exposure, subsa
                                        int(seed), int(exposure), int(subsample), out)
     if rc != 0:
         raise ValueError("wayne_oracle_psf_philox: status %d" % rc)
+    return out
+
+
+def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, split_min=32):
+    """The thrower's default mode (WAYNE_RNG_SPLIT) on the CPU, same counters as the device."""
+    counts, x, y, ratio, sl, sh = _prep(counts, x, y, ratio, sl, sh)
+    out = np.empty(n * n, dtype=np.int32)
+    rc = lib().wayne_oracle_psf_split(counts, counts.size, x, y, ratio, sl, sh, n, int(split_min),
+                                      int(seed), int(exposure), int(subsample), out)
+    if rc != 0:
+        raise ValueError("wayne_oracle_psf_split: status %d" % rc)
+    return out
+
+
+def binomial_vec(n, p, seed, subsample=0, exposure=0):
+    """Binomial(n[i], p[i]) from the STAGE_NARROW stream of element i (fp32 sampler)."""
+    n = np.ascontiguousarray(n, dtype=np.float32)
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    out = np.empty(n.size, dtype=np.float32)
+    lib().wayne_oracle_binomial_vec(n, p, n.size, int(seed), int(subsample), int(exposure), out)
     return out
 
 

@@ -1,0 +1,219 @@
+/*
+ * oracle/split_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU statement of the production thrower's default mode (WAYNE_RNG_SPLIT,
+ * include/wayne_hip.h): what the reference does electron by electron
+ * (pyparallel_menu.c:87-108) is, for the narrow gaussian of a well-populated
+ * bin, drawn as ONE multinomial over the pixels around the bin.
+ *
+ * Throwing n electrons independently at pixels with probabilities p_ij gives
+ * multinomial(n; p_ij) pixel counts; x and y of the reference's electron are
+ * independent normals (:57-61, :99-107), so p_ij = P_i Q_j with P, Q the
+ * masses of N(pos, sigma_l^2) on [i, i+1) -- the reference's (int) truncation
+ * is floor() wherever it keeps the electron (:91-93).  The multinomial is
+ * sampled as a chain of conditional binomials: columns centre-out, then the
+ * rows of each non-empty column centre-out, over a +-6 pixel window
+ * (>= 6.5 sigma_l; the < 1e-10 of mass outside the window is not thrown).
+ *
+ * Parity status: the reference has no such mode -- its result for the same
+ * inputs is ONE sample of the same distribution -- so this file is "parity
+ * unpinned" against the reference and pinned instead by
+ *   (a) distribution tests against scipy.stats.binom (tests/test_samplers.py),
+ *   (b) agreement with the device on the same counters (tests/test_split_gpu.py),
+ *   (c) the moments of the per-electron thrower, which IS pinned bit-for-bit.
+ * Binomial(n, p): inversion by sequential search below n*min(p,1-p) = 10
+ * (Kachitvichyanukul & Schmeiser 1988, BINV), Hoermann's BTRS transformed
+ * rejection above (J. Stat. Comput. Simul. 46, 1993).  fp32 arithmetic, libm,
+ * no contraction (Makefile: -ffp-contract=off), like the device's
+ * "exact sampler" policy.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+uint32_t wayne_oracle_xo_next(uint32_t state[4]);
+
+enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
+
+static float so_u01(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
+
+/* ln k! minus its Stirling approximation sqrt(2 pi) (k+1)^(k+1/2) e^-(k+1) */
+static float so_fc(float k) {
+  static const float small[10] = {
+      0.0810614667953272f,  0.0413406959554092f,  0.0276779256849983f, 0.02079067210376509f,
+      0.0166446911898211f,  0.0138761288230707f,  0.0118967099458917f, 0.0104112652619720f,
+      0.00925546218271273f, 0.00833056343336287f};
+  if (k < 10.0f) return small[(int)k];
+  const float k1 = k + 1.0f, k1s = k1 * k1;
+  return ((float)(1.0 / 12) - ((float)(1.0 / 360) - (float)(1.0 / 1260) / k1s) / k1s) / k1;
+}
+
+float wayne_oracle_binomial_f(float n, float p, uint32_t state[4]) {
+  if (!(n > 0.0f) || !(p > 0.0f)) return 0.0f;
+  if (p >= 1.0f) return n;
+  const int mirrored = p > 0.5f;
+  if (mirrored) p = 1.0f - p;
+  const float q = 1.0f - p;
+  float x = 0.0f;
+  if (n * p < 10.0f) {
+    /* BINV: f(0) = q^n, f(x) = f(x-1) * ((n+1) s / x - s), s = p/q */
+    const float s = p / q;
+    const float a = (n + 1.0f) * s;
+    float f = expf(n * log1pf(-p));
+    float u = so_u01(wayne_oracle_xo_next(state));
+    for (int it = 0; it < 256 && u > f; ++it) {
+      u = u - f;
+      x = x + 1.0f;
+      f = f * (a / x - s);
+      if (x >= n) { x = n; break; }
+    }
+  } else {
+    /* BTRS */
+    const float spq = sqrtf(n * p * q);
+    const float b = 1.15f + 2.53f * spq;
+    const float a = -0.0873f + 0.0248f * b + 0.01f * p;
+    const float c = n * p + 0.5f;
+    const float vr = 0.92f - 4.2f / b;
+    const float alpha = (2.83f + 5.1f / b) * spq;
+    const float m = floorf((n + 1.0f) * p);
+    const float r = p / q;
+    x = floorf(n * p + 0.5f);
+    for (int it = 0; it < 256; ++it) {
+      const float U = so_u01(wayne_oracle_xo_next(state)) - 0.5f;
+      const float V = so_u01(wayne_oracle_xo_next(state));
+      const float us = 0.5f - fabsf(U);
+      const float k = floorf((2.0f * a / us + b) * U + c);
+      if (us >= 0.07f && V <= vr) { x = k; break; }
+      if (k < 0.0f || k > n) continue;
+      const float v = logf(V * alpha / (a / (us * us) + b));
+      const float nm = n - m + 1.0f, nk = n - k + 1.0f;
+      const float bound = (m + 0.5f) * logf((m + 1.0f) / (r * nm)) + (n + 1.0f) * logf(nm / nk) +
+                          (k + 0.5f) * logf(r * nk / (k + 1.0f)) + so_fc(m) + so_fc(n - m) - so_fc(k) -
+                          so_fc(n - k);
+      if (v <= bound) { x = k; break; }
+    }
+  }
+  return mirrored ? n - x : x;
+}
+
+/* n draws of Binomial(n[i], p[i]), element i from the STAGE_NARROW stream of "bin" i. */
+void wayne_oracle_binomial_vec(const float *n, const float *p, int64_t count, uint32_t seed,
+                               uint32_t subsample, uint32_t exposure, float *out) {
+  const uint32_t key[2] = {seed, SO_STAGE_NARROW};
+  for (int64_t i = 0; i < count; ++i) {
+    const uint32_t ctr[4] = {(uint32_t)i, 0u, subsample, exposure};
+    uint32_t st[4];
+    wayne_oracle_philox4x32(ctr, key, st);
+    out[i] = wayne_oracle_binomial_f(n[i], p[i], st);
+  }
+}
+
+static float so_tail(float t) { return 0.5f * erfcf(t * 0.70710678118654752f); }
+
+/* Masses of N(frac, sigma^2) on the 13 unit cells of the window, in visiting
+ * order: centre, +1, -1, +2, -2, ...  `before[c]` = mass not yet visited when
+ * cell c is reached (1 for the centre, the two remaining tails afterwards). */
+static void so_cell_masses(float frac, float inv_sigma, float mass[SO_CELLS], float before[SO_CELLS]) {
+  float above = so_tail((1.0f - frac) * inv_sigma);
+  float below = so_tail(frac * inv_sigma);
+  mass[0] = 1.0f - above - below;
+  before[0] = 1.0f;
+  for (int c = 1; c < SO_CELLS; ++c) {
+    const int d = (c + 1) / 2;
+    before[c] = above + below;
+    if (c % 2) {
+      const float next = so_tail(((float)(d + 1) - frac) * inv_sigma);
+      mass[c] = above - next;
+      above = next;
+    } else {
+      const float next = so_tail(((float)d + frac) * inv_sigma);
+      mass[c] = below - next;
+      below = next;
+    }
+  }
+}
+
+static int so_cell_offset(int c) { return c == 0 ? 0 : (c % 2 ? (c + 1) / 2 : -(c / 2)); }
+
+static float so_clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+static int so_trunc(float v) {
+  if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
+  return (int)v;
+}
+
+/*
+ * The whole thrower in split mode for one sub-sample.  Bins with at least
+ * `split_min` narrow electrons (and 0.05 < sigma_l <= 6/6.5) hand them to the
+ * multinomial; everything else -- the wide electrons of those bins, and sparse
+ * bins whole -- is thrown one by one from STAGE_THROW streams exactly as
+ * wayne_oracle_psf_philox does, numbered bin-major over the thrown electrons.
+ */
+int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos, const double *y_pos,
+                           const double *psf_ratio, const double *psf_sigmal, const double *psf_sigmah,
+                           int n, int split_min, uint32_t seed, uint32_t exposure, uint32_t subsample,
+                           int32_t *out) {
+  if (size < 0 || n <= 0) return -1;
+  memset(out, 0, (size_t)n * (size_t)n * sizeof(int32_t));
+  const uint32_t key_t[2] = {seed, SO_STAGE_THROW};
+  const uint32_t key_n[2] = {seed, SO_STAGE_NARROW};
+  uint64_t e = 0;
+  uint32_t g[4] = {0, 0, 0, 0};
+  for (int b = 0; b < size; ++b) {
+    if (counts[b] < 0) return -2;
+    const double nwd = (double)counts[b] * psf_ratio[b];
+    int64_t n_wide = (nwd >= 2147483647.0) ? 2147483647 : (nwd > -2147483648.0 ? (int64_t)(int32_t)nwd : -2147483648LL);
+    if (n_wide < 0) n_wide = 0;
+    if (n_wide > counts[b]) n_wide = counts[b];
+    const int64_t n_narrow = counts[b] - n_wide;
+    const int split = split_min > 0 && n_narrow >= split_min && psf_sigmal[b] > 0.05 &&
+                      psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
+    const float x = (float)x_pos[b], y = (float)y_pos[b];
+    const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
+
+    /* one by one */
+    const int64_t thrown = split ? n_wide : counts[b];
+    for (int64_t j = 0; j < thrown; ++j, ++e) {
+      if ((e & 127u) == 0) {
+        const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
+        wayne_oracle_philox4x32(ctr, key_t, g);
+      }
+      const float ua = so_u01(wayne_oracle_xo_next(g));
+      const float ub = so_u01(wayne_oracle_xo_next(g));
+      const float R = sqrtf(-2.0f * logf(ub));
+      const float ang = 6.283185307179586f * ua;
+      const float sig = (j < n_wide) ? sh : sl;
+      const int xp = so_trunc(fmaf(R * cosf(ang), sig, x));
+      const int yp = so_trunc(fmaf(R * sinf(ang), sig, y));
+      if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
+    }
+    if (!split) continue;
+
+    /* the narrow component as one multinomial */
+    const int ic = (int)floorf(x), jc = (int)floorf(y);
+    const float inv_s = 1.0f / sl;
+    float P[SO_CELLS], Pb[SO_CELLS], Q[SO_CELLS], Qb[SO_CELLS];
+    so_cell_masses(x - (float)ic, inv_s, P, Pb);
+    so_cell_masses(y - (float)jc, inv_s, Q, Qb);
+    const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
+    uint32_t st[4];
+    wayne_oracle_philox4x32(ctr, key_n, st);
+    float left = (float)n_narrow;
+    for (int c = 0; c < SO_CELLS && left > 0.0f; ++c) {
+      const float in_col = wayne_oracle_binomial_f(left, so_clamp01(P[c] / Pb[c]), st);
+      left -= in_col;
+      const int col = ic + so_cell_offset(c);
+      float col_left = in_col;
+      float q_before = 1.0f;   /* rows: running 1 - sum of the masses visited (not the two tails) */
+      for (int r = 0; r < SO_CELLS && col_left > 0.0f; ++r) {
+        const float m = wayne_oracle_binomial_f(col_left, so_clamp01(Q[r] / q_before), st);
+        col_left -= m;
+        q_before -= Q[r];
+        const int row = jc + so_cell_offset(r);
+        if (m > 0.0f && col > 0 && col < n && row > 0 && row < n) out[(size_t)row * n + col] += (int32_t)m;
+      }
+    }
+  }
+  return 0;
+}

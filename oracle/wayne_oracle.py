@@ -649,6 +649,10 @@ class ExposureOracle(object):
             def throw(counts, x, y, ratio, sl, sh, ny, nx, seed, threads, k):
                 return clib.psf_philox_oracle(np.asarray(counts).astype(np.int32), x, y, ratio, sl, sh, ny, nx,
                                               draws.seed, draws.exposure, k)
+        elif thrower == "split":
+            def throw(counts, x, y, ratio, sl, sh, ny, nx, seed, threads, k):
+                return clib.psf_split_oracle(np.asarray(counts).astype(np.int32), x, y, ratio, sl, sh, ny,
+                                             draws.seed, draws.exposure, k)
         else:
             raise ValueError(thrower)
 

@@ -108,6 +108,35 @@ def test_full_noise_philox_everything_on():
     assert np.median(d) < 5e-3
 
 
+@pytest.mark.parametrize("name", ["tiny", "small256"])
+def test_default_split_thrower_against_oracle_same_counters(name):
+    # the production default (WAYNE_RNG_SPLIT): accumulated electrons per read interval, flat applied,
+    # against oracle/split_oracle.c driven by the same counters.  A moved electron shows as +-1 in two pixels.
+    # (brighter than the fixture's star so that most bins exceed the split threshold)
+    v, got, want, rec, orec = run_both(name, thrower="split", rng_mode=_lib.RNG_SPLIT, **dict(DET_OFF, scale_factor=25.0))
+    np.testing.assert_array_equal(rec["counts"], np.stack(orec["counts"]))
+    assert (rec["counts"] * 0.7 > 32).mean() > 0.5
+    acc_o = np.stack(orec["acc"])
+    total = acc_o.sum()
+    assert total > 1e5
+    assert abs(rec["acc"].sum() - total) <= 3 + 2e-5 * total
+    moved = np.abs(rec["acc"] - acc_o).sum() / 2
+    assert moved <= 5e-4 * total, "%.0f of %.0f electrons moved" % (moved, total)
+    # and the reads built from them: a moved electron touches two pixels of every later read
+    d = np.abs(got - want)
+    assert (d > 0.05 + 1e-6 * np.abs(want)).sum() <= 2 * got.shape[0] * max(moved, 1)
+    assert np.median(d) < 1e-6
+
+
+def test_full_noise_default_mode_everything_on():
+    over = dict(noise_mean=2.0, noise_std=0.5)
+    v, got, want, rec, orec = run_both("tiny", thrower="split", rng_mode=_lib.RNG_SPLIT, **over)
+    d = np.abs(got - want)
+    bad = int((d > 0.05 + 1e-6 * np.abs(want)).sum())
+    assert bad <= 2e-3 * got.size, "%d of %d pixels differ" % (bad, got.size)
+    assert np.median(d) < 5e-3
+
+
 def test_noise_stages_exact_samplers_replay_thrower():
     # every noise source on, but the bit-exact replay thrower: what differs from the oracle can
     # only come from the Poisson / normal stages (same streams, libm vs ocml within 1 ulp)

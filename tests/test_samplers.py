@@ -1,0 +1,191 @@
+"""Distribution tests of the oracle's counter-keyed samplers (CPU only).
+
+The reference draws Poisson / normal variates from numpy's legacy MT19937
+stream (exposure_generator.py:495,626,725; detector.py:191,198;
+cosmic_rays.py:127) and throws electrons one by one (pyparallel_menu.c:87-108).
+A sharded device path cannot replay that stream, so the oracle restates the
+same published algorithms over Philox counters (oracle/noise_oracle.c,
+oracle/split_oracle.c); these tests pin those restatements to scipy.stats.
+The device is then compared with the oracle on the same counters in the
+`-m gpu` tests.
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import clib
+
+M = 200000
+P_MIN = 1e-4      # a correct sampler fails one of these ~20 tests once in ~500 runs; the seeds are fixed
+
+
+def chi2_pvalue(sample, pmf, lo, hi):
+    """Chi-square p-value of integer `sample` against pmf(k), cells pooled to expectation >= 10."""
+    ks = np.arange(lo, hi + 1)
+    expect = pmf(ks) * sample.size
+    obs = np.bincount((np.clip(sample, lo, hi) - lo).astype(np.int64), minlength=ks.size).astype(float)
+    # the clipped end cells take the tails
+    expect[0] += (stats_sum_below(pmf, lo)) * sample.size
+    expect[-1] += max(0.0, sample.size - expect.sum())
+    cells_o, cells_e, o_acc, e_acc = [], [], 0.0, 0.0
+    for o, e in zip(obs, expect):
+        o_acc += o
+        e_acc += e
+        if e_acc >= 10.0:
+            cells_o.append(o_acc)
+            cells_e.append(e_acc)
+            o_acc = e_acc = 0.0
+    if e_acc > 0 and cells_e:
+        cells_o[-1] += o_acc
+        cells_e[-1] += e_acc
+    o, e = np.array(cells_o), np.array(cells_e)
+    e *= o.sum() / e.sum()
+    stat = ((o - e) ** 2 / e).sum()
+    return stats.chi2.sf(stat, len(o) - 1)
+
+
+def stats_sum_below(pmf, lo):
+    return float(pmf(np.arange(max(lo - 2000, 0), lo)).sum()) if lo > 0 else 0.0
+
+
+def support(mean, sd):
+    return max(int(mean - 8 * sd) - 2, 0), int(mean + 8 * sd) + 8
+
+
+@pytest.mark.parametrize("lam", [0.02, 0.7, 3.0, 9.99, 10.0, 37.5, 255.0, 1.0e4, 2.5e6])
+def test_poisson_f64_counter_streams(lam):
+    L = clib.lib()
+    out = np.empty(M)
+    L.wayne_oracle_poisson_f64(np.full(M, lam), M, 11, 1, 0, 3, 5, out)
+    assert np.all(out == np.floor(out)) and out.min() >= 0
+    lo, hi = support(lam, np.sqrt(lam))
+    assert chi2_pvalue(out, lambda k: stats.poisson.pmf(k, lam), lo, hi) > P_MIN
+    # a different counter word gives a different, equally distributed sample
+    out2 = np.empty(M)
+    L.wayne_oracle_poisson_f64(np.full(M, lam), M, 11, 1, 0, 4, 5, out2)
+    assert not np.array_equal(out, out2)
+    assert abs(out2.mean() - lam) < 5 * np.sqrt(lam / M)
+
+
+@pytest.mark.parametrize("lam", [0.3, 9.5, 10.5, 80.0, 255.9, 256.0, 3000.0])
+def test_sky_poisson_step_fp32_and_fp64_branches(lam):
+    # per-pixel seeded streams, float32 sampler below 256, float64 above (k_ramp's sky draw)
+    L = clib.lib()
+    idx = np.arange(M, dtype=np.uint32)
+    st = np.empty(M * 4, dtype=np.uint32)
+    L.wayne_oracle_seed_streams(idx, M, 99, 3, 7, st)
+    lamf = np.full(M, lam, dtype=np.float32)
+    lo, hi = support(lam, np.sqrt(lam))
+    first = np.empty(M)
+    L.wayne_oracle_poisson_sky_step(lamf, M, st, first)
+    second = np.empty(M)
+    L.wayne_oracle_poisson_sky_step(lamf, M, st, second)       # the next read's draw of the same streams
+    for s in (first, second):
+        assert chi2_pvalue(s, lambda k: stats.poisson.pmf(k, float(lamf[0])), lo, hi) > P_MIN
+    r = np.corrcoef(first, second)[0, 1]
+    assert abs(r) < 5 / np.sqrt(M)
+
+
+def test_normal_step_is_standard_normal_and_pairs_are_independent():
+    L = clib.lib()
+    idx = np.arange(M, dtype=np.uint32)
+    st = np.empty(M * 4, dtype=np.uint32)
+    L.wayne_oracle_seed_streams(idx, M, 5, 6, 0, st)
+    z0, z1 = np.empty(M, np.float32), np.empty(M, np.float32)
+    L.wayne_oracle_normal_step(M, st, z0, z1)
+    for z in (z0, z1):
+        assert stats.kstest(z.astype(float), "norm").pvalue > P_MIN
+        assert abs(z.mean()) < 5 / np.sqrt(M) and abs(z.var() - 1) < 5 * np.sqrt(2.0 / M)
+    assert abs(np.corrcoef(z0, z1)[0, 1]) < 5 / np.sqrt(M)
+    assert abs(stats.kurtosis(z0.astype(float))) < 0.06
+
+
+@pytest.mark.parametrize("n,p", [(40, 0.1), (1000, 0.004), (7, 0.5), (37, 0.97),          # inversion (BINV)
+                                 (1000, 0.3), (2000, 0.7), (50000, 0.5), (400, 0.03),     # rejection (BTRS)
+                                 (100000, 1e-5), (1, 0.25), (33, 0.999)])
+def test_binomial_fp32(n, p):
+    x = clib.binomial_vec(np.full(M, n, np.float32), np.full(M, p, np.float32), seed=5, subsample=2, exposure=9)
+    assert np.all(x == np.floor(x)) and x.min() >= 0 and x.max() <= n
+    pf = float(np.float32(p))
+    lo, hi = support(n * pf, np.sqrt(n * pf * (1 - pf)))
+    hi = min(hi, n)
+    assert chi2_pvalue(x, lambda k: stats.binom.pmf(k, n, pf), lo, hi) > P_MIN
+
+
+def test_binomial_degenerate_arguments():
+    n = np.array([0, 10, 10, 10, 5], np.float32)
+    p = np.array([0.5, 0.0, 1.0, -0.2, 1.5], np.float32)
+    np.testing.assert_array_equal(clib.binomial_vec(n, p, seed=1), [0, 0, 10, 0, 5])
+
+
+def _cell_probs(pos, sigma, n):
+    edges = np.arange(n + 1, dtype=float)
+    cdf = stats.norm.cdf((edges - pos) / sigma)
+    return np.diff(cdf)
+
+
+@pytest.mark.parametrize("sigma,fx,fy", [(0.55, 0.5, 0.5), (0.8, 0.07, 0.93), (0.89, 0.999, 0.001)])
+def test_split_oracle_lone_bin_is_the_multinomial_of_the_narrow_gaussian(sigma, fx, fy):
+    # ratio 0: every electron is narrow -> the whole frame is one multinomial draw
+    N, n = 40, 3000000
+    x, y = 20 + fx, 17 + fy
+    f = clib.psf_split_oracle([n], [x], [y], [0.0], [sigma], [5.0], N, seed=8, exposure=1, subsample=4)
+    f = f.reshape(N, N)
+    assert f.sum() == n
+    p = np.outer(_cell_probs(y, sigma, N), _cell_probs(x, sigma, N))
+    big = p * n >= 10
+    o = np.append(f[big], f[~big].sum()).astype(float)
+    e = np.append(p[big], p[~big].sum()) * n
+    keep = e > 0
+    stat = ((o[keep] - e[keep]) ** 2 / e[keep]).sum()
+    assert stats.chi2.sf(stat, keep.sum() - 1) > P_MIN
+    # marginals: columns and rows are binomial chains of their own
+    for marg, pm in ((f.sum(axis=0), _cell_probs(x, sigma, N)), (f.sum(axis=1), _cell_probs(y, sigma, N))):
+        z = (marg - n * pm) / np.sqrt(np.maximum(n * pm * (1 - pm), 1e-9))
+        assert np.abs(z[n * pm > 50]).max() < 5
+
+
+def test_split_oracle_matches_per_electron_oracle_in_distribution():
+    # the same spectrum thrown both ways, many seeds: equal pixel means within the Poisson error
+    rng = np.random.default_rng(3)
+    W, N = 60, 64
+    counts = rng.integers(0, 4000, W).astype(np.int32)
+    counts[::7] = rng.integers(0, 40, counts[::7].size)        # sparse bins stay per-electron
+    x = np.linspace(8.3, 55.1, W)
+    y = 30.2 + 0.01 * (x - 8)
+    ratio = np.full(W, 0.22)
+    sl = np.linspace(0.5, 0.9, W)
+    sh = np.full(W, 3.1)
+    a = np.zeros(N * N)
+    b = np.zeros(N * N)
+    reps = 40
+    for s in range(reps):
+        fa = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=100 + s, exposure=0, subsample=0)
+        fb = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 100 + s, 0, 0)
+        assert abs(int(fa.sum()) - int(fb.sum())) <= 40         # only the far wide tail leaves the frame
+        a += fa
+        b += fb
+    big = (a + b) > 400
+    z = (a[big] - b[big]) / np.sqrt(a[big] + b[big])
+    assert big.sum() > 300
+    assert abs(z.mean()) < 5 / np.sqrt(big.sum())
+    assert 0.85 < z.std() < 1.15
+
+
+def test_split_oracle_sparse_bins_fall_back_to_per_electron_streams():
+    # below split_min narrow electrons nothing is split: identical to the per-electron oracle
+    W, N = 30, 48
+    counts = np.full(W, 30, np.int32)
+    x = np.linspace(5.5, 40.5, W)
+    y = np.full(W, 20.25)
+    ratio = np.full(W, 0.2)
+    sl, sh = np.full(W, 0.7), np.full(W, 2.5)
+    a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
+    b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
+    np.testing.assert_array_equal(a, b)
+    # a PSF too wide for the +-6 px window is never split either
+    counts[:] = 5000
+    sl[:] = 1.0
+    a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
+    b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
+    np.testing.assert_array_equal(a, b)
