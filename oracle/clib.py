@@ -68,7 +68,7 @@ def lib():
                                                  C.c_uint32, C.c_uint32, _u32p]
         L.wayne_oracle_psf_split.restype = C.c_int
         L.wayne_oracle_psf_split.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int,
-                                             C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
+                                             C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
         L.wayne_oracle_binomial_vec.restype = None
         L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
         _lib = L
@@ -139,11 +139,11 @@ def psf_philox_oracle(counts, x, y, ratio, sl, sh, nr, nc, seed, exposure, subsa
     return out
 
 
-def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, split_min=32):
+def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, split_min=32, sparse_max=16):
     """The thrower's default mode (WAYNE_RNG_SPLIT) on the CPU, same counters as the device."""
     counts, x, y, ratio, sl, sh = _prep(counts, x, y, ratio, sl, sh)
     out = np.empty(n * n, dtype=np.int32)
-    rc = lib().wayne_oracle_psf_split(counts, counts.size, x, y, ratio, sl, sh, n, int(split_min),
+    rc = lib().wayne_oracle_psf_split(counts, counts.size, x, y, ratio, sl, sh, n, int(split_min), int(sparse_max),
                                       int(seed), int(exposure), int(subsample), out)
     if rc != 0:
         raise ValueError("wayne_oracle_psf_split: status %d" % rc)

@@ -34,7 +34,7 @@
 void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t wayne_oracle_xo_next(uint32_t state[4]);
 
-enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
+enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_STAGE_SPARSE = 10, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
 
 static float so_u01(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
 
@@ -146,18 +146,24 @@ static int so_trunc(float v) {
 /*
  * The whole thrower in split mode for one sub-sample.  Bins with at least
  * `split_min` narrow electrons (and 0.05 < sigma_l <= 6/6.5) hand them to the
- * multinomial; everything else -- the wide electrons of those bins, and sparse
- * bins whole -- is thrown one by one from STAGE_THROW streams exactly as
- * wayne_oracle_psf_philox does, numbered bin-major over the thrown electrons.
+ * multinomial.  Bins with fewer than `sparse_max` electrons are thrown from
+ * their own counters: electron j takes words 2(j&1), 2(j&1)+1 of Philox block
+ * (bin, j/2, sub-sample, exposure), stage SPARSE (a finely sampled scan has
+ * ~1 electron per bin and sub-sample; the device gives such bins one lane
+ * each).  Everything else -- the wide electrons of the split bins, and the
+ * in-between bins whole -- is thrown one by one from STAGE_THROW streams
+ * exactly as wayne_oracle_psf_philox does, numbered bin-major over the
+ * electrons thrown that way.
  */
 int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos, const double *y_pos,
                            const double *psf_ratio, const double *psf_sigmal, const double *psf_sigmah,
-                           int n, int split_min, uint32_t seed, uint32_t exposure, uint32_t subsample,
-                           int32_t *out) {
+                           int n, int split_min, int sparse_max, uint32_t seed, uint32_t exposure,
+                           uint32_t subsample, int32_t *out) {
   if (size < 0 || n <= 0) return -1;
   memset(out, 0, (size_t)n * (size_t)n * sizeof(int32_t));
   const uint32_t key_t[2] = {seed, SO_STAGE_THROW};
   const uint32_t key_n[2] = {seed, SO_STAGE_NARROW};
+  const uint32_t key_s[2] = {seed, SO_STAGE_SPARSE};
   uint64_t e = 0;
   uint32_t g[4] = {0, 0, 0, 0};
   for (int b = 0; b < size; ++b) {
@@ -171,6 +177,24 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
                       psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
     const float x = (float)x_pos[b], y = (float)y_pos[b];
     const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
+
+    if (!split && split_min > 0 && counts[b] > 0 && counts[b] < sparse_max) {
+      uint32_t w4[4] = {0, 0, 0, 0};
+      for (int j = 0; j < counts[b]; ++j) {
+        if ((j & 1) == 0) {
+          const uint32_t ctr[4] = {(uint32_t)b, (uint32_t)(j >> 1), subsample, exposure};
+          wayne_oracle_philox4x32(ctr, key_s, w4);
+        }
+        const float ua = so_u01(w4[2 * (j & 1)]), ub = so_u01(w4[2 * (j & 1) + 1]);
+        const float R = sqrtf(-2.0f * logf(ub));
+        const float ang = 6.283185307179586f * ua;
+        const float sig = (j < n_wide) ? sh : sl;
+        const int xp = so_trunc(fmaf(R * cosf(ang), sig, x));
+        const int yp = so_trunc(fmaf(R * sinf(ang), sig, y));
+        if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
+      }
+      continue;
+    }
 
     /* one by one */
     const int64_t thrown = split ? n_wide : counts[b];

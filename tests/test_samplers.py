@@ -189,3 +189,39 @@ def test_split_oracle_sparse_bins_fall_back_to_per_electron_streams():
     a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
     b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
     np.testing.assert_array_equal(a, b)
+
+
+def test_split_oracle_sparse_bins_use_their_own_counters():
+    # bins with fewer than 16 electrons: per-bin Philox blocks (stage SPARSE).  Same distribution as
+    # the per-electron thrower; a bin's electrons do not depend on what the other bins hold.
+    rng = np.random.default_rng(5)
+    W, N = 400, 64
+    counts = rng.integers(0, 16, W).astype(np.int32)
+    x = np.linspace(10.2, 52.7, W)
+    y = 30.4 + 0.01 * (x - 8)
+    ratio = np.full(W, 0.3)
+    sl, sh = np.linspace(0.5, 0.9, W), np.full(W, 2.2)
+    a = np.zeros(N * N)
+    b = np.zeros(N * N)
+    for s_ in range(60):
+        fa = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=300 + s_, exposure=1, subsample=2)
+        fb = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 300 + s_, 1, 2)
+        assert fa.sum() == fb.sum() == counts.sum()
+        a += fa
+        b += fb
+    big = (a + b) > 300
+    z = (a[big] - b[big]) / np.sqrt(a[big] + b[big])
+    assert big.sum() > 100
+    assert abs(z.mean()) < 5 / np.sqrt(big.sum()) and 0.8 < z.std() < 1.2
+    # with the rule switched off the same call is the per-electron thrower, bit for bit
+    off = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2, sparse_max=0)
+    np.testing.assert_array_equal(off, clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 1, 2))
+    # locality: emptying every other bin leaves the electrons of the remaining bins where they were
+    one = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)
+    c2 = counts.copy()
+    c2[1::2] = 0
+    c3 = counts.copy()
+    c3[0::2] = 0
+    two = clib.psf_split_oracle(c2, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)
+    three = clib.psf_split_oracle(c3, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)
+    np.testing.assert_array_equal(one, two + three)

@@ -103,6 +103,31 @@ def test_split_mode_against_oracle_same_counters(gpu_ctx, name, scale):
         assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
 
 
+def test_sparse_bins_against_oracle_same_counters(gpu_ctx):
+    # a finely sampled scan: 0-15 electrons per bin -> every bin is thrown by its own lane from its own
+    # Philox blocks (stage SPARSE); mixed with a few dense bins that take the other two routes
+    from oracle import clib
+    rng = np.random.default_rng(8)
+    W, N = 5000, 256
+    counts = rng.integers(0, 16, W).astype(np.int32)
+    counts[::97] = rng.integers(16, 3000, counts[::97].size)
+    x = np.linspace(20.3, 230.9, W)
+    y = 120.7 + 0.012 * (x - 20)
+    ratio = np.full(W, 0.27)
+    sl, sh = np.linspace(0.52, 0.9, W), np.linspace(2.0, 3.0, W)
+    for seed, exp, sub in [(5, 0, 0), (6, 3, 77)]:
+        want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed, exp, sub)
+        got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, seed, rng_mode=_lib.RNG_SPLIT, exposure=exp, subsample=sub)
+        assert got.sum() == want.sum() == counts.sum()
+        moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
+        assert moved <= 2 + 5e-4 * counts.sum(), "%d of %d electrons moved" % (moved, counts.sum())
+    # only sparse bins: nothing is left for the per-electron kernel
+    counts = rng.integers(0, 16, W).astype(np.int32)
+    want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, 9, 1, 2)
+    got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 9, rng_mode=_lib.RNG_SPLIT, exposure=1, subsample=2)
+    assert int(np.abs(got.astype(np.int64) - want).sum()) // 2 <= 2 + 5e-4 * counts.sum()
+
+
 def test_spectrum_both_modes_agree_statistically(gpu_ctx):
     from conftest import load_golden_psf
     k = load_golden_psf("s256_t4")
@@ -136,13 +161,12 @@ def test_split_mode_deterministic_sparse_and_edges(gpu_ctx):
     assert f[0, :].sum() == 0 and f[:, 0].sum() == 0                     # row / column 0 never populated (:93)
     ref = np.mean([gpu_ctx.psf_apply(*args[:-1], 50 + s, rng_mode=_lib.RNG_PHILOX).sum() for s in range(4)])
     assert abs(a.sum() - ref) < 6 * np.sqrt(ref)                         # same loss off the edges
-    # sparse bins (< 32 narrow electrons) are thrown one by one: modes coincide exactly
+    # in-between bins (>= 16 electrons, < 32 of them narrow) are thrown one by one from the STAGE_THROW
+    # blocks: there the two modes coincide exactly
     small = load_golden_psf("s64_t1")
-    s1 = gpu_ctx.psf_apply(small["counts"] // 3, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3,
-                           rng_mode=_lib.RNG_PHILOX)
-    s2 = gpu_ctx.psf_apply(small["counts"] // 3, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3,
-                           rng_mode=_lib.RNG_SPLIT)
-    assert (small["counts"] // 3).max() < 32
+    c = np.clip(small["counts"] // 3, 16, 31).astype(np.int32)
+    s1 = gpu_ctx.psf_apply(c, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3, rng_mode=_lib.RNG_PHILOX)
+    s2 = gpu_ctx.psf_apply(c, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3, rng_mode=_lib.RNG_SPLIT)
     np.testing.assert_array_equal(s1, s2)
 
 

@@ -212,7 +212,8 @@ struct PrepArgs {
   // outputs
   int32_t* counts;           // [K*W]
   int32_t* nwide;            // [K*W]
-  int32_t* nsplit;           // [K*W] narrow electrons handed to k_narrow (split mode), else 0
+  int32_t* nsplit;           // [K*W] split mode: > 0 narrow electrons handed to k_narrow's multinomial,
+                             //        < 0 minus the electrons of a sparse bin (all thrown by k_narrow), else 0
   uint32_t* prefix;          // [K*(W+1)] exclusive prefix of the electrons k_throw throws one by one
   double* xpos;              // [K*W] frame coords (x_sub)
   double* ypos;              // [K*W]
@@ -225,6 +226,7 @@ struct PrepArgs {
 
 constexpr int kPrepThreads = 512;
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
+constexpr int kSparseMax = 16;         // WAYNE_RNG_SPLIT: bins with fewer electrons are thrown lane-per-bin (k_narrow)
 
 __device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
   // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
@@ -325,8 +327,13 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       const double sl = a.wa.sigl[w];
       const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
                          sl * 6.5 <= (double)kNarrowR;
-      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
+      // ... and a sparsely populated bin (long scans sampled finely: ~1 electron per bin and
+      // sub-sample) is thrown whole by the lane that owns it in k_narrow, from the bin's own
+      // Philox blocks: walking such bins electron by electron costs a bin fetch per electron
+      const bool sparse = a.split_min > 0 && c > 0 && c < (uint32_t)kSparseMax;
+      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : sparse ? -(int32_t)c : 0;
       if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
+      if (sparse) { n_split_total += c; c = 0; }
     }
   }
   // exclusive scan of c inside the chunk: shuffle scan per wave, wave totals through LDS
@@ -476,6 +483,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
 //   (detector.py:146-147).  Integer atomics commute, so the result is
 //   bit-reproducible for any launch geometry.
 constexpr int kThrowThreads = 512;
+constexpr int kThrowPCache = 512;       // bins of a workgroup's slice whose prefix / parameters are kept in LDS
 
 struct ThrowArgs {
   int W, K, N, S;          // bins, sub-samples, frame side, bordered side
@@ -587,16 +595,53 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   uint64_t wg_end = (uint64_t)(s + 1) * kThrowThreads * L * UNIT;
   if (wg_end > E) wg_end = E;
 
+  // First / last bin of the workgroup's electron range, found by all threads at once: thread t owns
+  // a chunk of ceil(W/T) bins, the one chunk whose prefix range holds the target finishes the search
+  // locally (a per-thread binary search over the whole prefix array costs ~12 dependent HBM/L2 round
+  // trips per lane; this costs one round of independent loads plus <= 4 dependent ones in two threads).
+  __shared__ int s_rect[4];
+  __shared__ int s_bins[2];
+  __shared__ uint32_t s_P[kThrowPCache];
+  {
+    const int c = (W + kThrowThreads - 1) / kThrowThreads;
+    const int lo0 = min(tid * c, W), hi0 = min(lo0 + c, W);
+    if (lo0 < hi0) {
+      const uint32_t plo = P[lo0], phi = P[hi0];
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const uint32_t e = which ? (uint32_t)(wg_end - 1) : (uint32_t)wg_begin;
+        if (plo <= e && e < phi) {
+          int lo = lo0, hi = hi0;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P[mid] <= e) lo = mid; else hi = mid; }
+          s_bins[which] = lo;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int b0 = s_bins[0], b1 = s_bins[1];
+  // the slice's prefix entries P[b0 .. b1+1] go to LDS: the per-lane searches below stay on chip
+  const int nb = b1 - b0 + 2;
+  // (and, for the Philox thrower, the bins' parameters: lanes of a wave cross bin boundaries at
+  // different electrons, so nearly every iteration of a wave has some lane fetching a new bin --
+  // from LDS that costs ~100 cycles instead of a ~1 us round trip to L2 / HBM)
+  const bool p_cached = nb <= kThrowPCache;
+  __shared__ float s_par[RNG_MODE == 1 ? 4 * kThrowPCache : 4];
+  __shared__ int s_nw[RNG_MODE == 1 ? kThrowPCache : 4];
+  if (p_cached) {
+    for (int i = tid; i < nb; i += kThrowThreads) s_P[i] = P[b0 + i];
+    if (RNG_MODE == 1)
+      for (int i = tid; i < nb - 1; i += kThrowThreads) {
+        s_par[i] = (float)XP[b0 + i];
+        s_par[kThrowPCache + i] = (float)YP[b0 + i];
+        s_par[2 * kThrowPCache + i] = (float)a.sigl[b0 + i];
+        s_par[3 * kThrowPCache + i] = (float)a.sigh[b0 + i];
+        s_nw[i] = max(NW[b0 + i], 0);
+      }
+  }
   // the workgroup's tile: trace positions of its first and last bin +- margin, clipped to the
   // sub-sample's rectangle (already inside [1, N)) and to the LDS budget
-  __shared__ int s_rect[4];
   if (tid == 0) {
-    auto bin_of = [&](uint32_t e) {
-      int lo = 0, hi = W;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P[mid] <= e) lo = mid; else hi = mid; }
-      return lo;
-    };
-    const int b0 = bin_of((uint32_t)wg_begin), b1 = bin_of((uint32_t)(wg_end - 1));
     const double xa = fmin(XP[b0], XP[b1]), xb = fmax(XP[b0], XP[b1]);
     const double ya = fmin(YP[b0], YP[b1]), yb = fmax(YP[b0], YP[b1]);
     const double lim = 1e6;
@@ -624,29 +669,54 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   if (e_begin64 < e_end64) {
     uint32_t e = (uint32_t)e_begin64;
     const uint32_t e_end = (uint32_t)e_end64;
-    // bin b with P[b] <= e < P[b+1]
-    int lo = 0, hi = W;  // invariant: P[lo] <= e < P[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (P[mid] <= e) lo = mid; else hi = mid;
+    // bin b with P[b] <= e < P[b+1], inside the workgroup's [b0, b1]
+    int b;
+    uint32_t bin_start, bin_end;
+    if (p_cached) {
+      int lo = 0, hi = nb - 1;   // invariant: s_P[lo] <= e < s_P[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_P[mid] <= e) lo = mid; else hi = mid;
+      }
+      b = b0 + lo; bin_start = s_P[lo]; bin_end = s_P[lo + 1];
+    } else {
+      int lo = b0, hi = b1 + 1;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (P[mid] <= e) lo = mid; else hi = mid;
+      }
+      b = lo; bin_start = P[b]; bin_end = P[b + 1];
     }
-    int b = lo;
-    uint32_t bin_start = P[b], bin_end = P[b + 1];
-    uint32_t wide_end = bin_start + (uint32_t)max(NW[b], 0);
+    uint32_t wide_end = (RNG_MODE == 1 && p_cached) ? 0u : bin_start + (uint32_t)max(NW[b], 0);
 
     if (RNG_MODE == 1) {
-      float x = (float)XP[b], y = (float)YP[b];
-      float sl = (float)a.sigl[b], sh = (float)a.sigh[b];
+      float x, y, sl, sh;
+      if (p_cached) {
+        const int i = b - b0;
+        x = s_par[i]; y = s_par[kThrowPCache + i]; sl = s_par[2 * kThrowPCache + i]; sh = s_par[3 * kThrowPCache + i];
+        wide_end = bin_start + (uint32_t)s_nw[i];
+      } else {
+        x = (float)XP[b]; y = (float)YP[b];
+        sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
+      }
       while (e < e_end) {
         // one seeded stream per block of kThrowBlock electrons
         SeededStream rng(a.seed, STAGE_THROW, e / kThrowBlock, (uint32_t)k + a.subsample0, a.exposure);
         const uint32_t blk_end = min(e_end, (e / kThrowBlock + 1u) * kThrowBlock);
         for (; e < blk_end; ++e) {
           if (e >= bin_end) {
-            do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
-            wide_end = bin_start + (uint32_t)max(NW[b], 0);
-            x = (float)XP[b]; y = (float)YP[b];
-            sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
+            if (p_cached) {
+              int i = b - b0;
+              do { ++i; bin_start = bin_end; bin_end = s_P[i + 1]; } while (bin_end <= e && i + 2 < nb);
+              b = b0 + i;
+              x = s_par[i]; y = s_par[kThrowPCache + i]; sl = s_par[2 * kThrowPCache + i]; sh = s_par[3 * kThrowPCache + i];
+              wide_end = bin_start + (uint32_t)s_nw[i];
+            } else {
+              do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
+              wide_end = bin_start + (uint32_t)max(NW[b], 0);
+              x = (float)XP[b]; y = (float)YP[b];
+              sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
+            }
           }
           const float ua = u01f(rng.next());
           const float ub = u01f(rng.next());
@@ -753,12 +823,12 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const int tid = threadIdx.x;
   const int w = blockIdx.x * kNarrowThreads + tid;
   const SubInfo si = a.sub[k];
-  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;
-  if (!__syncthreads_or(n0 > 0)) return;
+  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // > 0 multinomial, < 0 sparse bin
+  if (!__syncthreads_or(n0 != 0)) return;
 
   float x = 0.f, y = 0.f, sg = 1.f;
   int ic0 = 0, jc0 = 0;
-  if (n0 > 0) {
+  if (n0 != 0) {
     x = (float)a.xpos[(size_t)k * a.W + w];
     y = (float)a.ypos[(size_t)k * a.W + w];
     sg = (float)a.sigl[w];
@@ -768,7 +838,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   // workgroup tile = bounding box of its bins' windows, clipped to [1, N)
   if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
   __syncthreads();
-  if (n0 > 0) {
+  if (n0 != 0) {
     atomicMin(&s_box[0], ic0 - kNarrowR); atomicMax(&s_box[1], ic0 + kNarrowR + 1);
     atomicMin(&s_box[2], jc0 - kNarrowR); atomicMax(&s_box[3], jc0 + kNarrowR + 1);
   }
@@ -779,60 +849,95 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const int tarea = tw * th;
   for (int i = tid; i < tarea; i += kNarrowThreads) tile[i] = 0;
 
+  // (waves that hold only sparse or empty bins skip the multinomial altogether)
+  const bool any_multi = __any(n0 > 0);
   const float inv_s = 1.f / sg;
-  // row probabilities, centre-out: c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)
-  {
-    const float f = y - (float)jc0;
-    float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
-    s_q[0][tid] = 1.f - up - lo;
-    for (int c = 1; c < kNarrowCells; ++c) {
-      const int d = (c + 1) >> 1;
-      if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); s_q[c][tid] = up - nx; up = nx; }
-      else       { const float nx = upper_tail(((float)d + f) * inv_s);       s_q[c][tid] = lo - nx; lo = nx; }
+  if (any_multi) {
+    // row probabilities, centre-out: c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)
+    {
+      const float f = y - (float)jc0;
+      float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
+      s_q[0][tid] = 1.f - up - lo;
+      for (int c = 1; c < kNarrowCells; ++c) {
+        const int d = (c + 1) >> 1;
+        if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); s_q[c][tid] = up - nx; up = nx; }
+        else       { const float nx = upper_tail(((float)d + f) * inv_s);       s_q[c][tid] = lo - nx; lo = nx; }
+      }
     }
   }
   __syncthreads();
 
-  SeededStream rng(a.seed, STAGE_NARROW, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
-  const float fx = x - (float)ic0;
-  float up = upper_tail((1.f - fx) * inv_s), lo = upper_tail(fx * inv_s);
-  float n_rem = (float)n0;
-  for (int c = 0; c < kNarrowCells; ++c) {
-    if (!__any(n_rem > 0.f)) break;
-    // this column's mass and the mass of everything not yet visited (before it)
-    const int d = (c + 1) >> 1;
-    const int ci = (c == 0) ? ic0 : ((c & 1) ? ic0 + d : ic0 - d);
-    float P, rem;
-    if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
-    else if (c & 1) { const float nx = upper_tail(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
-    else            { const float nx = upper_tail(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
-    float n_col = 0.f;
-    if (n_rem > 0.f) {
-      const float pc = fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
-      n_col = binomial<M>(n_rem, pc, rng);
-      n_rem -= n_col;
-    }
-    if (!__any(n_col > 0.f)) continue;
-    // rows of this column
-    float m_rem = n_col, qrem = 1.f;
-    for (int r = 0; r < kNarrowCells; ++r) {
-      if (!__any(m_rem > 0.f)) break;
-      const float Q = s_q[r][tid];
-      float m = 0.f;
-      if (m_rem > 0.f) {
-        const float qc = fminf(fmaxf(M::div_(Q, qrem), 0.f), 1.f);
-        m = binomial<M>(m_rem, qc, rng);
-        m_rem -= m;
+  if (any_multi) {
+    SeededStream rng(a.seed, STAGE_NARROW, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
+    const float fx = x - (float)ic0;
+    float up = upper_tail((1.f - fx) * inv_s), lo = upper_tail(fx * inv_s);
+    float n_rem = (float)max(n0, 0);
+    for (int c = 0; c < kNarrowCells; ++c) {
+      if (!__any(n_rem > 0.f)) break;
+      // this column's mass and the mass of everything not yet visited (before it)
+      const int d = (c + 1) >> 1;
+      const int ci = (c == 0) ? ic0 : ((c & 1) ? ic0 + d : ic0 - d);
+      float P, rem;
+      if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
+      else if (c & 1) { const float nx = upper_tail(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
+      else            { const float nx = upper_tail(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
+      float n_col = 0.f;
+      if (n_rem > 0.f) {
+        const float pc = fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
+        n_col = binomial<M>(n_rem, pc, rng);
+        n_rem -= n_col;
       }
-      qrem -= Q;
-      if (m > 0.f) {
-        const int e = (r + 1) >> 1;
-        const int rj = (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e);
-        const int lx = ci - tx0, ly = rj - ty0;
-        if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-          atomicAdd(&tile[ly * tw + lx], (int)m);
-        else if (ci > 0 && ci < a.N && rj > 0 && rj < a.N)       // (:93)
-          deposit_global<FLUSH>(a, si, ci, rj, (int)m);
+      if (!__any(n_col > 0.f)) continue;
+      // rows of this column
+      float m_rem = n_col, qrem = 1.f;
+      for (int r = 0; r < kNarrowCells; ++r) {
+        if (!__any(m_rem > 0.f)) break;
+        const float Q = s_q[r][tid];
+        float m = 0.f;
+        if (m_rem > 0.f) {
+          const float qc = fminf(fmaxf(M::div_(Q, qrem), 0.f), 1.f);
+          m = binomial<M>(m_rem, qc, rng);
+          m_rem -= m;
+        }
+        qrem -= Q;
+        if (m > 0.f) {
+          const int e = (r + 1) >> 1;
+          const int rj = (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e);
+          const int lx = ci - tx0, ly = rj - ty0;
+          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+            atomicAdd(&tile[ly * tw + lx], (int)m);
+          else if (ci > 0 && ci < a.N && rj > 0 && rj < a.N)       // (:93)
+            deposit_global<FLUSH>(a, si, ci, rj, (int)m);
+        }
+      }
+    }
+  }
+  // sparse bins: electron j of the bin takes words 2(j&1), 2(j&1)+1 of Philox block (w, j/2, k, exposure),
+  // stage STAGE_SPARSE; the first n_wide electrons get sigma_h as everywhere (pyparallel_menu.c:89-107)
+  {
+    const int cs = (n0 < 0) ? -n0 : 0;
+    int nw = 0;
+    float sh = 1.f;
+    if (cs > 0) { nw = max(a.nwide[(size_t)k * a.W + w], 0); sh = (float)a.sigh[w]; }
+    for (int j = 0; __any(j < cs); j += 2) {
+      if (j < cs) {
+        const u32x4 r = philox4x32_10((uint32_t)w, (uint32_t)(j >> 1), (uint32_t)k + a.subsample0, a.exposure,
+                                      a.seed, STAGE_SPARSE);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (j + h < cs) {
+            const float ua = u01f(r.v[2 * h]), ub = u01f(r.v[2 * h + 1]);
+            const float R = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
+            const float sig = (j + h < nw) ? sh : sg;
+            const int xi = (int)fmaf(R * __builtin_amdgcn_cosf(ua), sig, x);
+            const int yi = (int)fmaf(R * __builtin_amdgcn_sinf(ua), sig, y);
+            const int lx = xi - tx0, ly = yi - ty0;
+            if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+              atomicAdd(&tile[ly * tw + lx], 1);
+            else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
+              deposit_global<FLUSH>(a, si, xi, yi, 1);
+          }
+        }
       }
     }
   }

@@ -36,6 +36,8 @@ enum Stage : uint32_t {
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
   STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's
                       //   narrow-PSF electrons over pixels (k_narrow, rng_mode WAYNE_RNG_SPLIT)
+  STAGE_SPARSE = 10,  // Philox block  (bin w, j / 2, sub-sample k, exposure): words 2(j&1), 2(j&1)+1 -> electron j of a
+                      //   sparsely populated bin (fewer than kSparseMax electrons; rng_mode WAYNE_RNG_SPLIT)
 };
 constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 

@@ -56,9 +56,10 @@ struct Slot {
   DevBuf ratio, sigl, sigh, sens, dlam;
   DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
-  void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait)
+  void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait), followed by a copy of `misc`
   size_t pinned_cap = 0;
-  struct { unsigned long long electrons; int status; int pad; } misc_host{};
+  struct Misc { unsigned long long electrons; int status; int pad; };
+  Misc* pinned_misc = nullptr;   // inside `pinned`: a copy into pageable memory would block the caller
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
@@ -66,6 +67,7 @@ struct Slot {
       b->release();
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
+    pinned_misc = nullptr;
     pinned_cap = 0;
   }
 };
@@ -375,6 +377,10 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
         if (narrow >= (uint32_t)kSplitMin && psf_sigmal[i] > 0.05 && psf_sigmal[i] * 6.5 <= (double)kNarrowR) {
           nsplit[i] = (int32_t)narrow;
           thrown = wide;
+          any_split = true;
+        } else if (counts[i] > 0 && counts[i] < kSparseMax) {   // sparse bin: thrown whole by k_narrow
+          nsplit[i] = -counts[i];
+          thrown = 0;
           any_split = true;
         }
       }
@@ -808,16 +814,18 @@ int wayne_exposure_fetch_async(wayne_ctx* c, int slot) {
   use_slot_stream(c, slot);
   const size_t SS = (size_t)c->S * c->S;
   const size_t bytes = (size_t)(s.R + 1) * SS * ((s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float));
-  if (s.pinned_cap < bytes) {
+  const size_t tail = (bytes + 63) & ~(size_t)63;
+  if (s.pinned_cap < tail + 64) {
     if (s.pinned) (void)hipHostFree(s.pinned);
     s.pinned = nullptr;
     s.pinned_cap = 0;
-    if (hipHostMalloc(&s.pinned, bytes, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&s.pinned, tail + 64, hipHostMallocDefault) != hipSuccess)
       return fail(c, WAYNE_E_NOMEM, "fetch_async: pinned host allocation failed");
-    s.pinned_cap = bytes;
+    s.pinned_cap = tail + 64;
   }
+  s.pinned_misc = (Slot::Misc*)((char*)s.pinned + tail);
   HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&s.misc_host, s.misc.p, sizeof s.misc_host, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, c->stream));
   return WAYNE_OK;
 }
 
@@ -825,12 +833,12 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
   if (!c || !host_reads) return WAYNE_E_INVALID;
   if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "wait: slot");
   Slot& s = c->slots[slot];
-  if (!s.uploaded || !s.pinned) return fail(c, WAYNE_E_STATE, "wait: fetch_async first");
+  if (!s.uploaded || !s.pinned || !s.pinned_misc) return fail(c, WAYNE_E_STATE, "wait: fetch_async first");
   (void)hipSetDevice(c->device);
   use_slot_stream(c, slot);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *host_reads = s.pinned;
-  if (s.misc_host.status != 0)
+  if (s.pinned_misc->status != 0)
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
   return WAYNE_OK;
 }

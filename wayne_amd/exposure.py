@@ -9,6 +9,7 @@ the fused k_ramp kernel, and the class only holds the finished reads (read 0 =
 zero read, exposure.py:47) and writes them out (exposure.py:133-214).
 """
 import os
+import sys
 import queue
 import threading
 
@@ -99,6 +100,10 @@ class FitsWriterPool(object):
             threads = min(16, os.cpu_count() or 4)
         self._q = queue.Queue(maxsize=max_pending or 2 * threads)
         self._errors = []
+        # the generating thread must get the interpreter back quickly after each (GIL-free) GPU call:
+        # with the default 5 ms switch interval it waits behind the writers' header formatting
+        self._switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(self._switch_interval, 2e-4))
         self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, threads))]
         for t in self._threads:
             t.start()
@@ -126,5 +131,6 @@ class FitsWriterPool(object):
             self._q.put(None)
         for t in self._threads:
             t.join()
+        sys.setswitchinterval(self._switch_interval)
         if self._errors:
             raise self._errors[0]

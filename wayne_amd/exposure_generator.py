@@ -47,6 +47,7 @@ class ExposureGenerator(object):
         self.NSAMP, self.SAMPSEQ, self.SUBARRAY = NSAMP, SAMPSEQ, SUBARRAY
         self.calibration = calibration if calibration is not None else grism.calibration
         self.device, self.seed, self.exposure_index = device, seed, exposure_index
+        self._submit_slot, self._pending = None, None      # pipelined use: submit() / collect()
 
         self.exptime = self.detector.exptime(NSAMP, SUBARRAY, SAMPSEQ)             # s
         self.read_times = self.detector.get_read_times(NSAMP, SUBARRAY, SAMPSEQ)   # s
@@ -91,7 +92,7 @@ class ExposureGenerator(object):
                       add_non_linear, clip_values_det_limits, add_read_noise, add_stellar_noise,
                       add_initial_bias, progress_bar=None, threads=2, **kw):
         """A staring exposure is a scan at speed 0 sampled once per read (:146-176)."""
-        self.exposure = self.scanning_frame(
+        self.scanning_frame(
             x_ref, y_ref, x_jitter, y_jitter, wl, stellar_flux, planet_signal, 0.0, MS_PER_YEAR,
             sample_mid_points, sample_durations, read_index, None, noise_mean, noise_std, add_dark, add_flat,
             cosmic_rate, sky_background, scale_factor, add_gain_variations, add_non_linear,
@@ -124,6 +125,7 @@ class ExposureGenerator(object):
         approximations (same algorithm and streams; for parity runs).
         """
         start_time = time.time()
+        slot = self._submit_slot
         eng = _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP,
                                  self.SAMPSEQ, self.SUBARRAY, add_initial_bias)
         desc = self.build_descriptor(
@@ -132,8 +134,13 @@ class ExposureGenerator(object):
             add_flat, cosmic_rate, sky_background, scale_factor, add_gain_variations, add_non_linear,
             clip_values_det_limits, add_read_noise, add_stellar_noise, add_initial_bias, progress_bar, threads,
             rng_mode, out_dtype, reference_quirks, exact_samplers)
-        R = len(self.read_times)
-        read_dt = self._read_dt
+        if slot is not None:
+            # pipelined use (submit / collect): enqueue everything and return; the reads are picked up later
+            eng.ctx.upload(slot, desc)
+            eng.ctx.run(slot)
+            eng.ctx.fetch_async(slot)
+            self._pending = (eng, slot, start_time)
+            return None
         if record is None:
             reads = eng.ctx.synthesize(desc)
         else:
@@ -143,8 +150,12 @@ class ExposureGenerator(object):
             record.update(self._host_vectors)
             eng.ctx.run_back(0)
             reads = eng.ctx.download(0)
+        return self._fill_exposure(reads, start_time)
 
+    def _fill_exposure(self, reads, start_time):
         # read 0 is the zero read (:301-303); reads 1..R carry their timing (:371-382)
+        R = len(self.read_times)
+        read_dt = self._read_dt
         self.exposure.add_read(reads[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
         for r in range(R):
             self.exposure.add_read(reads[r + 1], {"cumulative_exp_time": float(self.read_times[r]),
@@ -152,6 +163,24 @@ class ExposureGenerator(object):
         assert len(self.exposure.reads) == self.NSAMP                                  # (:397)
         self.exp_info["sim_time"] = time.time() - start_time
         return self.exposure
+
+    # -- pipelined generation: the host prepares exposure n+1 while the GPU works on n ---------------
+    def submit(self, slot, *args, staring=False, **kw):
+        """Enqueue a scanning (or staring) frame on context slot `slot` -- same arguments as
+        scanning_frame / staring_frame -- and return at once; collect() returns the Exposure."""
+        self._submit_slot = int(slot)
+        try:
+            (self.staring_frame if staring else self.scanning_frame)(*args, **kw)
+        finally:
+            self._submit_slot = None
+        return self
+
+    def collect(self):
+        """Wait for a submitted frame -> Exposure (the reads are copied out of the slot's pinned buffer)."""
+        eng, slot, start_time = self._pending
+        self._pending = None
+        reads = np.array(eng.ctx.wait(slot))
+        return self._fill_exposure(reads, start_time)
 
     def build_descriptor(self, eng, x_ref, y_ref, x_jitter, y_jitter, wl, stellar_flux, planet_signal,
                          scan_speed, sample_rate, sample_mid_points=None, sample_durations=None,

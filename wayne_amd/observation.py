@@ -12,6 +12,7 @@ instead of an exodata object.  What changed underneath:
   * exposures are independent (counter-based RNG), so `run_observation` can
     take a (rank, world) pair and generate only its round-robin share.
 """
+import collections
 import os
 
 import numpy as np
@@ -186,21 +187,36 @@ class Observation(object):
         # files are written by background threads while the GPU works on the next exposures
         from .exposure import FitsWriterPool
         pool = FitsWriterPool() if write_fits else None
+        # ... and the host prepares exposure n+1.. while the GPU generates n: up to `depth` exposures
+        # in flight on alternating context slots (even / odd slots run on different HIP streams)
+        depth = 3
+        in_flight = collections.deque()
+
+        def finish_oldest():
+            j, gen = in_flight.popleft()
+            frame = gen.collect()
+            if pool is not None:
+                pool.submit(frame, self.outdir, "{:04d}_raw.fits".format(j + 1))
+                frames[j + 1] = None          # on disk; do not keep 64 MB per exposure alive
+            else:
+                frames[j + 1] = frame
+
         try:
-            for i in range(rank, len(self.exp_start_times), world):
-                frame = self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False)
-                if pool is not None:
-                    pool.submit(frame, self.outdir, "{:04d}_raw.fits".format(i + 1))
-                    frames[i + 1] = None          # on disk; do not keep 64 MB per exposure alive
-                else:
-                    frames[i + 1] = frame
+            for n, i in enumerate(range(rank, len(self.exp_start_times), world)):
+                if len(in_flight) >= depth:
+                    finish_oldest()
+                in_flight.append((i, self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False,
+                                                             submit_slot=n % (depth + 1))))
+            while in_flight:
+                finish_oldest()
         finally:
             if pool is not None:
                 pool.close()
         return frames
 
-    def _generate_exposure(self, expstart, number, write_fits=True):
-        """observation.py:415-504."""
+    def _generate_exposure(self, expstart, number, write_fits=True, submit_slot=None):
+        """observation.py:415-504.  With `submit_slot` the exposure is only enqueued on that context
+        slot and the ExposureGenerator is returned: call its collect() for the Exposure."""
         index_number = number - 1
         filename = "{:04d}_raw.fits".format(number)
         exp_gen = ExposureGenerator(self.detector, self.grism, self.NSAMP, self.SAMPSEQ, self.SUBARRAY, self.planet,
@@ -221,12 +237,15 @@ class Observation(object):
                       add_read_noise=self.add_read_noise, add_stellar_noise=self.add_stellar_noise,
                       add_initial_bias=self.add_initial_bias, threads=self.threads)
         if self.spatial_scan:
-            exp_frame = exp_gen.scanning_frame(x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux,
-                                               planet_depths, self.scan_speed, sample_rate, sample_mid_points,
-                                               sample_durations, read_index, ssv_generator=self.ssv_gen, **common)
+            args = (x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux, planet_depths,
+                    self.scan_speed, sample_rate, sample_mid_points, sample_durations, read_index)
+            common["ssv_generator"] = self.ssv_gen
         else:
-            exp_frame = exp_gen.staring_frame(x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux,
-                                              planet_depths, sample_mid_points, sample_durations, read_index, **common)
+            args = (x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux, planet_depths,
+                    sample_mid_points, sample_durations, read_index)
+        if submit_slot is not None:
+            return exp_gen.submit(submit_slot, *args, staring=not self.spatial_scan, **common)
+        exp_frame = exp_gen.scanning_frame(*args, **common) if self.spatial_scan else exp_gen.staring_frame(*args, **common)
         if write_fits:
             exp_frame.generate_fits(self.outdir, filename)
         return exp_frame
