@@ -1080,7 +1080,8 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
         } else if (lam < 10.f) {
           enlam = M::exp_(-lam); prod = 1.f; kk = 0.f; mode = 1;
         } else if (lam < 256.f) {
-          ps.init(lam); mode = 2;
+          if (lam != ps.lam) ps.init(lam);   // SPARS / STEP sequences repeat their read interval: same lam again
+          mode = 2;
         } else {
           done = (float)poisson<ExactMath<double> >((double)lam, rng);   // rare: long reads
         }
