@@ -60,6 +60,12 @@ struct Slot {
   size_t pinned_cap = 0;
   struct Misc { unsigned long long electrons; int status; int pad; };
   Misc* pinned_misc = nullptr;   // inside `pinned`: a copy into pageable memory would block the caller
+  // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
+  // wayne_exposure_upload returns without waiting for the slot's stream to drain
+  char* stage = nullptr;
+  size_t stage_cap = 0, stage_used = 0;
+  hipEvent_t stage_ev = nullptr;
+  bool stage_pending = false;
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
@@ -69,6 +75,12 @@ struct Slot {
     pinned = nullptr;
     pinned_misc = nullptr;
     pinned_cap = 0;
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr;
+    stage_cap = stage_used = 0;
+    if (stage_ev) (void)hipEventDestroy(stage_ev);
+    stage_ev = nullptr;
+    stage_pending = false;
   }
 };
 
@@ -187,6 +199,22 @@ template <class T>
 int upload(wayne_ctx* c, DevBuf& b, const T* src, size_t n) {
   HIP_TRY(c, b.reserve(std::max<size_t>(n, 1) * sizeof(T)));
   if (n) HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return WAYNE_OK;
+}
+
+inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// Copy `n` elements into the slot's pinned arena and enqueue the host-to-device copy from there.
+template <class T>
+int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
+  HIP_TRY(c, b.reserve(std::max<size_t>(n, 1) * sizeof(T)));
+  if (!n) return WAYNE_OK;
+  const size_t bytes = n * sizeof(T);
+  if (s.stage_used + bytes > s.stage_cap) return fail(c, WAYNE_E_NOMEM, "upload: staging arena too small");
+  char* at = s.stage + s.stage_used;
+  std::memcpy(at, src, bytes);
+  s.stage_used += align64(bytes);
+  HIP_TRY(c, hipMemcpyAsync(b.p, at, bytes, hipMemcpyHostToDevice, c->stream));
   return WAYNE_OK;
 }
 
@@ -547,27 +575,49 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   Slot& s = c->slots[slot];
   int rc;
   const size_t KW = (size_t)K * W;
-  if ((rc = upload(c, s.wl, d->wl_um, (size_t)W))) return rc;
-  if ((rc = upload(c, s.flux, d->flux, (size_t)W))) return rc;
+  {
+    // staging arena: every array of the descriptor, 64-byte aligned
+    size_t need = 2 * align64((size_t)W * 8) + 3 * align64((size_t)K * 8) + 2 * align64((size_t)K * 4) + align64((size_t)R * 8);
+    if (d->lc_z) need += 2 * align64((size_t)K * 8) + align64((size_t)W * 8);
+    if (d->depth) need += align64(KW * 8);
+    if (s.stage_pending) {           // the previous upload of this slot may still be reading the arena
+      HIP_TRY(c, hipEventSynchronize(s.stage_ev));
+      s.stage_pending = false;
+    }
+    if (s.stage_cap < need) {
+      if (s.stage) (void)hipHostFree(s.stage);
+      s.stage = nullptr;
+      s.stage_cap = 0;
+      if (hipHostMalloc((void**)&s.stage, need, hipHostMallocDefault) != hipSuccess)
+        return fail(c, WAYNE_E_NOMEM, "upload: pinned staging allocation failed");
+      s.stage_cap = need;
+    }
+    if (!s.stage_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_ev, hipEventDisableTiming));
+    s.stage_used = 0;
+  }
+  if ((rc = upload_staged(c, s, s.wl, d->wl_um, (size_t)W))) return rc;
+  if ((rc = upload_staged(c, s, s.flux, d->flux, (size_t)W))) return rc;
   s.has_lc = d->lc_z != nullptr;
   if (s.has_lc) {
     if (d->depth) return fail(c, WAYNE_E_INVALID, "upload: give either depth or lc_z, not both");
     if (!d->lc_rp) return fail(c, WAYNE_E_INVALID, "upload: lc_z needs lc_rp");
-    if ((rc = upload(c, s.lc_z, d->lc_z, (size_t)K))) return rc;
-    if ((rc = upload(c, s.lc_rp, d->lc_rp, (size_t)W))) return rc;
+    if ((rc = upload_staged(c, s, s.lc_z, d->lc_z, (size_t)K))) return rc;
+    if ((rc = upload_staged(c, s, s.lc_rp, d->lc_rp, (size_t)W))) return rc;
     s.has_lc_hidden = d->lc_hidden != nullptr;
-    if (s.has_lc_hidden && (rc = upload(c, s.lc_hidden, d->lc_hidden, (size_t)K))) return rc;
+    if (s.has_lc_hidden && (rc = upload_staged(c, s, s.lc_hidden, d->lc_hidden, (size_t)K))) return rc;
     HIP_TRY(c, s.depth.reserve(KW * sizeof(double)));
   }
   s.has_depth = d->depth != nullptr || s.has_lc;
-  if (d->depth && (rc = upload(c, s.depth, d->depth, KW))) return rc;
-  if ((rc = upload(c, s.xref, d->x_ref, (size_t)K))) return rc;
-  if ((rc = upload(c, s.yref, d->y_ref, (size_t)K))) return rc;
-  if ((rc = upload(c, s.dur, d->dur_ms, (size_t)K))) return rc;
+  if (d->depth && (rc = upload_staged(c, s, s.depth, d->depth, KW))) return rc;
+  if ((rc = upload_staged(c, s, s.xref, d->x_ref, (size_t)K))) return rc;
+  if ((rc = upload_staged(c, s, s.yref, d->y_ref, (size_t)K))) return rc;
+  if ((rc = upload_staged(c, s, s.dur, d->dur_ms, (size_t)K))) return rc;
   s.has_replay_seed = d->replay_seed != nullptr;
-  if (s.has_replay_seed && (rc = upload(c, s.rseed, d->replay_seed, (size_t)K))) return rc;
-  if ((rc = upload(c, s.sread, d->sample_read, (size_t)K))) return rc;
-  if ((rc = upload(c, s.read_dt, d->read_dt_s, (size_t)R))) return rc;
+  if (s.has_replay_seed && (rc = upload_staged(c, s, s.rseed, d->replay_seed, (size_t)K))) return rc;
+  if ((rc = upload_staged(c, s, s.sread, d->sample_read, (size_t)K))) return rc;
+  if ((rc = upload_staged(c, s, s.read_dt, d->read_dt_s, (size_t)R))) return rc;
+  HIP_TRY(c, hipEventRecord(s.stage_ev, c->stream));
+  s.stage_pending = true;
   for (DevBuf* b : {&s.ratio, &s.sigl, &s.sigh, &s.sens, &s.dlam}) HIP_TRY(c, b->reserve((size_t)W * sizeof(double)));
   HIP_TRY(c, s.counts.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.nwide.reserve(KW * sizeof(int32_t)));
@@ -594,7 +644,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   }
   const size_t out_elem = (d->flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
   HIP_TRY(c, s.out.reserve((size_t)(R + 1) * SS * out_elem));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host arrays may go away after return
+  // (no stream synchronisation: the host arrays were copied into the pinned arena above)
   s.d = *d;
   s.d.wl_um = s.d.flux = s.d.depth = s.d.x_ref = s.d.y_ref = s.d.dur_ms = s.d.read_dt_s = nullptr;
   s.d.replay_seed = s.d.sample_read = nullptr;

@@ -241,9 +241,12 @@ class ExposureGenerator(object):
         # per-exposure draws (:327-329): replay seeds and per-sub-sample jitter
         z_x, z_y, s_rand_seeds = _lib.host_sample_draws(self.seed, self.exposure_index, K)
         s_x = x_ref + z_x * x_jitter
-        s_y = np.array([s_y_refs[i] if i < len(s_y_refs) else s_y_refs[-1] for i in range(K)]) + z_y * y_jitter
+        s_y_refs = np.asarray(s_y_refs, dtype=float)
+        s_y = s_y_refs[np.minimum(np.arange(K), len(s_y_refs) - 1)] + z_y * y_jitter
         # a sub-sample without a duration (bad SSV) exposes for 0 ms (:337-342)
-        s_dur = np.array([sample_durations[i] if i < len(sample_durations) else 0.0 for i in range(K)])
+        s_dur = np.zeros(K)
+        n_dur = min(K, len(sample_durations))
+        s_dur[:n_dur] = np.asarray(sample_durations, dtype=float)[:n_dur]
 
         # crop to the grism's limits (:332-334)
         i0, i1 = tools.crop_spectrum_ind(self.grism.wl_limits[0], self.grism.wl_limits[-1], wl)
