@@ -41,9 +41,11 @@ extern "C" {
 /* rng_mode */
 #define WAYNE_RNG_REPLAY 0 /* glibc rand_r streams + OpenMP partition of the reference: bit-exact */
 #define WAYNE_RNG_PHILOX 1 /* Philox-keyed streams, every electron thrown individually */
-#define WAYNE_RNG_SPLIT 2  /* as 1 for the wide PSF component; the narrow component of each
-                              well-populated bin is drawn as one multinomial (binomial chains):
-                              the same distribution of the frame, several times less work      */
+#define WAYNE_RNG_SPLIT 2  /* production default, three routes by bin population: >= 32 narrow
+                              electrons -> the narrow component is ONE multinomial draw (binomial
+                              chains), the wide component is thrown as in mode 1; < 16 electrons ->
+                              the bin's own Philox blocks (one lane per bin); otherwise as mode 1.
+                              Same distribution of the frame, several times less work            */
 
 /* wayne_exposure_desc.flags -- the keyword switches of
  * ExposureGenerator.scanning_frame (exposure_generator.py:178-192) */
