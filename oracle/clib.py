@@ -66,6 +66,10 @@ def lib():
         L.wayne_oracle_philox_blocks.restype = None
         L.wayne_oracle_philox_blocks.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_uint32, _u32p]
+        L.wayne_oracle_sky_alias_table.restype = None
+        L.wayne_oracle_sky_alias_table.argtypes = [C.c_double, _u32p]
+        L.wayne_oracle_sky_alias_step.restype = None
+        L.wayne_oracle_sky_alias_step.argtypes = [_f32p, _f32p, _i32p, _u32p, C.c_int64, _u32p, _f64p]
         L.wayne_oracle_psf_split.restype = C.c_int
         L.wayne_oracle_psf_split.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int,
                                              C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]

@@ -19,6 +19,7 @@
  * statements of one specification check each other.
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -177,6 +178,76 @@ void wayne_oracle_poisson_sky_step(const float *lam, int64_t n, uint32_t *state,
     s.xo = state + 4 * i;
     s.have = 0;
     out[i] = (lam[i] < 256.0f) ? (double)wo_poisson_f(lam[i], &s) : wo_poisson_d((double)lam[i], &s);
+  }
+}
+
+/* ---- sky background through shared alias tables -------------------------
+ * (device: wayne_amd/csrc/kernels.h sky_draw; reference call site
+ *  exposure_generator.py:488-495, pixel += poisson(master_sky * bg_count)).
+ * Poisson(sky_px * bg) = Poisson(level * bg) + Poisson((sky_px - level) * bg):
+ * the first term from a Walker alias table shared by all pixels of one sky
+ * level, the second by sequential search from 0.
+ *
+ * Table of Poisson(lam) over 0..255 by Vose's construction: columns are
+ * visited from a stack of "small" (scaled probability < 1) and "large"
+ * entries, both filled in ascending order and popped from the top; entry =
+ * alias << 24 | round(prob * 2^24) capped at 2^24 - 1. */
+void wayne_oracle_sky_alias_table(double lam, uint32_t *out /* 256 */) {
+  enum { NT = 256 };
+  double scaled[NT], keep[NT];
+  int other[NT], lo_stack[NT], hi_stack[NT], n_lo = 0, n_hi = 0;
+  double total = 0.0;
+  for (int k = 0; k < NT; ++k) {
+    scaled[k] = (lam > 0.0) ? exp(-lam + k * log(lam) - lgamma(k + 1.0)) : (k == 0 ? 1.0 : 0.0);
+    total += scaled[k];
+  }
+  for (int k = 0; k < NT; ++k) {
+    scaled[k] = scaled[k] / total * NT;
+    keep[k] = 1.0;
+    other[k] = k;
+    if (scaled[k] < 1.0) lo_stack[n_lo++] = k; else hi_stack[n_hi++] = k;
+  }
+  while (n_lo > 0 && n_hi > 0) {
+    const int a = lo_stack[--n_lo];
+    const int b = hi_stack[--n_hi];
+    keep[a] = scaled[a];
+    other[a] = b;
+    scaled[b] = (scaled[b] + scaled[a]) - 1.0;
+    if (scaled[b] < 1.0) lo_stack[n_lo++] = b; else hi_stack[n_hi++] = b;
+  }
+  for (int k = 0; k < NT; ++k) {
+    double t = floor(keep[k] * 16777216.0 + 0.5);
+    if (t > 16777215.0) t = 16777215.0;
+    if (t < 0.0) t = 0.0;
+    out[k] = ((uint32_t)other[k] << 24) | (uint32_t)t;
+  }
+}
+
+/* One sky draw per pixel from its STAGE_SKY stream, advancing the state.
+ * table_of[i] selects the pixel's 256-entry table, lam_level[i] is the rate the
+ * table was built for, lam[i] the pixel's own rate (float32 arithmetic). */
+void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const int32_t *table_of,
+                                 const uint32_t *tables, int64_t n, uint32_t *state, double *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (!(lam[i] > 0.0f)) { out[i] = 0.0; continue; }
+    uint32_t *st = state + 4 * i;
+    const uint32_t w = wayne_oracle_xo_next(st);
+    const uint32_t col = w >> 24;
+    const uint32_t entry = tables[(size_t)table_of[i] * 256 + col];
+    float k = (float)(((w & 0xFFFFFFu) < (entry & 0xFFFFFFu)) ? col : (entry >> 24));
+    const float rest = lam[i] - lam_level[i];
+    if (rest > 0.0f) {
+      float u = wo_u01f(wayne_oracle_xo_next(st));
+      float term = expf(-rest);
+      float j = 0.0f;
+      for (int it = 0; it < 512 && u > term; ++it) {
+        u = u - term;
+        j = j + 1.0f;
+        term = term * (rest / j);
+      }
+      k = k + j;
+    }
+    out[i] = (double)k;
   }
 }
 

@@ -350,7 +350,7 @@ class LegacyDraws(object):
     def gaussian_noise(self, mean, std, dim, r):
         return self.rs.normal(mean, std, (dim, dim))    # :725
 
-    def sky_poisson(self, lam, r):
+    def sky_poisson(self, lam, r, unit_sky=None, bg_count=None):
         return self.rs.poisson(lam)                     # :495
 
     def cosmic_frame(self, rate, time, size, r):
@@ -434,14 +434,61 @@ class PhiloxDraws(object):
         z0, _ = self._normal_step(self._stream("noise", self.interior_idx, STAGE_NOISE))
         return mean + std * z0.astype(np.float64).reshape(dim, dim)
 
-    def sky_poisson(self, lam, r):
+    SKY_TABLE = 256          # entries per alias table
+    SKY_TABLES = 15          # tables that fit the device's LDS array (kMaxReads)
+
+    @staticmethod
+    def _sky_fits(lam):
+        lam = float(lam)
+        return lam >= 0. and lam + 8. * np.sqrt(lam) + 8. <= 255.
+
+    def begin_sky(self, unit_sky, bg_counts):
+        """Plan the sky draws of an exposure (device: wayne_exposure_run_back + kernels.h sky_draw):
+        L levels of the master sky per distinct read interval, one alias table of
+        Poisson(level * bg_count) each; used when every table fits 256 entries."""
+        unit = np.asarray(unit_sky, dtype=np.float32)
+        bg_counts = [np.float32(b) for b in bg_counts]
+        self._sky_plan = None
+        pos = unit[unit > 0]
+        if pos.size == 0:
+            return
+        distinct = []
+        for b in bg_counts:
+            if not any(b.tobytes() == d.tobytes() for d in distinct):
+                distinct.append(b)
+        L = max(1, min(self.SKY_TABLES // len(distinct), self.SKY_TABLES))
+        lo, hi = np.float32(pos.min()), np.float32(pos.max())
+        delta = np.float32((hi - lo) / np.float32(L))
+        levels = np.array([lo + np.float32(l) * delta for l in range(L)], dtype=np.float32)
+        tables = np.zeros((len(distinct) * L, self.SKY_TABLE), dtype=np.uint32)
+        for j, b in enumerate(distinct):
+            for l in range(L):
+                lam = np.float32(levels[l] * b)
+                if not self._sky_fits(lam):
+                    return                                    # some read does not fit: direct sampler
+                clib.lib().wayne_oracle_sky_alias_table(float(lam), tables[j * L + l])
+        if delta > 0:
+            lvl = np.clip(((unit - lo) / delta).astype(np.int64), 0, L - 1)      # float32 division, truncation
+        else:
+            lvl = np.zeros(unit.shape, dtype=np.int64)
+        self._sky_plan = dict(L=L, distinct=distinct, levels=levels, tables=tables, lvl=lvl)
+
+    def sky_poisson(self, lam, r, unit_sky=None, bg_count=None):
         # STAGE_SKY stream of each interior pixel, consumed read after read
         assert r == self._sky_next
         self._sky_next += 1
         lam32 = np.ascontiguousarray(lam, dtype=np.float32).ravel()
         out = np.empty(lam32.size)
-        clib.lib().wayne_oracle_poisson_sky_step(lam32, lam32.size, self._stream("sky", self.interior_idx, STAGE_SKY),
-                                                 out)
+        state = self._stream("sky", self.interior_idx, STAGE_SKY)
+        plan = getattr(self, "_sky_plan", None)
+        if plan is None:
+            clib.lib().wayne_oracle_poisson_sky_step(lam32, lam32.size, state, out)
+            return out.reshape(lam.shape)
+        j = [i for i, d in enumerate(plan["distinct"]) if d.tobytes() == np.float32(bg_count).tobytes()][0]
+        lvl = plan["lvl"].ravel()
+        lam_level = np.ascontiguousarray((plan["levels"][lvl] * np.float32(bg_count)).astype(np.float32))
+        table_of = np.ascontiguousarray((j * plan["L"] + lvl).astype(np.int32))
+        clib.lib().wayne_oracle_sky_alias_step(lam32, lam_level, table_of, plan["tables"].ravel(), lam32.size, state, out)
         return out.reshape(lam.shape)
 
     def cosmic_frame(self, rate, time, size, r):
@@ -566,8 +613,9 @@ class ExposureOracle(object):
         if sky_background:
             master_sky = self.grism.get_master_sky(array_size)
             bg_count = sky_background * read_exp_time
+            unit_sky = master_sky.copy()
             master_sky *= np.float32(bg_count)               # in-place on a float32 array (:493)
-            pixel_array += draws.sky_poisson(master_sky, r)
+            pixel_array += draws.sky_poisson(master_sky, r, unit_sky=unit_sky, bg_count=np.float32(bg_count))
         if cosmic_rate is not None:
             pixel_array += draws.cosmic_frame(cosmic_rate, read_exp_time, array_size, r)
         if add_gain_variations:
@@ -658,6 +706,9 @@ class ExposureOracle(object):
 
         if record is not None:
             record.update(counts=[], x=[], y=[], acc=[])
+        if sky_background and hasattr(draws, "begin_sky"):
+            dts = np.diff(np.concatenate([[0.], np.asarray(read_exp_times, dtype=float)]))
+            draws.begin_sky(self.grism.get_master_sky(pixel_array.shape[0]), [sky_background * dt for dt in dts])
         wavelength_only_test = False
         for i, s_mid in enumerate(sample_mid_points):                             # :336
             try:

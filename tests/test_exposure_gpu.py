@@ -147,6 +147,32 @@ def test_noise_stages_exact_samplers_replay_thrower():
     assert np.median(d) < 1e-4
 
 
+@pytest.mark.parametrize("sky", [0.02, 3.0, 400.0])
+def test_sky_levels_faint_to_bright(sky):
+    # faint and ordinary skies are drawn through the shared alias tables + per-pixel remainder; a sky
+    # whose rate does not fit a 256-entry table (400 e-/s) takes the direct Poisson sampler.  Same
+    # streams as the oracle in every case; only the sky stage is on.
+    over = dict(DET_OFF, sky_background=sky, add_non_linear=False, clip_values_det_limits=False)
+    v, got, want, rec, orec = run_both("small256", **over)
+    d = np.abs(got - want)
+    bad = int((d > 1e-3 + 1e-6 * np.abs(want)).sum())
+    assert bad <= 2e-4 * got.size, "%d of %d pixels differ" % (bad, got.size)
+    # and it is a Poisson sky: mean and variance of the last read's sky away from the spectrum
+    N = 256
+    acc = np.stack(orec["acc"]).sum(axis=0)[5:-5, 5:-5]
+    last = got[-1][5:-5, 5:-5] - got[0][5:-5, 5:-5]
+    dark = acc == 0
+    assert dark.sum() > 0.5 * N * N
+    lam = sky * float(pgen_exptime(v))
+    e = last[dark] * 2.35
+    assert abs(e.mean() - lam) < 0.03 * lam + 0.02
+
+
+def pgen_exptime(v):
+    from wayne_amd import detector
+    return detector.WFC3_IR().get_read_times(v.NSAMP, v.SUBARRAY, v.SAMPSEQ)[-1]
+
+
 def test_fast_samplers_agree_with_exact():
     # production math (v_rcp/v_sqrt/v_log/v_exp/v_sin/v_cos) against the exact policy, same streams
     v = helpers.make_visit("small256")

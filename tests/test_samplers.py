@@ -225,3 +225,66 @@ def test_split_oracle_sparse_bins_use_their_own_counters():
     two = clib.psf_split_oracle(c2, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)
     three = clib.psf_split_oracle(c3, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)
     np.testing.assert_array_equal(one, two + three)
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.05, 3.3, 16.4, 55.86, 146.0])
+def test_sky_alias_table_is_the_poisson_pmf(lam):
+    # the table decoded analytically: P(k) = (sum over columns that keep k + columns that alias to k) / 256
+    t = np.zeros(256, np.uint32)
+    clib.lib().wayne_oracle_sky_alias_table(float(lam), t)
+    thr = (t & 0xFFFFFF).astype(float) / 2.0 ** 24
+    alias = (t >> 24).astype(int)
+    pmf = np.zeros(256)
+    np.add.at(pmf, np.arange(256), thr / 256)
+    np.add.at(pmf, alias, (1 - thr) / 256)
+    want = stats.poisson.pmf(np.arange(256), lam) if lam > 0 else np.eye(256)[0]
+    assert abs(pmf.sum() - 1) < 1e-6
+    assert np.abs(pmf - want).max() < 2.0 ** -23           # thresholds are rounded to 24 bits
+    assert abs((pmf * np.arange(256)).sum() - lam) < 1e-4 * max(lam, 1)
+
+
+@pytest.mark.parametrize("bg", [2.0, 15.2, 51.8, 120.0])
+def test_sky_by_levels_and_residual_is_poisson(bg):
+    # Poisson(level * bg) from the shared table + Poisson((sky - level) * bg) by inversion, per pixel
+    L = clib.lib()
+    rng = np.random.default_rng(4)
+    levels = np.float32(0.93) + np.arange(7, dtype=np.float32) * np.float32(0.021)
+    tables = np.zeros((7, 256), np.uint32)
+    for l in range(7):
+        L.wayne_oracle_sky_alias_table(float(np.float32(levels[l] * np.float32(bg))), tables[l])
+    for sky in (0.93, 0.9415, 1.0, 1.0769):
+        lvl = min(6, int((np.float32(sky) - levels[0]) / np.float32(0.021)))
+        lam = np.full(M, np.float32(sky) * np.float32(bg), dtype=np.float32)
+        lam_level = np.full(M, levels[lvl] * np.float32(bg), dtype=np.float32)
+        st = np.empty(M * 4, dtype=np.uint32)
+        L.wayne_oracle_seed_streams(np.arange(M, dtype=np.uint32), M, 77, 3, int(sky * 1000), st)
+        out = np.empty(M)
+        L.wayne_oracle_sky_alias_step(lam, lam_level, np.full(M, lvl, np.int32), tables.ravel(), M, st, out)
+        lo, hi = support(float(lam[0]), np.sqrt(float(lam[0])))
+        assert chi2_pvalue(out, lambda k: stats.poisson.pmf(k, float(lam[0])), lo, hi) > P_MIN
+        second = np.empty(M)
+        L.wayne_oracle_sky_alias_step(lam, lam_level, np.full(M, lvl, np.int32), tables.ravel(), M, st, second)
+        assert abs(np.corrcoef(out, second)[0, 1]) < 5 / np.sqrt(M)
+
+
+def test_sky_plan_of_the_exposure_oracle():
+    from oracle import wayne_oracle as wo
+    d = wo.PhiloxDraws(3, 1, 64)
+    rng = np.random.default_rng(0)
+    unit = (1 + 0.05 * rng.standard_normal((64, 64))).astype(np.float32)
+    unit[3, 4] = 0.0                                            # a dead sky pixel draws nothing
+    d.begin_sky(unit, [2.9 * 5.0] + [10.0 * 5.0] * 14)
+    plan = d._sky_plan
+    assert plan is not None and plan["L"] == 7 and plan["tables"].shape == (14, 256)
+    assert plan["lvl"].min() == 0 and plan["lvl"].max() == 6
+    total = np.zeros((64, 64))
+    for r, bg in enumerate([2.9 * 5.0] + [10.0 * 5.0] * 14):
+        total += d.sky_poisson(unit * np.float32(bg), r, unit_sky=unit, bg_count=np.float32(bg))
+    assert total[3, 4] == 0
+    lam = unit.astype(float) * (2.9 * 5.0 + 14 * 50.0)
+    z = (total - lam) / np.sqrt(np.maximum(lam, 1))
+    assert abs(z.mean()) < 5 / 64 and 0.9 < z.std() < 1.1
+    # a sky too bright for the tables falls back to the direct sampler
+    d2 = wo.PhiloxDraws(3, 1, 64)
+    d2.begin_sky(unit, [400.0] * 3)
+    assert d2._sky_plan is None

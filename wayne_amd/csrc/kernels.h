@@ -1005,7 +1005,16 @@ struct RampArgs {
   const float* dark_err;
   const double* zero_read;   // [S*S] or null
   void* out;                 // [(R+1)*S*S] float or double
+  // sky background (see sky_draw): alias tables of Poisson(level_j * bg_count) for `sky_levels` levels
+  // of the master sky and every distinct read interval, for the reads whose bit is set in alias_mask
+  const uint32_t* sky_alias; // [n_tables <= kMaxReads][kSkyAlias] or null
+  uint32_t alias_mask;
+  int sky_levels;            // L
+  float sky_min, sky_delta;  // level j = sky_min + j * sky_delta
+  unsigned char sky_tab0[16];  // first table of read r (its level-0 table; level j is the j-th after it)
 };
+
+constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
 
 constexpr int kRampThreads = 256;
 constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
@@ -1050,6 +1059,41 @@ __device__ __forceinline__ double nonlinear_response(double px, float c1, float 
     u0 = u1;
   }
   return u1;
+}
+
+// Sky background of one read interval (exposure_generator.py:488-495: pixel += poisson(master_sky *
+// bg_count)).  All pixels of the frame share bg_count and the master sky is flat to a few per cent, so
+// the draw is split with the additivity of Poisson variables:
+//     Poisson(sky_px * bg) = Poisson(level_j * bg) + Poisson((sky_px - level_j) * bg),
+// level_j the highest of L levels of the master sky not above sky_px.  The first term comes from an
+// alias table (Walker / Vose) shared by every pixel of that level -- one random word, one LDS read; the
+// second has a mean of a fraction of an electron to a few electrons and is drawn by inversion from 0
+// (one word, a two- or three-step search).  No rejection loop, hardly any divergence: ~50
+// instructions instead of ~180 for a transformed-rejection draw per pixel, and exactly Poisson.
+// Exposures with a read whose rate does not fit the table (long reads under a bright sky) take the
+// ALIAS = false variant of k_ramp: Poisson(lam) per pixel by Knuth / PTRS (sky_counts below).
+template <class M, class RNG>
+__device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, float lam, RNG& rng) {
+  // shared part: N ~ Poisson(lam_level)
+  const uint32_t w = rng.next();
+  const uint32_t idx = w >> 24;
+  const uint32_t e = tab[idx];
+  float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
+  // the pixel's own part: Poisson(lam - lam_level) by sequential search
+  const float ld = lam - lam_level;
+  if (ld > 0.f) {
+    float u = M::u01(rng.next());
+    float pk = M::exp_(-ld);
+    float j = 0.f;
+    for (int it = 0; it < 512; ++it) {
+      if (u <= pk) break;
+      u = u - pk;
+      j = j + 1.f;
+      pk = pk * M::div_(ld, j);
+    }
+    k = k + j;
+  }
+  return k;
 }
 
 // Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
@@ -1105,9 +1149,11 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
   }
 }
 
-template <class OutT, bool FAST>
+template <class OutT, bool FAST, bool ALIAS>
 __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
-  __shared__ uint32_t s_sky[kMaxReads][kRampThreads];
+  typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
+  static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
+  __shared__ uint32_t s_tab[kMaxReads][kSkyAlias];   // ALIAS: alias tables; else: sky counts [read][thread]
   __shared__ float s_c[kMaxReads + 1];
   const int S = a.S;
   const int tid = threadIdx.x;
@@ -1127,15 +1173,27 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
   const bool do_sky = a.sky_ct_s > 0. && a.sky;
 
   if (tid < a.R) s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);        // bg_count of read tid (:489-491)
+  if (ALIAS && do_sky)
+    for (int i = tid; i < kMaxReads * kSkyAlias; i += kRampThreads) (&s_tab[0][0])[i] = a.sky_alias[i];
   float skyv = 0.f;
   if (interior && do_sky) skyv = a.sky[p];
   __syncthreads();
-  if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c, s_sky);
-  __syncthreads();
+  if (!ALIAS) {
+    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c, s_tab);
+    __syncthreads();
+  }
   if (!valid) return;
+  // the pixel's sky level (constant over the reads)
+  int sky_lvl = 0;
+  float sky_base = a.sky_min;
+  if (skyv > 0.f && a.sky_delta > 0.f) {
+    sky_lvl = min(a.sky_levels - 1, max((int)((skyv - a.sky_min) / a.sky_delta), 0));
+    sky_base = a.sky_min + (float)sky_lvl * a.sky_delta;
+  }
 
   // per-pixel streams, seeded only when the stage is on (one Philox block each)
-  SeededStream rn, rg;
+  SeededStream rn, rg, rs;
+  if (ALIAS && skyv > 0.f) rs = SeededStream(a.seed, STAGE_SKY, (uint32_t)p, 0u, a.exposure);
   if (rdn || do_dark) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
   if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
 
@@ -1187,7 +1245,15 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
         bm_pair<FAST>(g0, g1, z0, z1);
         px = px + (a.noise_mean * dt + (a.noise_std * dt) * (double)z0);
       }
-      if (skyv > 0.f) px = px + (double)s_sky[r][tid];   // += np.random.poisson(master_sky) (:495)
+      if (skyv > 0.f) {                                  // += np.random.poisson(master_sky) (:495)
+        // master_sky *= bg_count is an in-place float32 multiply (:493)
+        const float lam = skyv * s_c[r];
+        if (ALIAS) {
+          if (lam > 0.f) px = px + (double)sky_draw<M>(s_tab[a.sky_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
+        } else {
+          px = px + (double)s_tab[r][tid];
+        }
+      }
       px = px * inv_g;               // electrons -> DN (:507-511)
     }
     cum = cum + px;                  // cumulative_pixel_array += pixel_array_full (:378)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -60,6 +61,13 @@ struct Slot {
   size_t pinned_cap = 0;
   struct Misc { unsigned long long electrons; int status; int pad; };
   Misc* pinned_misc = nullptr;   // inside `pinned`: a copy into pageable memory would block the caller
+  // sky alias tables of this exposure (k_ramp): device copy, pinned host copy, the lam_max they were built for
+  DevBuf sky_tab;
+  uint32_t* sky_tab_host = nullptr;
+  hipEvent_t sky_tab_ev = nullptr;
+  bool sky_tab_pending = false;
+  std::vector<uint32_t> sky_tab_keys;
+  std::vector<double> read_dt_host;
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
   char* stage = nullptr;
@@ -69,8 +77,14 @@ struct Slot {
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
-                      &misc})
+                      &misc, &sky_tab})
       b->release();
+    if (sky_tab_host) (void)hipHostFree(sky_tab_host);
+    sky_tab_host = nullptr;
+    if (sky_tab_ev) (void)hipEventDestroy(sky_tab_ev);
+    sky_tab_ev = nullptr;
+    sky_tab_pending = false;
+    sky_tab_keys.clear();
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
     pinned_misc = nullptr;
@@ -114,6 +128,8 @@ struct wayne_ctx {
   DevBuf flat[4], pfl, sky, lin[4], dark_sci, dark_err, zero_read;
   bool has_flat = false, has_pfl = false, has_sky = false, has_lin = false, has_dark = false,
        has_zero = false;
+  float sky_max = 0.f, sky_min = 0.f;                            // range of the positive master sky pixels
+  std::map<uint32_t, std::vector<uint32_t> > alias_cache;        // float bits of lam_max -> alias table
   Slot slots[kSlots];
   // psf_apply scratch
   DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
@@ -203,6 +219,48 @@ int upload(wayne_ctx* c, DevBuf& b, const T* src, size_t n) {
 }
 
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// Does Poisson(lam) fit an alias table of kSkyAlias entries (mass beyond the table < 1e-14)?
+bool sky_alias_fits(double lam) {
+  return lam >= 0. && lam + 8. * std::sqrt(lam) + 8. <= (double)(kSkyAlias - 1);
+}
+
+// Walker / Vose alias table of Poisson(lam) over 0 .. kSkyAlias-1, entry = alias << 24 | threshold:
+// a 32-bit word w selects column w >> 24 and keeps it when (w & 0xFFFFFF) < threshold, else takes the
+// alias.  Probabilities in fp64, thresholds rounded to 24 bits (the resolution of a float32 uniform).
+std::vector<uint32_t> build_sky_alias(double lam) {
+  const int n = kSkyAlias;
+  std::vector<double> q((size_t)n, 0.);
+  double sum = 0.;
+  if (!(lam > 0.)) { q[0] = 1.; sum = 1.; }
+  else
+    for (int k = 0; k < n; ++k) {
+      q[k] = std::exp(-lam + k * std::log(lam) - std::lgamma(k + 1.0));
+      sum += q[k];
+    }
+  for (int k = 0; k < n; ++k) q[k] = q[k] / sum * n;
+  std::vector<int> small, large;
+  for (int k = 0; k < n; ++k) (q[k] < 1. ? small : large).push_back(k);
+  std::vector<double> prob((size_t)n, 1.);
+  std::vector<int> alias((size_t)n);
+  for (int k = 0; k < n; ++k) alias[k] = k;
+  while (!small.empty() && !large.empty()) {
+    const int s_ = small.back(); small.pop_back();
+    const int l_ = large.back(); large.pop_back();
+    prob[s_] = q[s_];
+    alias[s_] = l_;
+    q[l_] = (q[l_] + q[s_]) - 1.;
+    (q[l_] < 1. ? small : large).push_back(l_);
+  }
+  std::vector<uint32_t> out((size_t)n);
+  for (int k = 0; k < n; ++k) {
+    double t = std::floor(prob[k] * 16777216. + 0.5);
+    if (t > 16777215.) t = 16777215.;
+    if (t < 0.) t = 0.;
+    out[k] = ((uint32_t)alias[k] << 24) | (uint32_t)t;
+  }
+  return out;
+}
 
 // Copy `n` elements into the slot's pinned arena and enqueue the host-to-device copy from there.
 template <class T>
@@ -527,7 +585,17 @@ int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   c->has_sky = k->sky != nullptr;
+  c->sky_max = 0.f;
+  c->sky_min = 0.f;
   if (c->has_sky) {
+    bool any = false;
+    for (size_t i = 0; i < NN; ++i) {
+      const float v_ = k->sky[i];
+      if (!(v_ > 0.f)) continue;
+      if (!any) { c->sky_min = c->sky_max = v_; any = true; }
+      if (v_ > c->sky_max) c->sky_max = v_;
+      if (v_ < c->sky_min) c->sky_min = v_;
+    }
     std::vector<float> v = embed(k->sky, N, S, 0.0f);
     if ((rc = upload(c, c->sky, v.data(), SS))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -650,6 +718,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.replay_seed = s.d.sample_read = nullptr;
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
+  s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   s.uploaded = true;
   s.front_done = false;
   return WAYNE_OK;
@@ -812,15 +881,78 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
+  a.sky_alias = nullptr; a.alias_mask = 0; a.sky_levels = 1; a.sky_min = c->sky_min; a.sky_delta = 0.f;
+  std::memset(a.sky_tab0, 0, sizeof a.sky_tab0);
+  if (d.sky_ct_s > 0. && c->has_sky && c->sky_max > 0.f) {
+    // distinct read intervals (float32 bg_count, as the kernel and numpy use it, :489-493) -> L levels each
+    std::vector<float> bg;            // distinct bg_count values, first-appearance order
+    std::vector<int> bg_of((size_t)s.R);
+    for (int r = 0; r < s.R; ++r) {
+      const float b = (float)(d.sky_ct_s * s.read_dt_host[r]);
+      size_t j = 0;
+      while (j < bg.size() && std::memcmp(&bg[j], &b, 4) != 0) ++j;
+      if (j == bg.size()) bg.push_back(b);
+      bg_of[r] = (int)j;
+    }
+    const int L = std::max(1, std::min(kMaxReads / (int)bg.size(), kMaxReads));
+    const float delta = (c->sky_max - c->sky_min) / (float)L;
+    std::vector<uint32_t> keys(bg.size() * (size_t)L, 0u);
+    std::vector<char> fits(bg.size(), 1);
+    for (size_t j = 0; j < bg.size(); ++j)
+      for (int l = 0; l < L; ++l) {
+        const float level = c->sky_min + (float)l * delta;
+        const float lam = level * bg[j];
+        if (!sky_alias_fits((double)lam)) fits[j] = 0;
+        std::memcpy(&keys[j * L + l], &lam, 4);
+      }
+    uint32_t mask = 0;
+    for (int r = 0; r < s.R; ++r) {
+      if (fits[bg_of[r]]) mask |= 1u << r;
+      a.sky_tab0[r] = (unsigned char)(bg_of[r] * L);
+    }
+    if (mask == (1u << s.R) - 1u) {     // every read fits its tables; otherwise the exposure takes the direct sampler
+      if (keys != s.sky_tab_keys || !s.sky_tab.p) {
+        const size_t bytes = (size_t)kMaxReads * kSkyAlias * sizeof(uint32_t);
+        HIP_TRY(c, s.sky_tab.reserve(bytes));
+        if (!s.sky_tab_host && hipHostMalloc((void**)&s.sky_tab_host, bytes, hipHostMallocDefault) != hipSuccess)
+          return fail(c, WAYNE_E_NOMEM, "run: pinned allocation for the sky tables failed");
+        if (!s.sky_tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.sky_tab_ev, hipEventDisableTiming));
+        if (s.sky_tab_pending) { HIP_TRY(c, hipEventSynchronize(s.sky_tab_ev)); s.sky_tab_pending = false; }
+        std::memset(s.sky_tab_host, 0, bytes);
+        for (size_t t = 0; t < keys.size(); ++t) {
+          if (!fits[t / L]) continue;
+          auto it = c->alias_cache.find(keys[t]);
+          if (it == c->alias_cache.end()) {
+            float lam;
+            std::memcpy(&lam, &keys[t], 4);
+            if (c->alias_cache.size() > 4096) c->alias_cache.clear();
+            it = c->alias_cache.emplace(keys[t], build_sky_alias((double)lam)).first;
+          }
+          std::memcpy(s.sky_tab_host + t * kSkyAlias, it->second.data(), kSkyAlias * sizeof(uint32_t));
+        }
+        HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
+        s.sky_tab_pending = true;
+        s.sky_tab_keys = keys;
+      }
+      a.sky_alias = s.sky_tab.as<uint32_t>();
+      a.alias_mask = mask;
+      a.sky_levels = L;
+      a.sky_delta = delta;
+    }
+  }
   const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
     ProfScope ps(c, PK_RAMP);
     const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
-    if (f64 && exact) hipLaunchKernelGGL((k_ramp<double, false>), dim3(blocks), dim3(threads), 0, c->stream, a);
-    else if (f64) hipLaunchKernelGGL((k_ramp<double, true>), dim3(blocks), dim3(threads), 0, c->stream, a);
-    else if (exact) hipLaunchKernelGGL((k_ramp<float, false>), dim3(blocks), dim3(threads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ramp<float, true>), dim3(blocks), dim3(threads), 0, c->stream, a);
+    const bool alias = a.sky_alias != nullptr;
+    void (*kern)(RampArgs) =
+        alias ? (f64 ? (exact ? k_ramp<double, false, true> : k_ramp<double, true, true>)
+                     : (exact ? k_ramp<float, false, true> : k_ramp<float, true, true>))
+              : (f64 ? (exact ? k_ramp<double, false, false> : k_ramp<double, true, false>)
+                     : (exact ? k_ramp<float, false, false> : k_ramp<float, true, false>));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
   s.acc_dirty = false;
