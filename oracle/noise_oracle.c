@@ -14,7 +14,9 @@
  *   (c) agreement with the device under the same counters.
  * The algorithms are the published ones numpy's legacy poisson uses:
  * Knuth's product of uniforms for lam < 10 and Hoermann's PTRS transformed
- * rejection (Insurance: Mathematics and Economics 12, 1993) for lam >= 10.
+ * rejection (Insurance: Mathematics and Economics 12, 1993) for lam >= 10;
+ * the sky background of ordinary exposures is drawn as Poisson(level) from a
+ * Walker / Vose alias table + Poisson(remainder) by sequential search.
  * Written separately from wayne_amd/csrc/samplers.h on purpose: two
  * statements of one specification check each other.
  */
