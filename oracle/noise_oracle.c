@@ -190,7 +190,8 @@ void wayne_oracle_poisson_sky_step(const float *lam, int64_t n, uint32_t *state,
  * the first term from a Walker alias table shared by all pixels of one sky
  * level, the second by sequential search from 0.
  *
- * Table of Poisson(lam) over 0..255 by Vose's construction: columns are
+ * Table of Poisson(lam) over 0..255 (pmf by recurrence from the mode, then
+ * normalised) by Vose's construction: columns are
  * visited from a stack of "small" (scaled probability < 1) and "large"
  * entries, both filled in ascending order and popped from the top; entry =
  * alias << 24 | round(prob * 2^24) capped at 2^24 - 1. */
@@ -199,10 +200,17 @@ void wayne_oracle_sky_alias_table(double lam, uint32_t *out /* 256 */) {
   double scaled[NT], keep[NT];
   int other[NT], lo_stack[NT], hi_stack[NT], n_lo = 0, n_hi = 0;
   double total = 0.0;
-  for (int k = 0; k < NT; ++k) {
-    scaled[k] = (lam > 0.0) ? exp(-lam + k * log(lam) - lgamma(k + 1.0)) : (k == 0 ? 1.0 : 0.0);
-    total += scaled[k];
+  if (lam > 0.0) {
+    /* pmf by recurrence away from the mode: p(k+1) = p(k) lam / (k+1), p(k-1) = p(k) k / lam */
+    int mode = (int)lam;
+    if (mode > NT - 1) mode = NT - 1;
+    scaled[mode] = exp(-lam + mode * log(lam) - lgamma(mode + 1.0));
+    for (int k = mode + 1; k < NT; ++k) scaled[k] = scaled[k - 1] * lam / (double)k;
+    for (int k = mode - 1; k >= 0; --k) scaled[k] = scaled[k + 1] * (double)(k + 1) / lam;
+  } else {
+    for (int k = 0; k < NT; ++k) scaled[k] = (k == 0) ? 1.0 : 0.0;
   }
+  for (int k = 0; k < NT; ++k) total += scaled[k];
   for (int k = 0; k < NT; ++k) {
     scaled[k] = scaled[k] / total * NT;
     keep[k] = 1.0;

@@ -233,11 +233,14 @@ std::vector<uint32_t> build_sky_alias(double lam) {
   std::vector<double> q((size_t)n, 0.);
   double sum = 0.;
   if (!(lam > 0.)) { q[0] = 1.; sum = 1.; }
-  else
-    for (int k = 0; k < n; ++k) {
-      q[k] = std::exp(-lam + k * std::log(lam) - std::lgamma(k + 1.0));
-      sum += q[k];
-    }
+  else {
+    // pmf by recurrence from the mode (one exp / log / lgamma per table): p(k+1) = p(k) lam / (k+1)
+    const int k0 = std::min((int)lam, n - 1);
+    q[k0] = std::exp(-lam + k0 * std::log(lam) - std::lgamma(k0 + 1.0));
+    for (int k = k0; k + 1 < n; ++k) q[k + 1] = q[k] * lam / (double)(k + 1);
+    for (int k = k0; k > 0; --k) q[k - 1] = q[k] * (double)k / lam;
+    for (int k = 0; k < n; ++k) sum += q[k];
+  }
   for (int k = 0; k < n; ++k) q[k] = q[k] / sum * n;
   std::vector<int> small, large;
   for (int k = 0; k < n; ++k) (q[k] < 1. ? small : large).push_back(k);

@@ -97,7 +97,7 @@ class FitsWriterPool(object):
 
     def __init__(self, threads=None, max_pending=None):
         if threads is None:
-            threads = min(16, os.cpu_count() or 4)
+            threads = int(os.environ.get("WAYNE_FITS_THREADS", "0")) or min(16, os.cpu_count() or 4)
         self._q = queue.Queue(maxsize=max_pending or 2 * threads)
         self._errors = []
         # the generating thread must get the interpreter back quickly after each (GIL-free) GPU call:

@@ -199,7 +199,25 @@ def _fmt_value(v):
     return "'%-8s'" % s[:66]
 
 
+_CARD_CACHE = {}
+
+
 def _card(key, value, comment=""):
+    """One 80-character card.  A visit writes the same few hundred cards into every file, so rendered
+    cards are memoised (keyed with the value's type: True == 1 == 1.0 as dictionary keys)."""
+    try:
+        k = (key, type(value), value, comment)
+        hit = _CARD_CACHE.get(k)
+    except TypeError:            # unhashable value
+        return _render_card(key, value, comment)
+    if hit is None:
+        if len(_CARD_CACHE) > 20000:
+            _CARD_CACHE.clear()
+        hit = _CARD_CACHE[k] = _render_card(key, value, comment)
+    return hit
+
+
+def _render_card(key, value, comment=""):
     if key in ("COMMENT", "HISTORY"):
         return ("%-8s%s" % (key, value))[:80].ljust(80)
     body = "%-8s= %s" % (key[:8], _fmt_value(value))
