@@ -5,6 +5,7 @@ import pytest
 
 from conftest import golden_psf_cases, load_golden_psf
 from oracle import clib
+from wayne_amd import _lib
 
 pytestmark = pytest.mark.gpu
 CASES = golden_psf_cases()
@@ -114,3 +115,42 @@ def test_errors(gpu_ctx):
     z = gpu_ctx.psf_apply(np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0),
                           16, 16, 0, 1)
     assert z.shape == (256,) and not z.any()
+
+
+def test_hostile_inputs_all_modes(gpu_ctx):
+    # NaN / infinite / far-away positions, zero and negative sigmas, ratios outside [0, 1]: the reference's C
+    # turns all of these into rejected electrons (the (int) of a non-finite double fails 0 < pos < n,
+    # pyparallel_menu.c:91-93).  Replay mode must agree with the oracle bit for bit; the Philox modes
+    # must stay on the frame and conserve what the oracle keeps, whatever they are fed.
+    rng = np.random.default_rng(17)
+    W, N = 600, 128
+    counts = rng.integers(0, 400, W).astype(np.int32)
+    counts[::5] = rng.integers(0, 12, counts[::5].size)
+    x = rng.uniform(-30, N + 30, W)
+    y = rng.uniform(-30, N + 30, W)
+    ratio = rng.uniform(-0.5, 1.5, W)
+    sl = rng.uniform(0.0, 1.2, W)
+    sh = rng.uniform(0.0, 7.0, W)
+    x[3], y[4] = np.nan, np.nan
+    x[10], y[11] = np.inf, -np.inf
+    x[20], y[21] = 1e30, -1e30
+    sl[30], sh[31] = -0.7, -3.0
+    sl[40] = 0.0
+    ratio[50] = np.nan
+    want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, 77, 3)
+    got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 77, threads=3, rng_mode=_lib.RNG_REPLAY)
+    np.testing.assert_array_equal(got, want)
+    f = want.reshape(N, N)
+    assert f[0].sum() == 0 and f[:, 0].sum() == 0
+    for mode in (_lib.RNG_PHILOX, _lib.RNG_SPLIT):
+        a = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 5, rng_mode=mode)
+        b = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 5, rng_mode=mode)
+        np.testing.assert_array_equal(a, b)
+        fa = a.reshape(N, N)
+        assert a.min() >= 0 and fa[0].sum() == 0 and fa[:, 0].sum() == 0
+        assert abs(int(a.sum()) - int(want.sum())) < 6 * np.sqrt(want.sum())      # same loss off the frame
+    # and the default mode against its own oracle on the same counters
+    w2 = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, 5, 0, 0)
+    a = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 5, rng_mode=_lib.RNG_SPLIT)
+    moved = int(np.abs(a.astype(np.int64) - w2).sum()) // 2
+    assert moved <= 5 + 1e-3 * w2.sum(), "%d of %d electrons moved" % (moved, w2.sum())
