@@ -296,6 +296,13 @@ def main():
             if t:
                 line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = t["source"]
+        issue_file = os.path.join(ROOT, "profiles", "valu_issue.json")
+        if os.path.exists(issue_file) and args.config == "cfg4" and args.thrower == "split":
+            # the thrower kernels are bound by VALU issue, not by HBM: committed PMC summary of this workload
+            v = json.load(open(issue_file))
+            line["thrower"]["valu_issue"] = {k: {"frac": x["valu_issue_frac"], "lane_utilisation": x["lane_utilisation"]}
+                                             for k, x in v["kernels"].items()}
+            line["thrower"]["valu_issue_source"] = "profiles/valu_issue.json (rocprofv3 --pmc SQ counters, profiles/r01/final_pmc_sq.json)"
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline(visit)
         else:
