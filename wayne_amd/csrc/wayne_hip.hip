@@ -116,6 +116,11 @@ struct wayne_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // stream of the call in progress (one of streams[])
   hipStream_t streams[kStreams] = {nullptr, nullptr};
+  // k_narrow of an exposure runs beside its k_throw (both only add into the accumulators): a side
+  // stream per main stream, forked after the prep kernels and joined before the cosmic / ramp kernels
+  hipStream_t side[kStreams] = {nullptr, nullptr};
+  hipEvent_t ev_fork[kStreams] = {nullptr, nullptr}, ev_join[kStreams] = {nullptr, nullptr};
+  bool fork_narrow = true;
   int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
   std::string err;
   // grism
@@ -188,7 +193,10 @@ struct ProfScope {
 };
 
 int sync_all(wayne_ctx* c) {
-  for (int i = 0; i < kStreams; ++i) HIP_TRY(c, hipStreamSynchronize(c->streams[i]));
+  for (int i = 0; i < kStreams; ++i) {
+    HIP_TRY(c, hipStreamSynchronize(c->streams[i]));
+    if (c->side[i]) HIP_TRY(c, hipStreamSynchronize(c->side[i]));
+  }
   return WAYNE_OK;
 }
 
@@ -373,6 +381,13 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
       return nullptr;
     }
   c->stream = c->streams[0];
+  for (int i = 0; i < kStreams; ++i) {
+    if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
+      c->fork_narrow = false;     // not fatal: k_narrow then follows k_throw on the main stream
+  }
+  if (const char* e = std::getenv("WAYNE_FORK_NARROW")) c->fork_narrow = c->fork_narrow && std::atoi(e) != 0;
   if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
   if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
     for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
@@ -396,7 +411,12 @@ void wayne_ctx_destroy(wayne_ctx* c) {
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
-  for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
+  for (int i = 0; i < kStreams; ++i) {
+    (void)hipStreamDestroy(c->streams[i]);
+    if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
   delete c;
 }
 
@@ -806,6 +826,19 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
     HIP_TRY(c, hipGetLastError());
   }
+  // cosmic rays only add into the accumulators too: in split mode they ride on the side stream
+  bool cosmic_done = false;
+  auto launch_cosmic = [&]() -> int {
+    cosmic_done = true;
+    if (!(d.cosmic_rate >= 0.)) return WAYNE_OK;
+    CosmicArgs ca{};
+    ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
+    ca.rate = d.cosmic_rate; ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
+    ProfScope ps(c, PK_COSMIC);
+    hipLaunchKernelGGL(k_cosmic, dim3(R), dim3(256), 0, c->stream, ca);
+    HIP_TRY(c, hipGetLastError());
+    return WAYNE_OK;
+  };
   {
     ThrowArgs a{};
     a.W = W; a.K = K; a.N = N; a.S = S;
@@ -835,26 +868,39 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.acc = s.acc.as<long long>();
     a.frame = nullptr;
     if ((d.flags & WAYNE_F_ADD_FLAT) && !c->has_flat) return fail(c, WAYNE_E_STATE, "run: add_flat without a flat cube");
+    const int si_ = slot % c->n_streams;
+    const bool fork = d.rng_mode == WAYNE_RNG_SPLIT && c->fork_narrow;
+    hipStream_t main_stream = c->stream;
     {
-      ProfScope ps(c, PK_THROW);
+      // (with the fork, the PK_THROW interval spans both thrower kernels; PK_NARROW is k_narrow's own)
+      ProfScope ps_throw(c, PK_THROW);
+      if (fork) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork[si_], main_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->side[si_], c->ev_fork[si_], 0));
+        c->stream = c->side[si_];
+        int rc;
+        {
+          ProfScope ps(c, PK_NARROW);
+          rc = launch_narrow<1>(c, a, (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0);
+        }
+        if (rc == WAYNE_OK) rc = launch_cosmic();
+        if (rc == WAYNE_OK && hipEventRecord(c->ev_join[si_], c->side[si_]) != hipSuccess)
+          rc = fail(c, WAYNE_E_HIP, "run: event record on the side stream");
+        c->stream = main_stream;
+        if (rc) return rc;
+      }
       int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
       if (rc) return rc;
+      if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join[si_], 0));
     }
-    if (d.rng_mode == WAYNE_RNG_SPLIT) {
+    if (!fork && d.rng_mode == WAYNE_RNG_SPLIT) {
       ProfScope ps(c, PK_NARROW);
       int rc = launch_narrow<1>(c, a, (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0);
       if (rc) return rc;
     }
   }
   s.acc_dirty = true;
-  if (d.cosmic_rate >= 0.) {
-    CosmicArgs a{};
-    a.R = R; a.N = N; a.S = S; a.seed = d.seed; a.exposure = d.exposure_index;
-    a.rate = d.cosmic_rate; a.read_dt = s.read_dt.as<double>(); a.acc = s.acc.as<long long>();
-    ProfScope ps(c, PK_COSMIC);
-    hipLaunchKernelGGL(k_cosmic, dim3(R), dim3(256), 0, c->stream, a);
-    HIP_TRY(c, hipGetLastError());
-  }
+  if (!cosmic_done) { int rc = launch_cosmic(); if (rc) return rc; }
   s.front_done = true;
   return WAYNE_OK;
 }
