@@ -845,9 +845,11 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     int splits = d.thrower_splits;
     if (splits <= 0) {
       const char* e = std::getenv("WAYNE_THROW_WGS");
-      // measured optimum (scripts/sweep_throw.py): ~12 workgroups per CU -- each covers a short slice of
-      // the trace, so tiles are small (zeroing / flushing them is cheap) and occupancy is not LDS-limited
-      const int target = e ? std::max(std::atoi(e), 1) : 3072;
+      // measured (scripts/sweep_throw.py, bench.py with k_narrow running beside): flat from ~14 to ~48
+      // workgroups per CU, 8 % slower at 12 -- each workgroup covers a short slice of the trace, so
+      // tiles are small (zeroing / flushing them is cheap) and occupancy is not LDS-limited
+      // (3072 when every electron is thrown here: 5 RNG blocks per lane fill the lanes evenly)
+      const int target = e ? std::max(std::atoi(e), 1) : (d.rng_mode == WAYNE_RNG_SPLIT ? 4096 : 3072);
       splits = std::max(1, (target + K - 1) / K);
     }
     a.splits = std::min(splits, 4096);
