@@ -188,7 +188,8 @@ void wayne_oracle_poisson_sky_step(const float *lam, int64_t n, uint32_t *state,
  *  exposure_generator.py:488-495, pixel += poisson(master_sky * bg_count)).
  * Poisson(sky_px * bg) = Poisson(level * bg) + Poisson((sky_px - level) * bg):
  * the first term from a Walker alias table shared by all pixels of one sky
- * level, the second by sequential search from 0.
+ * level (levels = quantiles of the master sky), the second by sequential
+ * search from 0.
  *
  * Table of Poisson(lam) over 0..255 (pmf by recurrence from the mode, then
  * normalised) by Vose's construction: columns are
@@ -245,15 +246,18 @@ void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const
     const uint32_t col = w >> 24;
     const uint32_t entry = tables[(size_t)table_of[i] * 256 + col];
     float k = (float)(((w & 0xFFFFFFu) < (entry & 0xFFFFFFu)) ? col : (entry >> 24));
-    const float rest = lam[i] - lam_level[i];
-    if (rest > 0.0f) {
+    /* the remainder in pieces of mean <= 16: Poisson variables add */
+    float rest = lam[i] - lam_level[i];
+    while (rest > 0.0f) {
+      const float part = rest < 16.0f ? rest : 16.0f;
+      rest = rest - part;
       float u = wo_u01f(wayne_oracle_xo_next(st));
-      float term = expf(-rest);
+      float term = expf(-part);
       float j = 0.0f;
       for (int it = 0; it < 512 && u > term; ++it) {
         u = u - term;
         j = j + 1.0f;
-        term = term * (rest / j);
+        term = term * (part / j);
       }
       k = k + j;
     }

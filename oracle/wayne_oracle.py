@@ -457,9 +457,8 @@ class PhiloxDraws(object):
             if not any(b.tobytes() == d.tobytes() for d in distinct):
                 distinct.append(b)
         L = max(1, min(self.SKY_TABLES // len(distinct), self.SKY_TABLES))
-        lo, hi = np.float32(pos.min()), np.float32(pos.max())
-        delta = np.float32((hi - lo) / np.float32(L))
-        levels = np.array([lo + np.float32(l) * delta for l in range(L)], dtype=np.float32)
+        ordered = np.sort(pos)
+        levels = np.array([ordered[(l * ordered.size) // L] for l in range(L)], dtype=np.float32)   # l/L quantiles
         tables = np.zeros((len(distinct) * L, self.SKY_TABLE), dtype=np.uint32)
         for j, b in enumerate(distinct):
             for l in range(L):
@@ -467,10 +466,10 @@ class PhiloxDraws(object):
                 if not self._sky_fits(lam):
                     return                                    # some read does not fit: direct sampler
                 clib.lib().wayne_oracle_sky_alias_table(float(lam), tables[j * L + l])
-        if delta > 0:
-            lvl = np.clip(((unit - lo) / delta).astype(np.int64), 0, L - 1)      # float32 division, truncation
-        else:
-            lvl = np.zeros(unit.shape, dtype=np.int64)
+        # the highest level not above the pixel (level 0, the minimum, for the pixels that draw nothing anyway)
+        lvl = np.zeros(unit.shape, dtype=np.int64)
+        for l in range(1, L):
+            lvl += (levels[l] <= unit)
         self._sky_plan = dict(L=L, distinct=distinct, levels=levels, tables=tables, lvl=lvl)
 
     def sky_poisson(self, lam, r, unit_sky=None, bg_count=None):

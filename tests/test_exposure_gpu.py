@@ -168,6 +168,40 @@ def test_sky_levels_faint_to_bright(sky):
     assert abs(e.mean() - lam) < 0.03 * lam + 0.02
 
 
+def test_sky_plane_with_hot_dead_and_negative_pixels():
+    # a master sky as a real calibration file may hold it: dead (0) and negative pixels draw nothing, hot
+    # pixels (x6, x40) sit far above the top sky level, so their remainder is drawn in several pieces
+    from wayne_amd import calibration, detector, grism, synthetic
+    cal = calibration.CalibrationSet.synthetic(11)
+    sky = cal.sky["G141"]
+    c = (1014 - 256) // 2                       # inside the 256 sub-array's central crop
+    sky[c + 10, c + 20] = 0.0
+    sky[c + 11, c + 21] = -0.4
+    sky[c + 30, c + 40] *= 6.0
+    sky[c + 31, c + 41] *= 40.0
+    det = detector.WFC3_IR()
+    v = synthetic.Visit("small256", det, grism.G141(cal), cal, n_exposures=1)
+    over = dict(DET_OFF, sky_background=2.0, add_non_linear=False, clip_values_det_limits=False,
+                add_gain_variations=False)
+    kw = v.frame_kwargs(0, **over)
+    pg = helpers.product_generator(v, 0)
+    got = np.stack([r[0] for r in pg.scanning_frame(threads=3, rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                    exact_samplers=True, **kw).reads])
+    eo = helpers.oracle_generator(v)
+    want = np.stack(eo.scanning_frame(threads=3, draws=wo.PhiloxDraws(v.seed, 0, 256), thrower="oracle",
+                                      **helpers.oracle_kwargs(kw)))
+    d = np.abs(got - want)
+    assert int((d > 1e-3 + 1e-6 * np.abs(want)).sum()) <= 2e-4 * got.size
+    last = (got[-1] - got[0])[5:-5, 5:-5] * 2.35
+    assert last[10, 20] == 0 and last[11, 21] == 0
+    lam = 2.0 * float(pgen_exptime(v))
+    for (yy, xx, f) in ((30, 40, 6.0), (31, 41, 40.0)):
+        mean = lam * f * float(sky[c + yy, c + xx] / f)
+        assert abs(last[yy, xx] - mean) < 6 * np.sqrt(mean)
+    from wayne_amd import engine
+    engine.close_all()
+
+
 def pgen_exptime(v):
     from wayne_amd import detector
     return detector.WFC3_IR().get_read_times(v.NSAMP, v.SUBARRAY, v.SAMPSEQ)[-1]

@@ -273,14 +273,18 @@ def test_sky_plan_of_the_exposure_oracle():
     rng = np.random.default_rng(0)
     unit = (1 + 0.05 * rng.standard_normal((64, 64))).astype(np.float32)
     unit[3, 4] = 0.0                                            # a dead sky pixel draws nothing
+    unit[9, 9] = 3.5                                            # a hot one: its remainder is drawn in pieces
     d.begin_sky(unit, [2.9 * 5.0] + [10.0 * 5.0] * 14)
     plan = d._sky_plan
     assert plan is not None and plan["L"] == 7 and plan["tables"].shape == (14, 256)
     assert plan["lvl"].min() == 0 and plan["lvl"].max() == 6
+    counts = np.bincount(plan["lvl"].ravel(), minlength=7)
+    assert counts.min() > 0.1 * 64 * 64 and counts.max() < 0.2 * 64 * 64        # quantile levels: equal shares
     total = np.zeros((64, 64))
     for r, bg in enumerate([2.9 * 5.0] + [10.0 * 5.0] * 14):
         total += d.sky_poisson(unit * np.float32(bg), r, unit_sky=unit, bg_count=np.float32(bg))
     assert total[3, 4] == 0
+    assert abs(total[9, 9] - 3.5 * (2.9 * 5.0 + 14 * 50.0)) < 6 * np.sqrt(3.5 * 714.5)
     lam = unit.astype(float) * (2.9 * 5.0 + 14 * 50.0)
     z = (total - lam) / np.sqrt(np.maximum(lam, 1))
     assert abs(z.mean()) < 5 / 64 and 0.9 < z.std() < 1.1

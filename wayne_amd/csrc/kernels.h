@@ -1010,11 +1010,12 @@ struct RampArgs {
   const uint32_t* sky_alias; // [n_tables <= kMaxReads][kSkyAlias] or null
   uint32_t alias_mask;
   int sky_levels;            // L
-  float sky_min, sky_delta;  // level j = sky_min + j * sky_delta
+  float sky_level[16];       // ascending levels of the master sky (quantiles of its positive pixels; [0] = min)
   unsigned char sky_tab0[16];  // first table of read r (its level-0 table; level j is the j-th after it)
 };
 
 constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
+constexpr float kSkyPiece = 16.f; // largest mean drawn by one sequential search
 
 constexpr int kRampThreads = 256;
 constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
@@ -1065,7 +1066,7 @@ __device__ __forceinline__ double nonlinear_response(double px, float c1, float 
 // bg_count)).  All pixels of the frame share bg_count and the master sky is flat to a few per cent, so
 // the draw is split with the additivity of Poisson variables:
 //     Poisson(sky_px * bg) = Poisson(level_j * bg) + Poisson((sky_px - level_j) * bg),
-// level_j the highest of L levels of the master sky not above sky_px.  The first term comes from an
+// level_j the highest of L levels (quantiles of the master sky) not above sky_px.  The first term comes from an
 // alias table (Walker / Vose) shared by every pixel of that level -- one random word, one LDS read; the
 // second has a mean of a fraction of an electron to a few electrons and is drawn by inversion from 0
 // (one word, a two- or three-step search).  No rejection loop, hardly any divergence: ~50
@@ -1079,17 +1080,21 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   const uint32_t idx = w >> 24;
   const uint32_t e = tab[idx];
   float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
-  // the pixel's own part: Poisson(lam - lam_level) by sequential search
-  const float ld = lam - lam_level;
-  if (ld > 0.f) {
+  // the pixel's own part: Poisson(lam - lam_level) by sequential search from 0, in pieces of mean
+  // <= kSkyPiece (additivity again) so that exp(-mean) stays far from underflow whatever the sky plane
+  // holds (a hot pixel of the master sky only costs its own wave a longer loop)
+  float ld = lam - lam_level;
+  while (ld > 0.f) {
+    const float piece = fminf(ld, kSkyPiece);
+    ld = ld - piece;
     float u = M::u01(rng.next());
-    float pk = M::exp_(-ld);
+    float pk = M::exp_(-piece);
     float j = 0.f;
     for (int it = 0; it < 512; ++it) {
       if (u <= pk) break;
       u = u - pk;
       j = j + 1.f;
-      pk = pk * M::div_(ld, j);
+      pk = pk * M::div_(piece, j);
     }
     k = k + j;
   }
@@ -1183,13 +1188,11 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
     __syncthreads();
   }
   if (!valid) return;
-  // the pixel's sky level (constant over the reads)
+  // the pixel's sky level (constant over the reads): the highest level not above its sky value
   int sky_lvl = 0;
-  float sky_base = a.sky_min;
-  if (skyv > 0.f && a.sky_delta > 0.f) {
-    sky_lvl = min(a.sky_levels - 1, max((int)((skyv - a.sky_min) / a.sky_delta), 0));
-    sky_base = a.sky_min + (float)sky_lvl * a.sky_delta;
-  }
+  if (ALIAS && skyv > 0.f)
+    for (int l = 1; l < a.sky_levels; ++l) sky_lvl += (a.sky_level[l] <= skyv) ? 1 : 0;
+  const float sky_base = a.sky_level[sky_lvl];
 
   // per-pixel streams, seeded only when the stage is on (one Philox block each)
   SeededStream rn, rg, rs;

@@ -134,6 +134,7 @@ struct wayne_ctx {
   bool has_flat = false, has_pfl = false, has_sky = false, has_lin = false, has_dark = false,
        has_zero = false;
   float sky_max = 0.f, sky_min = 0.f;                            // range of the positive master sky pixels
+  std::vector<float> sky_sorted;                                 // those pixels in ascending order (levels = quantiles)
   std::map<uint32_t, std::vector<uint32_t> > alias_cache;        // float bits of lam_max -> alias table
   Slot slots[kSlots];
   // psf_apply scratch
@@ -611,14 +612,11 @@ int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
   c->sky_max = 0.f;
   c->sky_min = 0.f;
   if (c->has_sky) {
-    bool any = false;
-    for (size_t i = 0; i < NN; ++i) {
-      const float v_ = k->sky[i];
-      if (!(v_ > 0.f)) continue;
-      if (!any) { c->sky_min = c->sky_max = v_; any = true; }
-      if (v_ > c->sky_max) c->sky_max = v_;
-      if (v_ < c->sky_min) c->sky_min = v_;
-    }
+    c->sky_sorted.clear();
+    for (size_t i = 0; i < NN; ++i)
+      if (k->sky[i] > 0.f) c->sky_sorted.push_back(k->sky[i]);
+    std::sort(c->sky_sorted.begin(), c->sky_sorted.end());
+    if (!c->sky_sorted.empty()) { c->sky_min = c->sky_sorted.front(); c->sky_max = c->sky_sorted.back(); }
     std::vector<float> v = embed(k->sky, N, S, 0.0f);
     if ((rc = upload(c, c->sky, v.data(), SS))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -932,7 +930,8 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
-  a.sky_alias = nullptr; a.alias_mask = 0; a.sky_levels = 1; a.sky_min = c->sky_min; a.sky_delta = 0.f;
+  a.sky_alias = nullptr; a.alias_mask = 0; a.sky_levels = 1;
+  for (float& l_ : a.sky_level) l_ = c->sky_min;
   std::memset(a.sky_tab0, 0, sizeof a.sky_tab0);
   if (d.sky_ct_s > 0. && c->has_sky && c->sky_max > 0.f) {
     // distinct read intervals (float32 bg_count, as the kernel and numpy use it, :489-493) -> L levels each
@@ -946,12 +945,16 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
       bg_of[r] = (int)j;
     }
     const int L = std::max(1, std::min(kMaxReads / (int)bg.size(), kMaxReads));
-    const float delta = (c->sky_max - c->sky_min) / (float)L;
+    // levels = the l/L quantiles of the positive sky pixels (actual pixel values, [0] = the minimum): most
+    // pixels sit just above their level, so their own remainder is a fraction of an electron
+    float levels[16];
+    for (int l = 0; l < 16; ++l) levels[l] = c->sky_max;
+    for (int l = 0; l < L; ++l) levels[l] = c->sky_sorted[(size_t)l * c->sky_sorted.size() / (size_t)L];
     std::vector<uint32_t> keys(bg.size() * (size_t)L, 0u);
     std::vector<char> fits(bg.size(), 1);
     for (size_t j = 0; j < bg.size(); ++j)
       for (int l = 0; l < L; ++l) {
-        const float level = c->sky_min + (float)l * delta;
+        const float level = levels[l];
         const float lam = level * bg[j];
         if (!sky_alias_fits((double)lam)) fits[j] = 0;
         std::memcpy(&keys[j * L + l], &lam, 4);
@@ -989,7 +992,7 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
       a.sky_alias = s.sky_tab.as<uint32_t>();
       a.alias_mask = mask;
       a.sky_levels = L;
-      a.sky_delta = delta;
+      for (int l = 0; l < 16; ++l) a.sky_level[l] = levels[l];
     }
   }
   const int threads = kRampThreads;
