@@ -78,6 +78,9 @@ float wayne_oracle_binomial_f(float n, float p, uint32_t state[4]) {
     const float alpha = (2.83f + 5.1f / b) * spq;
     const float m = floorf((n + 1.0f) * p);
     const float r = p / q;
+    const float nm = n - m + 1.0f;
+    /* the part of the acceptance bound that the trial does not change */
+    const float fixed = (m + 0.5f) * logf((m + 1.0f) / (r * nm)) + so_fc(m) + so_fc(n - m);
     x = floorf(n * p + 0.5f);
     for (int it = 0; it < 256; ++it) {
       const float U = so_u01(wayne_oracle_xo_next(state)) - 0.5f;
@@ -87,9 +90,8 @@ float wayne_oracle_binomial_f(float n, float p, uint32_t state[4]) {
       if (us >= 0.07f && V <= vr) { x = k; break; }
       if (k < 0.0f || k > n) continue;
       const float v = logf(V * alpha / (a / (us * us) + b));
-      const float nm = n - m + 1.0f, nk = n - k + 1.0f;
-      const float bound = (m + 0.5f) * logf((m + 1.0f) / (r * nm)) + (n + 1.0f) * logf(nm / nk) +
-                          (k + 0.5f) * logf(r * nk / (k + 1.0f)) + so_fc(m) + so_fc(n - m) - so_fc(k) -
+      const float nk = n - k + 1.0f;
+      const float bound = fixed + (n + 1.0f) * logf(nm / nk) + (k + 0.5f) * logf(r * nk / (k + 1.0f)) - so_fc(k) -
                           so_fc(n - k);
       if (v <= bound) { x = k; break; }
     }

@@ -173,17 +173,18 @@ WAYNE_HD typename M::type poisson(typename M::type lam, RNG& rng) {
 // instead of throwing them one by one (k_narrow).
 // ---------------------------------------------------------------------------
 // ln k! - [ln sqrt(2 pi) + (k + 1/2) ln(k + 1) - (k + 1)]
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double kStirlingSmall[10] = {
+#else
+static const double kStirlingSmall[10] = {
+#endif
+    0.0810614667953272,  0.0413406959554092, 0.0276779256849983, 0.02079067210376509, 0.0166446911898211,
+    0.0138761288230707,  0.0118967099458917, 0.0104112652619720, 0.00925546218271273, 0.00833056343336287};
+
 template <class M>
 WAYNE_HD typename M::type stirling_tail(typename M::type k) {
   typedef typename M::type T;
-  if (k < (T)10) {
-    const int i = (int)k;
-    // exact values for k = 0..9
-    return i == 0 ? (T)0.0810614667953272 : i == 1 ? (T)0.0413406959554092 : i == 2 ? (T)0.0276779256849983
-         : i == 3 ? (T)0.02079067210376509 : i == 4 ? (T)0.0166446911898211 : i == 5 ? (T)0.0138761288230707
-         : i == 6 ? (T)0.0118967099458917 : i == 7 ? (T)0.0104112652619720 : i == 8 ? (T)0.00925546218271273
-                  : (T)0.00833056343336287;
-  }
+  if (k < (T)10) return (T)kStirlingSmall[(int)k];   // exact values for k = 0..9
   const T kp1 = k + (T)1;
   const T kp1sq = kp1 * kp1;
   return M::div_((T)(1.0 / 12) - M::div_((T)(1.0 / 360) - M::div_((T)(1.0 / 1260), kp1sq), kp1sq), kp1);
@@ -220,6 +221,9 @@ WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& 
     const T alpha = ((T)2.83 + M::div_((T)5.1, b)) * spq;
     const T m = M::floor_((n + (T)1) * p);
     const T r = M::div_(p, q);
+    // the terms of the acceptance bound that do not depend on the trial
+    const T nm = n - m + (T)1;
+    const T bound_m = (m + (T)0.5) * M::log_(M::div_(m + (T)1, r * nm)) + stirling_tail<M>(m) + stirling_tail<M>(n - m);
     x = M::floor_(n * p + (T)0.5);   // returned only if the (unreachable) iteration cap is hit
     for (int it = 0; it < 256; ++it) {
       const T U = M::u01(rng.next()) - (T)0.5;
@@ -229,10 +233,9 @@ WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& 
       if (us >= (T)0.07 && V <= vr) { x = k; break; }
       if (k < (T)0 || k > n) continue;
       const T v = M::log_(M::div_(V * alpha, M::div_(a, us * us) + b));
-      const T nm = n - m + (T)1, nk = n - k + (T)1;
-      const T ub = (m + (T)0.5) * M::log_(M::div_(m + (T)1, r * nm)) + (n + (T)1) * M::log_(M::div_(nm, nk)) +
-                   (k + (T)0.5) * M::log_(M::div_(r * nk, k + (T)1)) + stirling_tail<M>(m) +
-                   stirling_tail<M>(n - m) - stirling_tail<M>(k) - stirling_tail<M>(n - k);
+      const T nk = n - k + (T)1;
+      const T ub = bound_m + (n + (T)1) * M::log_(M::div_(nm, nk)) +
+                   (k + (T)0.5) * M::log_(M::div_(r * nk, k + (T)1)) - stirling_tail<M>(k) - stirling_tail<M>(n - k);
       if (v <= ub) { x = k; break; }
     }
   }
