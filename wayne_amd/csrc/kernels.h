@@ -487,7 +487,8 @@ constexpr int kThrowPCache = 512;       // bins of a workgroup's slice whose pre
 
 struct ThrowArgs {
   int W, K, N, S;          // bins, sub-samples, frame side, bordered side
-  int splits;
+  int splits;              // workgroups launched per sub-sample (an upper bound: see k_throw)
+  int min_wgs;             // spread the electrons over at least this many workgroups per launch
   int threads_compat;      // replay: emulated OpenMP team size
   uint32_t seed, exposure, subsample0;
   uint32_t flags;
@@ -587,12 +588,24 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   // Inside the slice lane l / wave v takes slot l (T/64) + v: the 64 lanes of a wave stay spread.
   constexpr uint32_t UNIT = (RNG_MODE == 1) ? kThrowBlock : 1u;
   const uint64_t n_units = ((uint64_t)E + UNIT - 1) / UNIT;
-  const uint64_t n_slots = (uint64_t)a.splits * kThrowThreads;
-  const uint64_t L = (n_units + n_slots - 1) / n_slots;
+  // How many of the `splits` launched workgroups share the sub-sample: enough for one unit per lane
+  // ("packed": full workgroups, the measured optimum), but at least min_wgs / K so that a few bright
+  // sub-samples (staring mode: K = 15) still reach every CU; the host sizes the grid from an estimate
+  // of the electrons, so few launched workgroups find themselves beyond B.  The B workgroups take
+  // equal shares of the units (floor / ceil), a lane m = ceil(share / T) consecutive units.
+  const uint64_t T64 = kThrowThreads;
+  uint64_t B = (n_units + T64 - 1) / T64;
+  const uint64_t spread = ((uint64_t)a.min_wgs + a.K - 1) / a.K;
+  if (B < spread) B = spread;
+  if (B > (uint64_t)a.splits) B = (uint64_t)a.splits;
+  if (B > n_units) B = n_units;
+  if ((uint64_t)s >= B) return;
+  const uint64_t u_begin = (uint64_t)s * n_units / B, u_end = ((uint64_t)s + 1) * n_units / B;
+  if (u_begin >= u_end) return;
+  const uint64_t m_units = (u_end - u_begin + T64 - 1) / T64;
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  const uint64_t wg_begin = (uint64_t)s * kThrowThreads * L * UNIT;
-  if (wg_begin >= E) return;
-  uint64_t wg_end = (uint64_t)(s + 1) * kThrowThreads * L * UNIT;
+  const uint64_t wg_begin = u_begin * UNIT;
+  uint64_t wg_end = u_end * UNIT;
   if (wg_end > E) wg_end = E;
 
   // First / last bin of the workgroup's electron range, found by all threads at once: thread t owns
@@ -661,9 +674,14 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   for (int i = tid; i < tarea; i += kThrowThreads) tile[i] = 0;
   __syncthreads();
 
-  const uint64_t slot = (uint64_t)s * kThrowThreads + (uint64_t)lane * (kThrowThreads / 64) + wave;
-  const uint64_t e_begin64 = slot * L * UNIT;
-  uint64_t e_end64 = (slot + 1) * L * UNIT;
+  // inside the workgroup lane l / wave v takes local slot l (T/64) + v: consecutive slots sit in
+  // different waves, so a partly filled workgroup still spreads over its 8 waves
+  const uint64_t q = (uint64_t)lane * (kThrowThreads / 64) + wave;
+  uint64_t ub = u_begin + q * m_units, ue = ub + m_units;
+  if (ub > u_end) ub = u_end;
+  if (ue > u_end) ue = u_end;
+  const uint64_t e_begin64 = ub * UNIT;
+  uint64_t e_end64 = ue * UNIT;
   if (e_end64 > E) e_end64 = E;
 
   if (e_begin64 < e_end64) {

@@ -68,6 +68,7 @@ struct Slot {
   bool sky_tab_pending = false;
   std::vector<uint32_t> sky_tab_keys;
   std::vector<double> read_dt_host;
+  double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
   char* stage = nullptr;
@@ -127,6 +128,7 @@ struct wayne_ctx {
   bool have_grism = false;
   GrismDev g{};
   DevBuf sens_wl, sens_val;
+  std::vector<double> sens_wl_host, sens_val_host;   // for the host's estimate of the electron count
   // calibration
   bool have_cal = false;
   int subarray = 0, N = 0, S = 0, cal_R = 0;
@@ -227,6 +229,7 @@ int upload(wayne_ctx* c, DevBuf& b, const T* src, size_t n) {
   return WAYNE_OK;
 }
 
+constexpr int kSplitMinHost = 32;
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 // Does Poisson(lam) fit an alias table of kSkyAlias entries (mass beyond the table < 1e-14)?
@@ -288,6 +291,44 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
   return WAYNE_OK;
 }
 
+// Expected number of electrons k_throw throws one by one in the longest sub-sample of an exposure
+// (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
+// the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
+double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d) {
+  const int W = d->n_wl, K = d->n_samples;
+  double dur_max = 0.;
+  for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
+  const GrismDev& g = c->g;
+  const std::vector<double>&sw = c->sens_wl_host, &sv = c->sens_val_host;
+  auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
+  double total = 0.;
+  for (int i = 0; i < W; ++i) {
+    const double x = d->wl_um[i];
+    double sens = 1.0;
+    if (!sw.empty()) {
+      if (x <= sw.front()) sens = sv.front();
+      else if (x >= sw.back()) sens = sv.back();
+      else {
+        const size_t hi = (size_t)(std::upper_bound(sw.begin(), sw.end(), x) - sw.begin());
+        const size_t lo = hi - 1;
+        sens = sv[lo] + (sv[hi] - sv[lo]) * (x - sw[lo]) / (sw[hi] - sw[lo]);
+      }
+    }
+    const double left = (i == 0) ? (d->wl_um[1] - d->wl_um[0]) / 2. : (x - d->wl_um[i - 1]) / 2.;
+    const double right = (i == W - 1) ? (d->wl_um[W - 1] - d->wl_um[W - 2]) / 2. : (d->wl_um[i + 1] - x) / 2.;
+    double cnt = d->flux[i] * sens * (left + right) * 1e4 * dur_max * 1e-3 * d->scale_factor;
+    if (!(cnt > 0.)) continue;
+    if (d->rng_mode == WAYNE_RNG_SPLIT) {
+      const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
+      const double sl = poly3(g.p_sigl, x);
+      if (cnt - wide >= (double)kSplitMinHost && sl > 0.05 && sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
+      else if (cnt < (double)kSparseMax) cnt = 0.;                                                    // sparse bin: k_narrow
+    }
+    total += cnt;
+  }
+  return total;
+}
+
 int side_of(int subarray) { return subarray == 1024 ? 1014 : subarray; }  // detector.py:116-119
 
 // N*N plane -> S*S bordered layout (value `fill` on the 5-px border)
@@ -320,6 +361,7 @@ int launch_throw(wayne_ctx* c, const ThrowArgs& a, int lds_ints) {
 }
 
 constexpr int kSplitMin = 32;   // bins with fewer narrow electrons are thrown one by one
+static_assert(kSplitMin == kSplitMinHost, "split threshold");
 
 template <int FLUSH>
 int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
@@ -526,6 +568,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.W = size; a.K = 1; a.N = N; a.S = N + 2 * kBorder;
     // enough workgroups to fill the chip when the call is big, one when small
     a.splits = (int)std::min<long long>(512, std::max<long long>(1, total / (64LL * kThrowThreads)));
+    a.min_wgs = a.splits;   // one call, one sub-sample: share the electrons among all launched workgroups
     a.threads_compat = threads_compat;
     a.margin = margin;
     const int lds_ints = thrower_lds_ints(c, a.splits, margin);
@@ -571,6 +614,8 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   if ((rc = upload(c, c->sens_wl, g->sens_wl_um, (size_t)g->n_sens))) return rc;
   if ((rc = upload(c, c->sens_val, g->sens_val, (size_t)g->n_sens))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->sens_wl_host.assign(g->sens_wl_um, g->sens_wl_um + g->n_sens);
+  c->sens_val_host.assign(g->sens_val, g->sens_val + g->n_sens);
   GrismDev& d = c->g;
   std::memcpy(d.trace, g->trace_coeff, sizeof d.trace);
   std::memcpy(d.wlsol, g->wl_solution, sizeof d.wlsol);
@@ -740,6 +785,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
+  s.est_thrown = estimate_thrown(c, d);
   s.uploaded = true;
   s.front_done = false;
   return WAYNE_OK;
@@ -840,16 +886,26 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   {
     ThrowArgs a{};
     a.W = W; a.K = K; a.N = N; a.S = S;
+    // grid: one unit (128 electrons; 1 in replay mode) per lane of the workgroups of a sub-sample, from
+    // the host's estimate of the electrons + 8 %, but at least ~4 workgroups per CU over the launch
+    // (WAYNE_THROW_WGS / desc.thrower_splits override); k_throw shares out what it actually finds
+    const int min_wgs = 1024;
     int splits = d.thrower_splits;
     if (splits <= 0) {
-      const char* e = std::getenv("WAYNE_THROW_WGS");
-      // measured (scripts/sweep_throw.py, bench.py with k_narrow running beside): flat from ~14 to ~48
-      // workgroups per CU, 8 % slower at 12 -- each workgroup covers a short slice of the trace, so
-      // tiles are small (zeroing / flushing them is cheap) and occupancy is not LDS-limited
-      // (3072 when every electron is thrown here: 5 RNG blocks per lane fill the lanes evenly)
-      const int target = e ? std::max(std::atoi(e), 1) : (d.rng_mode == WAYNE_RNG_SPLIT ? 4096 : 3072);
-      splits = std::max(1, (target + K - 1) / K);
+      if (const char* e = std::getenv("WAYNE_THROW_WGS")) {
+        splits = std::max(1, (std::max(std::atoi(e), 1) + K - 1) / K);
+      } else {
+        const double unit = (d.rng_mode == WAYNE_RNG_REPLAY) ? 1. : (double)kThrowBlock;
+        const double lanes = 1.08 * s.est_thrown / unit;
+        splits = (int)std::min(4096., std::ceil(lanes / kThrowThreads));
+        // a lane takes several units when the launch would exceed ~24 workgroups per CU: then ~12 per CU
+        // (each lane a handful of units) is the measured optimum (scripts/sweep_throw.py)
+        const int cap = std::max(1, (3072 + K - 1) / K);
+        if (splits > 2 * cap) splits = cap;
+        splits = std::max(splits, (min_wgs + K - 1) / K);
+      }
     }
+    a.min_wgs = min_wgs;
     a.splits = std::min(splits, 4096);
     a.margin = margin;
     const int lds_ints = thrower_lds_ints(c, a.splits, margin);
