@@ -1102,19 +1102,22 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   // <= kSkyPiece (additivity again) so that exp(-mean) stays far from underflow whatever the sky plane
   // holds (a hot pixel of the master sky only costs its own wave a longer loop)
   float ld = lam - lam_level;
-  while (ld > 0.f) {
-    const float piece = fminf(ld, kSkyPiece);
-    ld = ld - piece;
-    float u = M::u01(rng.next());
-    float pk = M::exp_(-piece);
-    float j = 0.f;
-    for (int it = 0; it < 512; ++it) {
-      if (u <= pk) break;
-      u = u - pk;
-      j = j + 1.f;
-      pk = pk * M::div_(piece, j);
+  if (ld > 0.f) {
+    for (;;) {
+      const float piece = fminf(ld, kSkyPiece);
+      float u = M::u01(rng.next());
+      float pk = M::exp_(-piece);
+      float j = 0.f;
+      for (int it = 0; it < 512; ++it) {
+        if (u <= pk) break;
+        u = u - pk;
+        j = j + 1.f;
+        pk = pk * M::div_(piece, j);
+      }
+      k = k + j;
+      ld = ld - piece;
+      if (!(ld > 0.f)) break;     // nearly always after the first piece
     }
-    k = k + j;
   }
   return k;
 }
