@@ -1091,20 +1091,20 @@ __device__ __forceinline__ double nonlinear_response(double px, float c1, float 
 // instructions instead of ~180 for a transformed-rejection draw per pixel, and exactly Poisson.
 // Exposures with a read whose rate does not fit the table (long reads under a bright sky) take the
 // ALIAS = false variant of k_ramp: Poisson(lam) per pixel by Knuth / PTRS (sky_counts below).
-template <class M, class RNG>
+template <class M, bool PIECES, class RNG>
 __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, float lam, RNG& rng) {
   // shared part: N ~ Poisson(lam_level)
   const uint32_t w = rng.next();
   const uint32_t idx = w >> 24;
   const uint32_t e = tab[idx];
   float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
-  // the pixel's own part: Poisson(lam - lam_level) by sequential search from 0, in pieces of mean
-  // <= kSkyPiece (additivity again) so that exp(-mean) stays far from underflow whatever the sky plane
-  // holds (a hot pixel of the master sky only costs its own wave a longer loop)
+  // the pixel's own part: Poisson(lam - lam_level) by sequential search from 0.  PIECES (chosen by the
+  // host when some pixel of the master sky lies far above its level -- a hot pixel): in pieces of mean
+  // <= kSkyPiece (additivity again), so that exp(-mean) stays far from underflow whatever the plane holds
   float ld = lam - lam_level;
   if (ld > 0.f) {
     for (;;) {
-      const float piece = fminf(ld, kSkyPiece);
+      const float piece = PIECES ? fminf(ld, kSkyPiece) : ld;
       float u = M::u01(rng.next());
       float pk = M::exp_(-piece);
       float j = 0.f;
@@ -1115,8 +1115,9 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
         pk = pk * M::div_(piece, j);
       }
       k = k + j;
+      if (!PIECES) break;
       ld = ld - piece;
-      if (!(ld > 0.f)) break;     // nearly always after the first piece
+      if (!(ld > 0.f)) break;
     }
   }
   return k;
@@ -1175,8 +1176,11 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
   }
 }
 
-template <class OutT, bool FAST, bool ALIAS>
+// SKY: 0 = Poisson(lam) per pixel (sky_counts), 1 = alias tables + one-piece remainder, 2 = alias tables +
+// remainder in pieces (a master sky with hot pixels)
+template <class OutT, bool FAST, int SKY>
 __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
+  constexpr bool ALIAS = SKY != 0;
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
   __shared__ uint32_t s_tab[kMaxReads][kSkyAlias];   // ALIAS: alias tables; else: sky counts [read][thread]
@@ -1273,7 +1277,7 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
         // master_sky *= bg_count is an in-place float32 multiply (:493)
         const float lam = skyv * s_c[r];
         if (ALIAS) {
-          if (lam > 0.f) px = px + (double)sky_draw<M>(s_tab[a.sky_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
+          if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[a.sky_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
         } else {
           px = px + (double)s_tab[r][tid];
         }

@@ -986,6 +986,7 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
+  bool sky_pieces = false;
   a.sky_alias = nullptr; a.alias_mask = 0; a.sky_levels = 1;
   for (float& l_ : a.sky_level) l_ = c->sky_min;
   std::memset(a.sky_tab0, 0, sizeof a.sky_tab0);
@@ -1049,6 +1050,12 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
       a.alias_mask = mask;
       a.sky_levels = L;
       for (int l = 0; l < 16; ++l) a.sky_level[l] = levels[l];
+      // largest remainder any pixel can have: the widest gap between levels (the top one reaches sky_max)
+      float gap = c->sky_max - levels[L - 1];
+      for (int l = 0; l + 1 < L; ++l) gap = std::max(gap, levels[l + 1] - levels[l]);
+      float bg_max = 0.f;
+      for (float b : bg) bg_max = std::max(bg_max, b);
+      sky_pieces = !(gap * bg_max <= kSkyPiece);
     }
   }
   const int threads = kRampThreads;
@@ -1056,12 +1063,14 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   {
     ProfScope ps(c, PK_RAMP);
     const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
-    const bool alias = a.sky_alias != nullptr;
+    const int sky_mode = a.sky_alias == nullptr ? 0 : (sky_pieces ? 2 : 1);
     void (*kern)(RampArgs) =
-        alias ? (f64 ? (exact ? k_ramp<double, false, true> : k_ramp<double, true, true>)
-                     : (exact ? k_ramp<float, false, true> : k_ramp<float, true, true>))
-              : (f64 ? (exact ? k_ramp<double, false, false> : k_ramp<double, true, false>)
-                     : (exact ? k_ramp<float, false, false> : k_ramp<float, true, false>));
+        sky_mode == 1 ? (f64 ? (exact ? k_ramp<double, false, 1> : k_ramp<double, true, 1>)
+                             : (exact ? k_ramp<float, false, 1> : k_ramp<float, true, 1>))
+        : sky_mode == 2 ? (f64 ? (exact ? k_ramp<double, false, 2> : k_ramp<double, true, 2>)
+                               : (exact ? k_ramp<float, false, 2> : k_ramp<float, true, 2>))
+                        : (f64 ? (exact ? k_ramp<double, false, 0> : k_ramp<double, true, 0>)
+                               : (exact ? k_ramp<float, false, 0> : k_ramp<float, true, 0>));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
