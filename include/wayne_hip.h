@@ -257,6 +257,10 @@ typedef struct wayne_profile {
 } wayne_profile;
 
 int wayne_profile_enable(wayne_ctx *ctx, int on);
+/* Restrict the HIP-event timing to the kernels whose bit (1 << index in `name`) is set; every event
+ * pair costs a few microseconds of stream time, so a throughput measurement that only needs one
+ * kernel's duration selects that kernel.  Default: all kernels. */
+int wayne_profile_select(wayne_ctx *ctx, unsigned mask);
 int wayne_profile_reset(wayne_ctx *ctx);
 int wayne_profile_get(wayne_ctx *ctx, wayne_profile *out); /* synchronises */
 

@@ -102,6 +102,7 @@ SYMBOLS = {
     "wayne_exposure_run_front": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_run_back": (C.c_int, [_vp, C.c_int]),
     "wayne_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "wayne_profile_select": (C.c_int, [_vp, C.c_uint]),
     "wayne_profile_reset": (C.c_int, [_vp]),
     "wayne_profile_get": (C.c_int, [_vp, C.POINTER(Profile)]),
     "wayne_philox4x32": (None, [_vp, _vp, _vp]),
@@ -324,6 +325,17 @@ class Context(object):
     # -- measurement -----------------------------------------------------------
     def profile_enable(self, on=True):
         self.check(self._L.wayne_profile_enable(self._h, 1 if on else 0))
+
+    def profile_select(self, names=None):
+        """Time only the named kernels (e.g. ["k_ramp"]); None = all."""
+        if names is None:
+            mask = 0xFFFFFFFF
+        else:
+            order = list(self.profile_get().keys())
+            mask = 0
+            for n in names:
+                mask |= 1 << order.index(n)
+        self.check(self._L.wayne_profile_select(self._h, mask))
 
     def profile_reset(self):
         self.check(self._L.wayne_profile_reset(self._h))

@@ -143,6 +143,7 @@ struct wayne_ctx {
   DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
   // profiling
   bool prof_on = false;
+  unsigned prof_mask = ~0u;   // kernels timed while prof_on (wayne_profile_select)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   uint64_t prof_launches[WAYNE_PROF_KERNELS] = {0};
@@ -180,7 +181,7 @@ struct ProfScope {
   wayne_ctx* c;
   ProfRec rec{};
   bool on;
-  ProfScope(wayne_ctx* c_, int kernel) : c(c_), on(c_->prof_on) {
+  ProfScope(wayne_ctx* c_, int kernel) : c(c_), on(c_->prof_on && ((c_->prof_mask >> kernel) & 1u)) {
     if (!on) return;
     rec.kernel = kernel;
     rec.a = get_event(c);
@@ -1196,6 +1197,12 @@ int wayne_exposure_debug_depth(wayne_ctx* c, int slot, double* depth) {
 int wayne_profile_enable(wayne_ctx* c, int on) {
   if (!c) return WAYNE_E_INVALID;
   c->prof_on = on != 0;
+  return WAYNE_OK;
+}
+
+int wayne_profile_select(wayne_ctx* c, unsigned mask) {
+  if (!c) return WAYNE_E_INVALID;
+  c->prof_mask = mask;
   return WAYNE_OK;
 }
 
