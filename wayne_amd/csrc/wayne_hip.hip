@@ -67,6 +67,11 @@ struct Slot {
   hipEvent_t sky_tab_ev = nullptr;
   bool sky_tab_pending = false;
   std::vector<uint32_t> sky_tab_keys;
+  bool sky_alias_on = false, sky_pieces = false;
+  uint32_t sky_mask = 0;
+  int sky_L = 1;
+  float sky_level[16] = {0};
+  unsigned char sky_tab0[16] = {0};
   std::vector<double> read_dt_host;
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
@@ -328,6 +333,85 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d) {
     total += cnt;
   }
   return total;
+}
+
+// Plan the sky draws of an exposure (k_ramp, sky_draw): levels of the master sky, one alias table of
+// Poisson(level * bg_count) per level and distinct read interval, uploaded on the slot's stream with
+// the descriptor -- long before k_ramp needs them.
+int prepare_sky_tables(wayne_ctx* c, Slot& s) {
+  const wayne_exposure_desc& d = s.d;
+  s.sky_pieces = false; s.sky_alias_on = false; s.sky_mask = 0; s.sky_L = 1;
+  for (float& l_ : s.sky_level) l_ = c->sky_min;
+  std::memset(s.sky_tab0, 0, sizeof s.sky_tab0);
+  if (d.sky_ct_s > 0. && c->has_sky && c->sky_max > 0.f) {
+    // distinct read intervals (float32 bg_count, as the kernel and numpy use it, :489-493) -> L levels each
+    std::vector<float> bg;            // distinct bg_count values, first-appearance order
+    std::vector<int> bg_of((size_t)s.R);
+    for (int r = 0; r < s.R; ++r) {
+      const float b = (float)(d.sky_ct_s * s.read_dt_host[r]);
+      size_t j = 0;
+      while (j < bg.size() && std::memcmp(&bg[j], &b, 4) != 0) ++j;
+      if (j == bg.size()) bg.push_back(b);
+      bg_of[r] = (int)j;
+    }
+    const int L = std::max(1, std::min(kMaxReads / (int)bg.size(), kMaxReads));
+    // levels = the l/L quantiles of the positive sky pixels (actual pixel values, [0] = the minimum): most
+    // pixels sit just above their level, so their own remainder is a fraction of an electron
+    float levels[16];
+    for (int l = 0; l < 16; ++l) levels[l] = c->sky_max;
+    for (int l = 0; l < L; ++l) levels[l] = c->sky_sorted[(size_t)l * c->sky_sorted.size() / (size_t)L];
+    std::vector<uint32_t> keys(bg.size() * (size_t)L, 0u);
+    std::vector<char> fits(bg.size(), 1);
+    for (size_t j = 0; j < bg.size(); ++j)
+      for (int l = 0; l < L; ++l) {
+        const float level = levels[l];
+        const float lam = level * bg[j];
+        if (!sky_alias_fits((double)lam)) fits[j] = 0;
+        std::memcpy(&keys[j * L + l], &lam, 4);
+      }
+    uint32_t mask = 0;
+    for (int r = 0; r < s.R; ++r) {
+      if (fits[bg_of[r]]) mask |= 1u << r;
+      s.sky_tab0[r] = (unsigned char)(bg_of[r] * L);
+    }
+    if (mask == (1u << s.R) - 1u) {     // every read fits its tables; otherwise the exposure takes the direct sampler
+      if (keys != s.sky_tab_keys || !s.sky_tab.p) {
+        const size_t bytes = (size_t)kMaxReads * kSkyAlias * sizeof(uint32_t);
+        HIP_TRY(c, s.sky_tab.reserve(bytes));
+        if (!s.sky_tab_host && hipHostMalloc((void**)&s.sky_tab_host, bytes, hipHostMallocDefault) != hipSuccess)
+          return fail(c, WAYNE_E_NOMEM, "upload: pinned allocation for the sky tables failed");
+        if (!s.sky_tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.sky_tab_ev, hipEventDisableTiming));
+        if (s.sky_tab_pending) { HIP_TRY(c, hipEventSynchronize(s.sky_tab_ev)); s.sky_tab_pending = false; }
+        std::memset(s.sky_tab_host, 0, bytes);
+        for (size_t t = 0; t < keys.size(); ++t) {
+          if (!fits[t / L]) continue;
+          auto it = c->alias_cache.find(keys[t]);
+          if (it == c->alias_cache.end()) {
+            float lam;
+            std::memcpy(&lam, &keys[t], 4);
+            if (c->alias_cache.size() > 4096) c->alias_cache.clear();
+            it = c->alias_cache.emplace(keys[t], build_sky_alias((double)lam)).first;
+          }
+          std::memcpy(s.sky_tab_host + t * kSkyAlias, it->second.data(), kSkyAlias * sizeof(uint32_t));
+        }
+        HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
+        s.sky_tab_pending = true;
+        s.sky_tab_keys = keys;
+      }
+      s.sky_alias_on = true;
+      s.sky_mask = mask;
+      s.sky_L = L;
+      for (int l = 0; l < 16; ++l) s.sky_level[l] = levels[l];
+      // largest remainder any pixel can have: the widest gap between levels (the top one reaches sky_max)
+      float gap = c->sky_max - levels[L - 1];
+      for (int l = 0; l + 1 < L; ++l) gap = std::max(gap, levels[l + 1] - levels[l]);
+      float bg_max = 0.f;
+      for (float b : bg) bg_max = std::max(bg_max, b);
+      s.sky_pieces = !(gap * bg_max <= kSkyPiece);
+    }
+  }
+  return WAYNE_OK;
 }
 
 int side_of(int subarray) { return subarray == 1024 ? 1014 : subarray; }  // detector.py:116-119
@@ -787,6 +871,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   s.est_thrown = estimate_thrown(c, d);
+  if ((rc = prepare_sky_tables(c, s))) return rc;
   s.uploaded = true;
   s.front_done = false;
   return WAYNE_OK;
@@ -987,78 +1072,12 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_GAIN_VARIATIONS) && !c->has_pfl) return fail(c, WAYNE_E_STATE, "run: add_gain_variations without a pixel flat");
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
-  bool sky_pieces = false;
-  a.sky_alias = nullptr; a.alias_mask = 0; a.sky_levels = 1;
-  for (float& l_ : a.sky_level) l_ = c->sky_min;
-  std::memset(a.sky_tab0, 0, sizeof a.sky_tab0);
-  if (d.sky_ct_s > 0. && c->has_sky && c->sky_max > 0.f) {
-    // distinct read intervals (float32 bg_count, as the kernel and numpy use it, :489-493) -> L levels each
-    std::vector<float> bg;            // distinct bg_count values, first-appearance order
-    std::vector<int> bg_of((size_t)s.R);
-    for (int r = 0; r < s.R; ++r) {
-      const float b = (float)(d.sky_ct_s * s.read_dt_host[r]);
-      size_t j = 0;
-      while (j < bg.size() && std::memcmp(&bg[j], &b, 4) != 0) ++j;
-      if (j == bg.size()) bg.push_back(b);
-      bg_of[r] = (int)j;
-    }
-    const int L = std::max(1, std::min(kMaxReads / (int)bg.size(), kMaxReads));
-    // levels = the l/L quantiles of the positive sky pixels (actual pixel values, [0] = the minimum): most
-    // pixels sit just above their level, so their own remainder is a fraction of an electron
-    float levels[16];
-    for (int l = 0; l < 16; ++l) levels[l] = c->sky_max;
-    for (int l = 0; l < L; ++l) levels[l] = c->sky_sorted[(size_t)l * c->sky_sorted.size() / (size_t)L];
-    std::vector<uint32_t> keys(bg.size() * (size_t)L, 0u);
-    std::vector<char> fits(bg.size(), 1);
-    for (size_t j = 0; j < bg.size(); ++j)
-      for (int l = 0; l < L; ++l) {
-        const float level = levels[l];
-        const float lam = level * bg[j];
-        if (!sky_alias_fits((double)lam)) fits[j] = 0;
-        std::memcpy(&keys[j * L + l], &lam, 4);
-      }
-    uint32_t mask = 0;
-    for (int r = 0; r < s.R; ++r) {
-      if (fits[bg_of[r]]) mask |= 1u << r;
-      a.sky_tab0[r] = (unsigned char)(bg_of[r] * L);
-    }
-    if (mask == (1u << s.R) - 1u) {     // every read fits its tables; otherwise the exposure takes the direct sampler
-      if (keys != s.sky_tab_keys || !s.sky_tab.p) {
-        const size_t bytes = (size_t)kMaxReads * kSkyAlias * sizeof(uint32_t);
-        HIP_TRY(c, s.sky_tab.reserve(bytes));
-        if (!s.sky_tab_host && hipHostMalloc((void**)&s.sky_tab_host, bytes, hipHostMallocDefault) != hipSuccess)
-          return fail(c, WAYNE_E_NOMEM, "run: pinned allocation for the sky tables failed");
-        if (!s.sky_tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.sky_tab_ev, hipEventDisableTiming));
-        if (s.sky_tab_pending) { HIP_TRY(c, hipEventSynchronize(s.sky_tab_ev)); s.sky_tab_pending = false; }
-        std::memset(s.sky_tab_host, 0, bytes);
-        for (size_t t = 0; t < keys.size(); ++t) {
-          if (!fits[t / L]) continue;
-          auto it = c->alias_cache.find(keys[t]);
-          if (it == c->alias_cache.end()) {
-            float lam;
-            std::memcpy(&lam, &keys[t], 4);
-            if (c->alias_cache.size() > 4096) c->alias_cache.clear();
-            it = c->alias_cache.emplace(keys[t], build_sky_alias((double)lam)).first;
-          }
-          std::memcpy(s.sky_tab_host + t * kSkyAlias, it->second.data(), kSkyAlias * sizeof(uint32_t));
-        }
-        HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
-        s.sky_tab_pending = true;
-        s.sky_tab_keys = keys;
-      }
-      a.sky_alias = s.sky_tab.as<uint32_t>();
-      a.alias_mask = mask;
-      a.sky_levels = L;
-      for (int l = 0; l < 16; ++l) a.sky_level[l] = levels[l];
-      // largest remainder any pixel can have: the widest gap between levels (the top one reaches sky_max)
-      float gap = c->sky_max - levels[L - 1];
-      for (int l = 0; l + 1 < L; ++l) gap = std::max(gap, levels[l + 1] - levels[l]);
-      float bg_max = 0.f;
-      for (float b : bg) bg_max = std::max(bg_max, b);
-      sky_pieces = !(gap * bg_max <= kSkyPiece);
-    }
-  }
+  // sky tables were planned and uploaded with the descriptor (prepare_sky_tables)
+  bool sky_pieces = s.sky_pieces;
+  a.sky_alias = s.sky_alias_on ? s.sky_tab.as<uint32_t>() : nullptr;
+  a.alias_mask = s.sky_alias_on ? s.sky_mask : 0u;
+  a.sky_levels = s.sky_L;
+  for (int l = 0; l < 16; ++l) { a.sky_level[l] = s.sky_level[l]; a.sky_tab0[l] = s.sky_tab0[l]; }
   const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
