@@ -3,6 +3,7 @@
 #include "../../include/wayne_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -194,9 +195,21 @@ struct ProfScope {
     if (!rec.a || !rec.b) { on = false; return; }
     (void)hipEventRecord(rec.a, c->stream);
   }
+  // For a single launch through hipExtLaunchKernel: the events then carry the kernel's own start and stop
+  // times (no marker packets before and after it in the stream).
+  ProfScope(wayne_ctx* c_, int kernel, bool ext_launch) : c(c_), on(c_->prof_on && ((c_->prof_mask >> kernel) & 1u)) {
+    if (!on) return;
+    rec.kernel = kernel;
+    rec.a = get_event(c);
+    rec.b = get_event(c);
+    if (!rec.a || !rec.b) { on = false; return; }
+    ext = ext_launch;
+    if (!ext) (void)hipEventRecord(rec.a, c->stream);
+  }
+  bool ext = false;
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(rec.b, c->stream);
+    if (!ext) (void)hipEventRecord(rec.b, c->stream);
     c->prof.push_back(rec);
   }
 };
@@ -1081,7 +1094,7 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
-    ProfScope ps(c, PK_RAMP);
+    ProfScope ps(c, PK_RAMP, true);
     const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
     const int sky_mode = a.sky_alias == nullptr ? 0 : (sky_pieces ? 2 : 1);
     void (*kern)(RampArgs) =
@@ -1091,7 +1104,8 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
                                : (exact ? k_ramp<float, false, 2> : k_ramp<float, true, 2>))
                         : (f64 ? (exact ? k_ramp<double, false, 0> : k_ramp<double, true, 0>)
                                : (exact ? k_ramp<float, false, 0> : k_ramp<float, true, 0>));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
+    if (ps.on) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, ps.rec.a, ps.rec.b, 0, a);
+    else hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
   s.acc_dirty = false;
