@@ -70,8 +70,11 @@ __device__ __forceinline__ double poly3(const double* c, double x) {
 // ---------------------------------------------------------------------------
 // k_prep_wl : A8 + the wavelength-only part of A9
 // ---------------------------------------------------------------------------
-__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o) {
+__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o, uint32_t* misc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the exposure's status words (total electrons, overflow flag) start from zero: cleared here, by the
+  // first kernel of the exposure, instead of by a separate fill in front of it
+  if (i < 16) misc[i] = 0u;
   if (i >= W) return;
   const double x = wl[i];
   o.ratio[i] = poly3(g.p_ratio, x);

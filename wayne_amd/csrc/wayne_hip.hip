@@ -904,8 +904,6 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
     s.acc_dirty = false;
   }
-  HIP_TRY(c, hipMemsetAsync(s.misc.p, 0, 64, c->stream));
-
   if (s.has_lc) {
     LcArgs a{};
     a.K = K; a.W = W;
@@ -934,7 +932,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   {
     ProfScope ps(c, PK_PREP_WL);
     hipLaunchKernelGGL(k_prep_wl, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->g, W,
-                       s.wl.as<double>(), wa);
+                       s.wl.as<double>(), wa, s.misc.as<uint32_t>());
     HIP_TRY(c, hipGetLastError());
   }
   const int margin = d.thrower_margin > 0 ? d.thrower_margin : 24;   // ~4 sigma_h: sweep in scripts/sweep_throw.py
