@@ -29,13 +29,16 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     for j in range(2):
         ctx.run(2 * j)
     ctx.synchronize()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
     t0 = time.perf_counter()
     for j in range(2, n + 2):
         ctx.run(2 * j)
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    # kernel times from a second pass (HIP events around every kernel cost a few per cent of throughput)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for j in range(2, n + 2):
+        ctx.run(2 * j)
     p = ctx.profile_get()
     ctx.profile_enable(False)
     # delivered: the visit runner (host prep + upload + kernels + download), exposures returned as numpy arrays
