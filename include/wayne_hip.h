@@ -188,7 +188,9 @@ typedef struct wayne_exposure_desc {
   double noise_std;
 
   int thrower_margin; /* LDS tile margin in px around the trace; 0 = default   */
-  int thrower_splits; /* workgroups per sub-sample; 0 = auto                   */
+  int thrower_splits; /* thrower workgroups launched per sub-sample (an upper bound: the kernel
+                         shares the electrons it finds among as many as it needs); 0 = sized
+                         from the host's estimate of the electron count           */
 
   /* Device light curves (replaces the W pylightcurve calls per exposure of
    * Observation.generate_lightcurves, observation.py:293-357).  When lc_z is
