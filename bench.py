@@ -174,17 +174,17 @@ def main():
     gr = grism.G141(cal) if cfg["grism"] == "G141" else grism.G102(cal)
     total = args.warmup + args.steps
     # exposure j of this rank is exposure index rank + j * n_gpus of the visit (round-robin)
-    visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=total * n_gpus)
+    visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=min(total, 120) * n_gpus)
     eng = engine.get_engine(device, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
     ctx = eng.ctx
-    if total > 125:
-        raise SystemExit("at most 125 exposures (HBM slots) per rank per run")
+    # exposures resident in HBM: one slot each, at most 120 (26 GB); a longer run cycles through them again
+    n_res = min(total, 120)
 
     from wayne_amd.exposure_generator import ExposureGenerator
     out_dtype = np.float64 if args.out_f64 else np.float32
     rng_mode = _lib.RNG_SPLIT if args.thrower == "split" else _lib.RNG_PHILOX
     W = None
-    for j in range(total):
+    for j in range(n_res):
         i = rank + j * n_gpus
         eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                device=device, seed=visit.seed, exposure_index=i)
@@ -203,7 +203,7 @@ def main():
     stride = 1 if args.streams == 2 else 2
 
     def slot_of(j):
-        return j * stride
+        return (j % n_res) * stride
 
     for j in range(args.warmup):
         ctx.run(slot_of(j))
@@ -241,24 +241,24 @@ def main():
     # (prep / ramp of one exposure co-run with the thrower of another)
     two = None
     if args.streams == 1 and n_gpus == 1 and not args.no_extra_pass:
-        for j in range(total):
+        for j in range(n_res):
             ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
                                             device=device, seed=visit.seed, exposure_index=rank + j * n_gpus
                                             ).build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode,
                                                                **visit.frame_kwargs(rank + j * n_gpus)))
         for j in range(args.warmup):
-            ctx.run(j)
+            ctx.run(j % n_res)
         sync_all()
         t1 = time.perf_counter()
         for j in range(args.warmup, total):
-            ctx.run(j)
+            ctx.run(j % n_res)
         ctx.synchronize()
         torch.cuda.synchronize()
         two = args.steps / (time.perf_counter() - t1)
         stride = 1
 
     # sanity: the last exposure really produced a frame
-    reads = ctx.download(slot_of(total - 1) if two is None else total - 1)
+    reads = ctx.download(slot_of(total - 1) if two is None else (total - 1) % n_res)
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
 
     if rank == 0:
