@@ -136,6 +136,34 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_staring_mode_visit(tmp_path):
+    # spatial_scan: False -> staring frames (one sub-sample per read) through the same pipelined driver
+    import shutil
+    import yaml
+    work = str(tmp_path / "stare")
+    shutil.copytree(MINI, work)
+    pfile = os.path.join(work, "params.yml")
+    cfg = yaml.safe_load(open(pfile))
+    cfg["observation"]["spatial_scan"] = False
+    cfg["observation"]["ssv_type"] = False
+    yaml.safe_dump(cfg, open(pfile, "w"))
+    obs = run_visit.run(["-p", pfile, "--max-exposures", "2"])
+    files = sorted(f for f in os.listdir(obs.outdir) if f.endswith("_raw.fits"))
+    assert files == ["0001_raw.fits", "0002_raw.fits"]
+    h = fitsio.read(os.path.join(obs.outdir, "0001_raw.fits"))
+    assert h[0].header["SCAN"] is True      # as the reference: staring_frame never resets exp_info (exposure_generator.py:162)
+    sci = [x for x in h if x.name == "SCI"]
+    assert len(sci) == 4
+    last = sci[0].data - sci[-1].data
+    # a staring spectrum: the flux sits in a few rows about the trace instead of a scanned band
+    rows = last.sum(axis=1)
+    assert rows.max() > 0 and (rows > 0.05 * rows.max()).sum() < 30
+    # same exposure generated directly, unpipelined: identical
+    frame = obs._generate_exposure(obs.exp_start_times[0], 1, write_fits=False)
+    np.testing.assert_array_equal(np.asarray(frame.reads[3][0], dtype=np.float64), sci[0].data)
+
+
+@pytest.mark.gpu
 def test_pipelined_visit_runner_matches_direct_calls(tmp_path):
     import helpers
     from wayne_amd import visit as wv
