@@ -164,6 +164,26 @@ def test_cli_staring_mode_visit(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_g102_visit(tmp_path):
+    import shutil
+    import yaml
+    work = str(tmp_path / "g102")
+    shutil.copytree(MINI, work)
+    pfile = os.path.join(work, "params.yml")
+    cfg = yaml.safe_load(open(pfile))
+    cfg["observation"]["grism"] = "G102"
+    yaml.safe_dump(cfg, open(pfile, "w"))
+    obs = run_visit.run(["-p", pfile, "--max-exposures", "2"])
+    assert obs.grism.name == "G102"
+    h = fitsio.read(os.path.join(obs.outdir, "0002_raw.fits"))
+    sci = [x for x in h if x.name == "SCI"]
+    flux = (sci[0].data - sci[-1].data)[5:-5, 5:-5]
+    assert flux.sum() > 1e4                                   # the 0.8-1.15 micron spectrum landed on the sub-array
+    cols = np.nonzero(flux.sum(axis=0) > 0.02 * flux.sum(axis=0).max())[0]
+    assert cols.size > 20
+
+
+@pytest.mark.gpu
 def test_pipelined_visit_runner_matches_direct_calls(tmp_path):
     import helpers
     from wayne_amd import visit as wv
