@@ -107,3 +107,37 @@ def test_device_depth_matrix_matches_numpy(gpu_ctx):
                                                   **dict(kw, planet_signal=dd.host_matrix(), **off)).reads])
     assert np.abs(a - b).max() < 0.5     # counts may round differently for a handful of bins (depth differs by 1e-9)
     assert np.median(np.abs(a - b)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_depths_interpolated_in_radius_ratio(gpu_ctx):
+    # a realistic spectrum: radius ratios within 1 % of each other, every z regime (no transit, contacts,
+    # planet inside the disk, over the centre): the device interpolates the quadrature in p and must
+    # stay within its usual 2e-8 of the numpy model for every wavelength
+    import helpers
+    from wayne_amd import engine, tools
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0)
+    K = len(v.sample_mid_points)
+    rp0 = np.sqrt(v.depth0.mean())
+    z_tr = np.array([1.5, 1.0 + rp0 * 1.0001, 1.0 + rp0 * 0.5, 1.0, 1.0 - rp0 * 0.9999, 0.6, rp0 * 1.0002, rp0 * 0.3, 0.0])
+    assert K == z_tr.size
+    spec = v.depth0 * (1 + 0.004 * np.sin(np.arange(v.depth0.size) / 300.0))
+    dd = lc.DeviceDepths(z_tr, np.zeros(K), spec, LD)
+    pg = helpers.product_generator(v, 0)
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    eng.ctx.upload(0, pg.build_descriptor(eng, **dict(kw, planet_signal=dd)))
+    eng.ctx.run_front(0)
+    got = eng.ctx.debug_depth(0)
+    eng.ctx.run_back(0)
+    i0, i1 = tools.crop_spectrum_ind(v.grism.wl_limits[0], v.grism.wl_limits[1], v.wl)
+    want = dd.host_matrix()[:, i0:i1]
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-8)
+    assert got[0].max() == 0.0 and got[5].min() > 0.01
+    # a flat spectrum (one radius ratio for all wavelengths) takes the single-evaluation path
+    flat = lc.DeviceDepths(z_tr, np.zeros(K), np.full_like(v.depth0, 0.0146), LD)
+    eng.ctx.upload(0, pg.build_descriptor(eng, **dict(kw, planet_signal=flat)))
+    eng.ctx.run_front(0)
+    got = eng.ctx.debug_depth(0)
+    eng.ctx.run_back(0)
+    np.testing.assert_allclose(got, flat.host_matrix()[:, i0:i1], rtol=0, atol=2e-8)

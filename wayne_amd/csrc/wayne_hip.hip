@@ -74,6 +74,7 @@ struct Slot {
   float sky_level[16] = {0};
   unsigned char sky_tab0[16] = {0};
   std::vector<double> read_dt_host;
+  double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
@@ -835,6 +836,8 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     if (!d->lc_rp) return fail(c, WAYNE_E_INVALID, "upload: lc_z needs lc_rp");
     if ((rc = upload_staged(c, s, s.lc_z, d->lc_z, (size_t)K))) return rc;
     if ((rc = upload_staged(c, s, s.lc_rp, d->lc_rp, (size_t)W))) return rc;
+    s.lc_p_lo = s.lc_p_hi = d->lc_rp[0];
+    for (int i = 1; i < W; ++i) { s.lc_p_lo = std::min(s.lc_p_lo, d->lc_rp[i]); s.lc_p_hi = std::max(s.lc_p_hi, d->lc_rp[i]); }
     s.has_lc_hidden = d->lc_hidden != nullptr;
     if (s.has_lc_hidden && (rc = upload_staged(c, s, s.lc_hidden, d->lc_hidden, (size_t)K))) return rc;
     HIP_TRY(c, s.depth.reserve(KW * sizeof(double)));
@@ -921,9 +924,10 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       a.w[i] = (float)(h * 0.25 * kPi * std::cosh(t) / (std::cosh(u) * std::cosh(u)));
       a.d[i] = (float)(0.5 * std::exp(-std::fabs(u)) / std::cosh(u));
     }
+    a.p_lo = s.lc_p_lo; a.p_hi = s.lc_p_hi;
     a.depth = s.depth.as<double>();
     ProfScope ps(c, PK_LIGHTCURVE);
-    hipLaunchKernelGGL(k_lightcurve, dim3((W + 255) / 256, K), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_lightcurve, dim3(K), dim3(256), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
 
