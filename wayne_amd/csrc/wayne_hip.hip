@@ -28,7 +28,9 @@ const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub", "
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool owns = true;        // false: a view into another allocation (the slot's input arena)
   hipError_t reserve(size_t bytes) {
+    if (!owns) { p = nullptr; cap = 0; owns = true; }
     if (bytes <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -38,10 +40,17 @@ struct DevBuf {
     if (e == hipSuccess) cap = bytes;
     return e;
   }
+  void view(void* at) {
+    if (owns && p) (void)hipFree(p);
+    p = at;
+    cap = 0;
+    owns = false;
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owns) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    owns = true;
   }
   template <class T> T* as() const { return (T*)p; }
 };
@@ -54,10 +63,11 @@ struct Slot {
   wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
   int W = 0, K = 0, R = 0;
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
-  DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;
+  DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;   // views into in_dev (depth: owned when computed by k_lightcurve)
   DevBuf ratio, sigl, sigh, sens, dlam;
   DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
+  DevBuf in_dev;          // device mirror of the staging arena: the descriptor's arrays arrive in ONE copy
   void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait), followed by a copy of `misc`
   size_t pinned_cap = 0;
   struct Misc { unsigned long long electrons; int status; int pad; };
@@ -85,7 +95,7 @@ struct Slot {
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
-                      &misc, &sky_tab})
+                      &misc, &sky_tab, &in_dev})
       b->release();
     if (sky_tab_host) (void)hipHostFree(sky_tab_host);
     sky_tab_host = nullptr;
@@ -300,14 +310,11 @@ std::vector<uint32_t> build_sky_alias(double lam) {
 // Copy `n` elements into the slot's pinned arena and enqueue the host-to-device copy from there.
 template <class T>
 int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
-  HIP_TRY(c, b.reserve(std::max<size_t>(n, 1) * sizeof(T)));
-  if (!n) return WAYNE_OK;
-  const size_t bytes = n * sizeof(T);
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
   if (s.stage_used + bytes > s.stage_cap) return fail(c, WAYNE_E_NOMEM, "upload: staging arena too small");
-  char* at = s.stage + s.stage_used;
-  std::memcpy(at, src, bytes);
+  if (n) std::memcpy(s.stage + s.stage_used, src, n * sizeof(T));
+  b.view((char*)s.in_dev.p + s.stage_used);      // same offset in the device mirror (copied in one piece)
   s.stage_used += align64(bytes);
-  HIP_TRY(c, hipMemcpyAsync(b.p, at, bytes, hipMemcpyHostToDevice, c->stream));
   return WAYNE_OK;
 }
 
@@ -810,7 +817,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   const size_t KW = (size_t)K * W;
   {
     // staging arena: every array of the descriptor, 64-byte aligned
-    size_t need = 2 * align64((size_t)W * 8) + 3 * align64((size_t)K * 8) + 2 * align64((size_t)K * 4) + align64((size_t)R * 8);
+    size_t need = 2 * align64((size_t)W * 8) + 3 * align64((size_t)K * 8) + 2 * align64((size_t)K * 4) + align64((size_t)R * 8) + 1024;
     if (d->lc_z) need += 2 * align64((size_t)K * 8) + align64((size_t)W * 8);
     if (d->depth) need += align64(KW * 8);
     if (s.stage_pending) {           // the previous upload of this slot may still be reading the arena
@@ -827,6 +834,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     }
     if (!s.stage_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_ev, hipEventDisableTiming));
     s.stage_used = 0;
+    HIP_TRY(c, s.in_dev.reserve(s.stage_cap));
   }
   if ((rc = upload_staged(c, s, s.wl, d->wl_um, (size_t)W))) return rc;
   if ((rc = upload_staged(c, s, s.flux, d->flux, (size_t)W))) return rc;
@@ -851,6 +859,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   if (s.has_replay_seed && (rc = upload_staged(c, s, s.rseed, d->replay_seed, (size_t)K))) return rc;
   if ((rc = upload_staged(c, s, s.sread, d->sample_read, (size_t)K))) return rc;
   if ((rc = upload_staged(c, s, s.read_dt, d->read_dt_s, (size_t)R))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(s.in_dev.p, s.stage, s.stage_used, hipMemcpyHostToDevice, c->stream));   // one copy for all arrays
   HIP_TRY(c, hipEventRecord(s.stage_ev, c->stream));
   s.stage_pending = true;
   for (DevBuf* b : {&s.ratio, &s.sigl, &s.sigh, &s.sens, &s.dlam}) HIP_TRY(c, b->reserve((size_t)W * sizeof(double)));
