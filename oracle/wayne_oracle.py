@@ -768,7 +768,7 @@ class SSVSine(object):
         return sample_durations * ssv_scaling
 
 
-def from_calibration(cal, grism_name, NSAMP, SAMPSEQ, SUBARRAY):
+def from_calibration(cal, grism_name, NSAMP, SAMPSEQ, SUBARRAY, g102_flat_quirk=False):
     """Build (Detector, Grism, ExposureOracle) over the arrays of a calibration
     set (any object with .flat/.flat_wl/.sky/.sens/.pfl/.lin/.bias_256 and
     .dark_frames(), e.g. wayne_amd.calibration.CalibrationSet -- data only)."""
@@ -779,8 +779,11 @@ def from_calibration(cal, grism_name, NSAMP, SAMPSEQ, SUBARRAY):
     except BaseException as e:  # no super-dark for the mode
         if type(e).__name__ != "WFC3SimNoDarkFileError":
             raise
-    wmin, wmax = cal.flat_wl.get(grism_name, (0., 1.))
+    # the reference's G102 keeps the flat cube (and WMIN / WMAX) that G141.__init__ loaded (grism.py:428,
+    # :66-76; only the path attribute is overridden, :453-454): reproduced when g102_flat_quirk is set
+    flat_name = "G141" if (g102_flat_quirk and grism_name == "G102") else grism_name
+    wmin, wmax = cal.flat_wl.get(flat_name, (0., 1.))
     sw, sv = cal.sens[grism_name]
-    gr = Grism(grism_name, flat=cal.flat.get(grism_name), flat_wmin=wmin, flat_wmax=wmax,
+    gr = Grism(grism_name, flat=cal.flat.get(flat_name), flat_wmin=wmin, flat_wmax=wmax,
                sky=cal.sky.get(grism_name), sens_wl=sw, sens_val=sv)
     return det, gr, ExposureOracle(det, gr, NSAMP, SAMPSEQ, SUBARRAY)

@@ -98,6 +98,25 @@ def test_reference_quirk_switch_at_1024():
     assert abs(cb - ca - 5.0) < 0.3
 
 
+def test_g102_flat_quirk_switch():
+    # reference_quirks=True flat-fields a G102 exposure with the G141 cube, as the reference does
+    # (grism.py:428,453-454); the default uses the G102 cube.  Each against the oracle built the same way.
+    v = helpers.make_visit("tiny_g102")
+    kw = v.frame_kwargs(0, add_stellar_noise=False, sky_background=0.0, cosmic_rate=None, add_dark=False,
+                        add_read_noise=False)
+    pg = helpers.product_generator(v, 0)
+    frames = {}
+    for quirk in (False, True):
+        got = np.stack([r[0] for r in pg.scanning_frame(threads=2, rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                        reference_quirks=quirk, **kw).reads])
+        det, gr, eo = wo.from_calibration(v.calibration, "G102", v.NSAMP, v.SAMPSEQ, v.SUBARRAY, g102_flat_quirk=quirk)
+        want = np.stack(eo.scanning_frame(threads=2, draws=wo.PhiloxDraws(v.seed, 0, 64), thrower="oracle",
+                                          reference_quirks=quirk, **helpers.oracle_kwargs(kw)))
+        assert np.abs(got - want).max() < 1e-4
+        frames[quirk] = got
+    assert np.abs(frames[True] - frames[False]).max() > 1e-3      # the two cubes differ
+
+
 def test_abi_error_paths():
     v = helpers.make_visit("tiny")
     eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)

@@ -127,13 +127,16 @@ class CalibrationSet(object):
         return sci, err
 
     def for_mode(self, grism, subarray, sampseq, read_times, add_initial_bias=True, detector=None,
-                 with_dark=True):
-        """Planes centre-cropped to the sub-array, as Context.set_calibration takes them."""
+                 with_dark=True, flat_grism=None):
+        """Planes centre-cropped to the sub-array, as Context.set_calibration takes them.
+        `flat_grism`: take the flat cube of another grism (the reference flat-fields G102 exposures with
+        the G141 cube, grism.py:428,453-454 -- `reference_quirks`)."""
         N = 1014 if subarray == 1024 else subarray
         S = N + 10
         out = {"subarray": subarray, "n_reads": len(read_times)}
-        if grism in self.flat:
-            out["flat"] = [np.ascontiguousarray(crop_central_box(p, N)) for p in self.flat[grism]]   # grism.py:406-407
+        fg = flat_grism or grism
+        if fg in self.flat:
+            out["flat"] = [np.ascontiguousarray(crop_central_box(p, N)) for p in self.flat[fg]]      # grism.py:406-407
         if self.pfl is not None:
             out["pfl"] = np.ascontiguousarray(crop_central_box(self.pfl, N))                          # detector.py:206-207
         if grism in self.sky:

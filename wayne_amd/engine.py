@@ -14,19 +14,22 @@ _engines = {}
 
 class Engine(object):
     def __init__(self, device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY,
-                 add_initial_bias=True):
+                 add_initial_bias=True, g102_flat_quirk=False):
         self.device = device
         self.grism, self.detector, self.calibration = grism, detector, calibration
         self.NSAMP, self.SAMPSEQ, self.SUBARRAY = NSAMP, SAMPSEQ, SUBARRAY
         self.read_times = detector.get_read_times(NSAMP, SUBARRAY, SAMPSEQ)    # seconds
         self.ctx = _lib.Context(device)
         sens_wl, sens_val = calibration.sensitivity(grism.name)
-        wmin, wmax = calibration.flat_wl.get(grism.name, (0.0, 1.0))
+        # the reference's G102 inherits the G141 flat cube and its WMIN / WMAX (grism.py:428: G102.__init__
+        # calls G141.__init__, which loads them; only the *path* is overridden afterwards, :453-454)
+        flat_grism = "G141" if (g102_flat_quirk and grism.name == "G102") else grism.name
+        wmin, wmax = calibration.flat_wl.get(flat_grism, (0.0, 1.0))
         self.ctx.set_grism(grism.trace_coeff, grism.wl_solution, grism.psf_ratio_poly.coeffs,
                            grism.psf_sigmal_poly.coeffs, grism.psf_sigmah_poly.coeffs,
                            sens_wl, sens_val, wmin, wmax)
         planes = calibration.for_mode(grism.name, SUBARRAY, SAMPSEQ, self.read_times,
-                                      add_initial_bias=add_initial_bias, detector=detector)
+                                      add_initial_bias=add_initial_bias, detector=detector, flat_grism=flat_grism)
         self.has_dark = "dark_sci" in planes
         self.ctx.set_calibration(planes["subarray"], planes["n_reads"], flat=planes.get("flat"),
                                  pfl=planes.get("pfl"), sky=planes.get("sky"), lin=planes.get("lin"),
@@ -38,12 +41,14 @@ class Engine(object):
         self.ctx.close()
 
 
-def get_engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias=True):
+def get_engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias=True,
+               g102_flat_quirk=False):
     """Cached engine per (device, grism, mode, calibration object)."""
-    key = (device, grism.name, NSAMP, SAMPSEQ, SUBARRAY, id(calibration), bool(add_initial_bias))
+    quirk = bool(g102_flat_quirk) and grism.name == "G102"
+    key = (device, grism.name, NSAMP, SAMPSEQ, SUBARRAY, id(calibration), bool(add_initial_bias), quirk)
     eng = _engines.get(key)
     if eng is None:
-        eng = Engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias)
+        eng = Engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias, quirk)
         _engines[key] = eng
     return eng
 

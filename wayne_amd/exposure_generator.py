@@ -117,7 +117,8 @@ class ExposureGenerator(object):
         thrown), or RNG_REPLAY (the reference's rand_r streams in the thrower,
         with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` float32 or
         float64 reads; `reference_quirks` keeps the reference's -5 px frame
-        offset at SUBARRAY=1024 (exposure_generator.py:630); `record`, if a dict,
+        offset at SUBARRAY=1024 (exposure_generator.py:630) and flat-fields G102 exposures with the
+        G141 cube as the reference does (grism.py:428,453-454); `record`, if a dict,
         receives the device's intermediate products (counts, x, y per bin and
         sub-sample; electrons accumulated per read interval) for parity tests;
         `exact_samplers` evaluates the per-pixel Poisson / normal draws with IEEE
@@ -127,7 +128,7 @@ class ExposureGenerator(object):
         start_time = time.time()
         slot = self._submit_slot
         eng = _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP,
-                                 self.SAMPSEQ, self.SUBARRAY, add_initial_bias)
+                                 self.SAMPSEQ, self.SUBARRAY, add_initial_bias, g102_flat_quirk=reference_quirks)
         desc = self.build_descriptor(
             eng, x_ref, y_ref, x_jitter, y_jitter, wl, stellar_flux, planet_signal, scan_speed, sample_rate,
             sample_mid_points, sample_durations, read_index, ssv_generator, noise_mean, noise_std, add_dark,
