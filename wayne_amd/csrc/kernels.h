@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
 //   (detector.py:146-147).  Integer atomics commute, so the result is
 //   bit-reproducible for any launch geometry.
 constexpr int kThrowThreads = 512;
-constexpr int kThrowPCache = 512;       // bins of a workgroup's slice whose prefix / parameters are kept in LDS
+constexpr int kThrowPCache = 256;       // bins of a workgroup's slice whose prefix / parameters are kept in LDS
 
 struct ThrowArgs {
   int W, K, N, S;          // bins, sub-samples, frame side, bordered side
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
 // still holds electrons).  Random words: the bin's STAGE_NARROW stream.
 constexpr int kNarrowThreads = 256;
 constexpr int kNarrowCells = 2 * kNarrowR + 1;
-constexpr int kNarrowTile = 4096;       // ints of LDS for the workgroup's tile
+constexpr int kNarrowTile = 1536;       // ints of LDS for the workgroup's tile (its bins span ~15 x 1 px + the 13 x 13 windows)
 
 __device__ __forceinline__ float upper_tail(float t) { return 0.5f * erfcf(t * 0.70710678118654752f); }
 
