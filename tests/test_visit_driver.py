@@ -124,6 +124,21 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
     assert files == ["0000_flt.fits", "0001_raw.fits", "0002_raw.fits", "0003_raw.fits", "params.yml", "visit_plan.txt"]
     h = fitsio.read(os.path.join(obs.outdir, "0002_raw.fits"))
     assert len(h) == 1 + 5 * 4 and h[0].header["NSAMP"] == 4 and h[0].header["SCAN"] is True
+    # the reference's primary-header keywords and their units (exposure.py:216-410)
+    p0 = h[0].header
+    for key in ("DATE", "FILENAME", "FILETYPE", "TELESCOP", "INSTRUME", "EQUINOX", "PRIMESI", "TARGNAME", "RA_TARG",
+                "DEC_TARG", "DATE-OBS", "TIME-OBS", "EXPSTART", "EXPEND", "EXPTIME", "POSTARG1", "POSTARG2", "OBSTYPE",
+                "OBSMODE", "SCLAMP", "SUBARRAY", "SUBTYPE", "DETECTOR", "FILTER", "SAMP_SEQ", "NSAMP", "SAMPZERO",
+                "APERTURE", "PROPAPER", "DIRIMAGE", "SIM", "SIM-VER", "SIM-TIME", "X-REF", "Y-REF", "SAMPRATE", "NSE-MEAN",
+                "NSE-STD", "ADD-DRK", "ADD-FLAT", "ADD-GAIN", "ADD-NLIN", "STAR-NSE", "CSMCRATE", "SKY-LVL", "VSTTREND",
+                "CLIPVALS", "RANDSEED", "V-PY", "V-NP", "MID-TRAN", "PERIOD", "SMA", "INC", "ECC", "PERI", "LD1", "LD4",
+                "STARX"):
+        assert key in p0, key
+    assert p0["TARGNAME"] == "HD 209458 b" and p0["FILTER"] == "G141" and p0["SUBTYPE"] == "SQ128SUB"
+    assert abs(p0["EXPSTART"] - (obs.exp_start_times[1] - 2400000.5)) < 1e-9          # Modified Julian Date
+    assert abs((p0["EXPEND"] - p0["EXPSTART"]) * 86400.0 - p0["EXPTIME"]) < 1e-3
+    assert p0["SAMPRATE"] == pytest.approx(0.025) and p0["RANDSEED"] == 1963 and p0["APERTURE"] == "GRISM128"
+    assert p0["PERIOD"] == pytest.approx(3.524746) and p0["LD1"] == pytest.approx(0.800627)
     sci = [x for x in h if x.name == "SCI"]
     assert [x.header["SAMPNUM"] for x in sci] == [3, 2, 1, 0] and sci[0].data.shape == (138, 138)
     assert sci[0].header["SAMPTIME"] == pytest.approx(detector.WFC3_IR().exptime(4, 128, "RAPID"))

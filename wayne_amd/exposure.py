@@ -15,6 +15,8 @@ import threading
 
 import numpy as np
 
+_VERSION = "0.1"
+
 from . import fitsio
 
 
@@ -38,29 +40,103 @@ class Exposure(object):
                 "DELTATIM": float(read_info.get("read_exp_time", 0.0)),
                 "CRPIX1": read_info.get("CRPIX1", 0)}
 
-    def generate_science_header(self):
-        """Primary-header keywords describing the simulation (subset of exposure.py:216-410:
-        the instrument / mode / simulation-switch keywords; no target ephemerides)."""
+    def generate_science_header(self, ldcoeffs=None):
+        """The primary header of the reference's files, keyword for keyword (exposure.py:216-410): HST
+        identification, target, exposure times as Modified Julian Dates, instrument configuration, the
+        simulation switches, package versions and -- when a planet is attached -- its orbital elements
+        and limb-darkening coefficients.  astropy / pandas versions are not written (neither is used)."""
+        import datetime
+        import platform
         e = self.exp_info
-        cards = [("TELESCOP", "HST", ""), ("INSTRUME", "WFC3", ""), ("DETECTOR", "IR", ""),
-                 ("SIM", True, "simulated exposure"), ("SIMULATR", "wayne_amd", "MI355X exposure synthesis"),
-                 ("FILENAME", str(e.get("filename", "")), ""), ("OBSTYPE", str(e.get("OBSTYPE", "SPECTROSCOPIC")), ""),
-                 ("FILTER", getattr(self.filter, "name", ""), ""),
-                 ("NSAMP", int(e.get("NSAMP", 0)), ""), ("SAMP_SEQ", str(e.get("SAMPSEQ", "")), ""),
-                 ("SUBARRAY", bool(e.get("SUBARRAY", 1024) != 1024), ""), ("SUBTYPE", "SQ%sSUB" % e.get("SUBARRAY", ""), ""),
-                 ("EXPSTART", float(e.get("EXPSTART", 0.0)), "JD"), ("EXPEND", float(e.get("EXPEND", 0.0)), "JD"),
-                 ("EXPTIME", float(e.get("EXPTIME", 0.0)), "seconds"),
-                 ("SCAN", bool(e.get("SCAN", False)), ""), ("STAR-X", float(e.get("x_ref", 0.0)), ""),
-                 ("STAR-Y", float(e.get("y_ref", 0.0)), ""), ("SAMPRATE", float(e.get("samp_rate", 0.0)), "ms"),
-                 ("SIM-TIME", float(e.get("sim_time", 0.0)), "seconds to generate"),
-                 ("NSE-MEAN", float(e.get("noise_mean") or 0.0), ""), ("NSE-STD", float(e.get("noise_std") or 0.0), ""),
-                 ("ADD-DRK", bool(e.get("add_dark", False)), ""), ("ADD-FLAT", bool(e.get("add_flat", False)), ""),
-                 ("ADD-GAIN", bool(e.get("add_gain", False)), ""), ("ADD-NLIN", bool(e.get("add_non_linear", False)), ""),
-                 ("STAR-NSE", bool(e.get("add_stellar_noise", False)), ""),
-                 ("CSMCRATE", float(e.get("cosmic_rate") if e.get("cosmic_rate") is not None else -1.0), ""),
-                 ("SKY-LVL", float(e.get("sky_background") or 0.0), "ct/s"),
-                 ("VSTTREND", float(e.get("scale_factor") if e.get("scale_factor") is not None else 1.0), ""),
-                 ("CLIPVALS", bool(e.get("clip_values_det_limits", False)), "")]
+        planet = self.planet
+
+        def blank(text=""):
+            return ("", text, "")
+
+        sub = e.get("SUBARRAY", 1024)
+        cards = [
+            ("DATE", datetime.datetime.now().strftime("%Y-%m-%d"), "date this file was written (yyyy-mm-dd)"),
+            ("FILENAME", str(e.get("filename", "")), "name of file"),
+            ("FILETYPE", "SCI", "type of data found in data file"),
+            blank(),
+            ("TELESCOP", getattr(self.detector, "telescope", "HST"), "telescope used to acquire data"),
+            ("INSTRUME", getattr(self.detector, "instrument", "WFC3"), "identifier for instrument used to acquire data"),
+            ("EQUINOX", 2000.0, "equinox of celestial coord. system"),
+            blank(), blank("/ DATA DESCRIPTION KEYWORDS"), blank(),
+            ("PRIMESI", getattr(self.detector, "instrument", "WFC3"), "instrument designated as prime"),
+            blank(), blank("/ TARGET INFORMATION"), blank(),
+            ("TARGNAME", str(getattr(planet, "name", "None")), "proposer's target name"),
+            ("RA_TARG", float(getattr(planet, "ra_deg", 0.0) or 0.0), "right ascension of the target (deg) (J2000)"),
+            ("DEC_TARG", float(getattr(planet, "dec_deg", 0.0) or 0.0), "declination of the target (deg) (J2000)"),
+            blank(), blank("/ EXPOSURE INFORMATION"), blank(),
+            ("DATE-OBS", False, "UT date of start of observation (yyyy-mm-dd)"),
+            ("TIME-OBS", False, "UT time of start of observation (hh:mm:ss)"),
+            ("EXPSTART", float(e.get("EXPSTART", 0.0)) - 2400000.5, "exposure start time (Modified Julian Date)"),
+            ("EXPEND", float(e.get("EXPEND", 0.0)) - 2400000.5, "exposure end time (Modified Julian Date)"),
+            ("EXPTIME", float(e.get("EXPTIME", 0.0)), "exposure duration (seconds)--calculated"),
+            blank(), blank("/ TARGET OFFSETS (POSTARGS)"), blank(),
+            ("POSTARG1", 0.0, "POSTARG in axis 1 direction"),
+            ("POSTARG2", e.get("SCAN_DIR") if e.get("SCAN_DIR") is not None else 0, "POSTARG in axis 2 direction"),
+            blank(), blank("/ INSTRUMENT CONFIGURATION INFORMATION"), blank(),
+            ("OBSTYPE", str(e.get("OBSTYPE", "SPECTROSCOPIC")), "observation type - imaging or spectroscopic"),
+            ("OBSMODE", "MULTIACCUM", "operating mode"),
+            ("SCLAMP", "NONE", "lamp status, NONE or name of lamp which is on"),
+            ("SUBARRAY", bool(sub != 1024), "data from a subarray (T) or full frame (F)"),
+            ("SUBTYPE", "SQ%sSUB" % sub, ""),
+            ("DETECTOR", getattr(self.detector, "detector_type", "IR"), "detector in use: UVIS or IR"),
+            ("FILTER", getattr(self.filter, "name", ""), "element selected from filter wheel"),
+            ("SAMP_SEQ", str(e.get("SAMPSEQ", "")), "MultiAccum exposure time sequence name"),
+            ("NSAMP", int(e.get("NSAMP", 0)), "number of MULTIACCUM samples"),
+            ("SAMPZERO", 0.0, "sample time of the zeroth read (sec)"),
+            ("APERTURE", "GRISM%s" % sub, "aperture name"),
+            ("PROPAPER", "", "proposed aperture name"),
+            ("DIRIMAGE", "NONE", "direct image for grism or prism exposure"),
+            blank(), blank("/ Wayne"), blank(),
+            ("SIM", True, "Wayne Simulation (T/F)"),
+            ("SIM-VER", "wayne_amd " + _VERSION, "WFC3Sim Version Used"),
+            ("SIM-TIME", float(e.get("sim_time", 0.0)), "Wayne exposure generation time (s)"),
+            blank(),
+            ("X-REF", float(e.get("x_ref", 0.0)), "x position of star on frame (full frame))"),
+            ("Y-REF", float(e.get("y_ref", 0.0)), "y position of star on frame (full frame))"),
+            ("SAMPRATE", float(e.get("samp_rate", 0.0)) * 1e-3, "How often exposure is sampled (s)"),
+            ("NSE-MEAN", e.get("noise_mean") if e.get("noise_mean") else False, "mean of normal noise (per s per pix)"),
+            ("NSE-STD", e.get("noise_std") if e.get("noise_std") else False, "std of normal noise (per s per pix)"),
+            ("ADD-DRK", bool(e.get("add_dark", False)), "dark current added (T/F)"),
+            ("ADD-FLAT", bool(e.get("add_flat", False)), "flat field added (T/F)"),
+            ("ADD-GAIN", bool(e.get("add_gain", False)), "gain variations added (T/F)"),
+            ("ADD-NLIN", bool(e.get("add_non_linear", False)), "non-linearity effects added (T/F)"),
+            ("STAR-NSE", bool(e.get("add_stellar_noise", False)), "Stellar Noise Added (T/F)"),
+            ("CSMCRATE", float(e.get("cosmic_rate")) if e.get("cosmic_rate") is not None else False,
+             "Rate of cosmic hits (per s)"),
+            ("SKY-LVL", float(e.get("sky_background") or 0.0), "multiple of master sky per s"),
+            ("VSTTREND", float(e.get("scale_factor")) if e.get("scale_factor") is not None else False,
+             "visit trend scale factor"),
+            ("CLIPVALS", bool(e.get("clip_values_det_limits", False)), "pixels clipped to detector range (T/F)"),
+            ("RANDSEED", int(e.get("seed", 0)), "seed used for the visit"),
+            ("SCAN", bool(e.get("SCAN", False)), "spatial scan (T/F); not a reference keyword"),
+            blank(), blank("/ Wayne Package Versions Used"), blank(),
+            ("V-PY", platform.python_version(), "Python version used"),
+            ("V-NP", np.__version__, "NumPy version used"),
+        ]
+        try:
+            import scipy
+            cards.append(("V-SP", scipy.__version__, "SciPy version used"))
+        except ImportError:
+            pass
+        if planet is not None and getattr(planet, "P", None) is not None:
+            cards += [blank(), blank("/ Wayne Observation Parameters"), blank(),
+                      ("MID-TRAN", float(planet.transittime) if planet.transittime is not None else False,
+                       "Time of mid transit (JD)"),
+                      ("PERIOD", float(planet.P), "Orbital Period (days)"),
+                      ("SMA", float(planet.sma_over_rs) if planet.a and planet.Rs else False, "Semi-major axis (a/R_s)"),
+                      ("INC", float(planet.i) if planet.i is not None else False, "Orbital Inclination (deg)"),
+                      ("ECC", float(planet.e or 0.0), "Orbital Eccentricity"),
+                      ("PERI", "%s" % planet.periastron, "Argument or periastron")]
+            ld = ldcoeffs if ldcoeffs is not None else getattr(planet, "ldcoeffs", None)
+            if ld is not None:
+                for n_, v_ in enumerate(ld, 1):
+                    cards.append(("LD%d" % n_, float(v_), "Non-linear limb darkening coeff %d" % n_))
+        cards.append(("STARX", float(e.get("x_ref", 0.0)), "x position of star on frame (full frame))"))
         return fitsio.Header(cards)
 
     def generate_fits(self, out_dir="", filename=None, ldcoeffs=None):
@@ -71,7 +147,7 @@ class Exposure(object):
         if filename is None:
             filename = self.exp_info.get("filename", "exposure_raw.fits")
         path = os.path.join(out_dir, filename)
-        hdus = [fitsio.HDU(self.generate_science_header(), None)]
+        hdus = [fitsio.HDU(self.generate_science_header(ldcoeffs=ldcoeffs), None)]
         n = len(self.reads)
         for i, (data, hdr) in enumerate(reversed(self.reads)):
             samp = n - 1 - i

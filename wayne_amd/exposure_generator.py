@@ -57,7 +57,7 @@ class ExposureGenerator(object):
             "EXPTIME": self.exptime, "SCAN": False, "SCAN_DIR": None, "OBSTYPE": "SPECTROSCOPIC",
             "NSAMP": NSAMP, "SAMPSEQ": SAMPSEQ, "SUBARRAY": SUBARRAY, "samp_rate": 0.0, "sim_time": 0.0,
             "scan_speed_var": False, "noise_mean": False, "noise_std": False, "add_dark": False,
-            "add_stellar_noise": False,
+            "add_stellar_noise": False, "seed": seed,
         }
 
     # -- sample timing (host, K-vectors) ----------------------------------------

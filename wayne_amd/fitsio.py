@@ -218,6 +218,8 @@ def _card(key, value, comment=""):
 
 
 def _render_card(key, value, comment=""):
+    if key == "":                      # blank-keyword card: free text (section titles of the HST headers)
+        return (" " * 8 + str(value))[:80].ljust(80)
     if key in ("COMMENT", "HISTORY"):
         return ("%-8s%s" % (key, value))[:80].ljust(80)
     body = "%-8s= %s" % (key[:8], _fmt_value(value))

@@ -90,6 +90,7 @@ class Observation(object):
                 raise ValueError("ldcoeffs are required (the reference looks them up with pylightcurve.clablimb, "
                                  "tools.py:220-230, which is not available)")
             self.ldcoeffs = list(ldcoeffs)
+            planet.ldcoeffs = self.ldcoeffs          # written into the FITS header (exposure.py:396-402)
         else:
             self.transmission_spectroscopy = False
 
