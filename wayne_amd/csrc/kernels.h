@@ -697,7 +697,8 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
     }
   }
   __syncthreads();
-  const int b0 = s_bins[0], b1 = s_bins[1];
+  // (clamped: an inconsistent prefix array must not turn into an out-of-range bin index)
+  const int b0 = min(max(s_bins[0], 0), W - 1), b1 = min(max(s_bins[1], b0), W - 1);
   // the slice's prefix entries P[b0 .. b1+1] go to LDS: the per-lane searches below stay on chip
   const int nb = b1 - b0 + 2;
   // (and, for the Philox thrower, the bins' parameters: lanes of a wave cross bin boundaries at
