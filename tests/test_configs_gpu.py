@@ -97,6 +97,31 @@ def test_cfg4_production_statistics():
     assert reads[-1].max() > 2000 and np.isfinite(reads).all()
 
 
+def test_full_frame_sky_is_poisson_in_production_mode():
+    # production samplers (hardware exp / rcp, alias tables + remainder): the sky of a full 1014^2 frame,
+    # nothing else switched on, must have the Poisson mean AND variance pixel by pixel.  The dispersion
+    # index sum((k - lam)^2 / lam) over ~10^6 pixels is chi-square with that many degrees of freedom.
+    v = helpers.make_visit("cfg4")
+    over = dict(add_stellar_noise=False, cosmic_rate=None, add_dark=False, add_read_noise=False,
+                add_non_linear=False, clip_values_det_limits=False, add_gain_variations=False,
+                add_flat=False, add_initial_bias=False, sky_background=5.0, scale_factor=1e-9)   # star switched off
+    reads = frames(v, **over)
+    cal = helpers.calibration_set()
+    sky = cal.sky["G141"].astype(np.float64)                       # 1014 x 1014 for SUBARRAY 1024
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    for r in (1, 2, 8, 15):
+        k = (reads[r][5:-5, 5:-5] - reads[r - 1][5:-5, 5:-5]) * 2.35      # electrons of read interval r
+        assert np.abs(k - np.round(k)).max() < 1e-6 and k.min() >= 0
+        lam = sky * 5.0 * dt[r - 1]
+        n = lam.size
+        assert abs((k - lam).sum()) < 5 * np.sqrt(lam.sum())
+        disp = ((k - lam) ** 2 / lam).sum()
+        assert abs(disp - n) < 6 * np.sqrt(2.0 * n), (r, disp / n)
+        # third moment too: skewness of a Poisson variable is lam^-1/2
+        skew = (((k - lam) / np.sqrt(lam)) ** 3).mean()
+        assert abs(skew - (1 / np.sqrt(lam)).mean()) < 6 * np.sqrt(15.0 / n)
+
+
 def test_cfg5_cosmic_rays_and_ssv():
     v = helpers.make_visit("cfg5")
     rec = {}
