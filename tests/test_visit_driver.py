@@ -31,6 +31,49 @@ def test_fits_roundtrip_all_types(tmp_path):
         assert back[i + 1].data.dtype.kind == a.dtype.kind and back[i + 1].data.dtype.itemsize == a.dtype.itemsize
 
 
+def test_exposure_file_layout_and_primary_header(tmp_path):
+    # the reference's file: primary header, then per read (latest first) SCI + four empty extensions
+    # (exposure.py:133-214), primary keywords as exposure.py:216-410 writes them
+    from wayne_amd import calibration, exposure, grism
+    from wayne_amd.exposure_generator import ExposureGenerator
+    from wayne_amd.observation import Planet
+    cal = calibration.CalibrationSet.synthetic(11)
+    det, gr = detector.WFC3_IR(), grism.G141(cal)
+    pl = Planet("HD 209458 b", period=3.524746, sma_au=0.047309, stellar_radius_rsun=1.155, inclination=86.71,
+                transittime=2456196.28836)
+    eg = ExposureGenerator(det, gr, 4, "RAPID", 128, pl, "0007_raw.fits", 2456196.25, calibration=cal, seed=77)
+    info = dict(eg.exp_info, x_ref=401.5, y_ref=399.0, samp_rate=25.0, SCAN=True, SCAN_DIR=1, sky_background=1.3,
+                cosmic_rate=11.0, scale_factor=0.9991, add_dark=True, sim_time=0.002)
+    exp = exposure.Exposure(det, gr, pl, info)
+    rng = np.random.default_rng(0)
+    frames = [rng.normal(100 * r, 5, (138, 138)).astype(np.float32) for r in range(4)]
+    t = det.get_read_times(4, 128, "RAPID")
+    exp.add_read(frames[0], {"cumulative_exp_time": 0.0, "read_exp_time": 0.0, "CRPIX1": 0})
+    for r in range(3):
+        exp.add_read(frames[r + 1], {"cumulative_exp_time": float(t[r]), "read_exp_time": float(t[r] - (t[r - 1] if r else 0)),
+                                     "CRPIX1": 0})
+    path = exp.generate_fits(str(tmp_path), ldcoeffs=[0.8, -0.7, 0.9, -0.4])
+    assert os.path.basename(path) == "0007_raw.fits"
+    h = fitsio.read(path)
+    assert [x.name for x in h[1:6]] == ["SCI", "ERR", "DQ", "SAMP", "TIME"] and len(h) == 1 + 5 * 4
+    sci = [x for x in h if x.name == "SCI"]
+    assert [x.header["SAMPNUM"] for x in sci] == [3, 2, 1, 0]
+    assert sci[0].data.dtype == np.dtype(">f8") or sci[0].data.dtype == np.float64
+    np.testing.assert_array_equal(sci[0].data, frames[3].astype(np.float64))
+    np.testing.assert_array_equal(sci[3].data, frames[0].astype(np.float64))
+    assert sci[0].header["SAMPTIME"] == pytest.approx(t[2]) and sci[3].header["SAMPTIME"] == 0.0
+    p0 = h[0].header
+    assert p0["TELESCOP"] == "HST" and p0["INSTRUME"] == "WFC3" and p0["DETECTOR"] == "IR" and p0["FILTER"] == "G141"
+    assert p0["EXPSTART"] == pytest.approx(2456196.25 - 2400000.5, abs=1e-9) and p0["EXPTIME"] == pytest.approx(t[-1])
+    assert p0["SUBARRAY"] is True and p0["SUBTYPE"] == "SQ128SUB" and p0["APERTURE"] == "GRISM128" and p0["NSAMP"] == 4
+    assert p0["SAMP_SEQ"] == "RAPID" and p0["OBSMODE"] == "MULTIACCUM" and p0["POSTARG2"] == 1
+    assert p0["X-REF"] == 401.5 and p0["STARX"] == 401.5 and p0["SAMPRATE"] == pytest.approx(0.025)
+    assert p0["ADD-DRK"] is True and p0["ADD-FLAT"] is False and p0["CSMCRATE"] == 11.0 and p0["SKY-LVL"] == 1.3
+    assert p0["VSTTREND"] == pytest.approx(0.9991) and p0["RANDSEED"] == 77 and p0["SIM"] is True
+    assert p0["TARGNAME"] == "HD 209458 b" and p0["PERIOD"] == pytest.approx(3.524746) and p0["INC"] == pytest.approx(86.71)
+    assert p0["SMA"] == pytest.approx(0.047309 / (1.155 * 0.00465047), rel=1e-3) and p0["LD2"] == pytest.approx(-0.7)
+
+
 def test_fits_reads_reference_data_files():
     # the reference's own small FITS data files, when its tree is present (not on the GPU box)
     ref = "/root/reference/wayne/data"
