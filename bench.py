@@ -257,6 +257,29 @@ def main():
         two = args.steps / (time.perf_counter() - t1)
         stride = 1
 
+    # delivered: the same exposures with their reads copied into pinned host memory (copy of exposure n
+    # overlapping the kernels of n + 1), as a visit driver consumes them
+    delivered = None
+    if two is not None and n_res >= 4:
+        pending = []
+        ring = 4                             # exposures in flight: their pinned buffers are allocated in the warm-up
+        for j in range(max(args.warmup, ring)):
+            ctx.run(j % ring)
+            ctx.fetch_async(j % ring)
+            ctx.wait(j % ring)
+        sync_all()
+        t2 = time.perf_counter()
+        for j in range(args.warmup, total):
+            slot = j % ring
+            ctx.run(slot)
+            ctx.fetch_async(slot)
+            pending.append(slot)
+            if len(pending) > 2:
+                ctx.wait(pending.pop(0))
+        while pending:
+            ctx.wait(pending.pop(0))
+        delivered = args.steps / (time.perf_counter() - t2)
+
     # sanity: the last exposure really produced a frame
     reads = ctx.download(slot_of(total - 1) if two is None else (total - 1) % n_res)
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
@@ -305,6 +328,10 @@ def main():
                         if forked else "k_throw then k_narrow on one stream"},
             "two_streams": None if two is None else {"value": two, "unit": "exposures/s",
                                                      "note": "same exposures alternating over two HIP streams"},
+            "delivered": None if delivered is None else {
+                "value": delivered, "unit": "exposures/s",
+                "note": "reads copied to pinned host memory (PCIe-inclusive; %.1f MB per exposure)" % (
+                    (eng.R + 1) * eng.S * eng.S * (8 if args.out_f64 else 4) / 1e6)},
         }
         traffic_file = os.path.join(ROOT, "profiles", "k_ramp_traffic.json")
         if os.path.exists(traffic_file):
