@@ -26,7 +26,7 @@ class BuildHip(Command):
 
 setup(
     name="wayne_amd",
-    version="0.1",
+    version="0.1.0",
     description="MI355X-native WFC3-IR exposure synthesis (the hot path of ucl-exoplanets/wayne)",
     packages=find_packages(include=["wayne_amd", "wayne_amd.*"]),
     package_data={"wayne_amd": ["libwayne_hip.so", "data/*", "csrc/*"]},

@@ -15,8 +15,8 @@ import threading
 
 import numpy as np
 
-_VERSION = "0.1"
 
+from . import __version__ as _VERSION
 from . import fitsio
 
 
