@@ -74,6 +74,47 @@ def test_planet_depths_matrix():
     assert np.all(d[0] > d[1]) and np.all(np.diff(d[0]) > 0)
 
 
+def test_jd_to_hjd():
+    from wayne_amd import tools
+    # the Sun at the March equinox and June solstice of 2000 (Astronomical Almanac low-precision formulae)
+    ra, dec = tools.sun_ra_dec(2451623.815)
+    assert abs(np.rad2deg(dec)) < 0.02 and min(np.rad2deg(ra), 360 - np.rad2deg(ra)) < 0.02
+    ra, dec = tools.sun_ra_dec(2451716.575)
+    assert abs(np.rad2deg(ra) - 90) < 0.02 and abs(np.rad2deg(dec) - 23.44) < 0.01
+    # a target in the ecliptic swings by +-(1 AU / c) cos(latitude) over the year; at the pole not at all
+    jd = np.linspace(2456000.0, 2456365.25, 731)
+    au_c = 149597870700.0 / 299792458.0
+    d = (tools.jd_to_hjd(jd, 330.795, 18.884) - jd) * 86400.0            # HD 209458: ecliptic latitude 28.7 deg
+    assert abs(d.max() - au_c * np.cos(np.deg2rad(28.70))) < 1.0 and abs(d.min() + d.max()) < 1.0
+    pole = (tools.jd_to_hjd(jd, 270.0, 66.5607) - jd) * 86400.0            # north ecliptic pole
+    assert np.abs(pole).max() < 0.5
+    # opposition: the Earth is nearer to the star than the Sun is -> HJD > JD
+    k = np.argmax(d)
+    ra_s, dec_s = tools.sun_ra_dec(jd[k])
+    assert abs(((np.rad2deg(ra_s) - 330.795 + 180) % 360) - 180) > 150
+    assert tools.jd_to_hjd(2456196.28836, 330.795, 18.884) > 2456196.28836
+
+
+def test_observation_uses_heliocentric_times_when_it_knows_the_target():
+    from wayne_amd import observation, tools
+    args = dict(period=3.524746, sma_au=0.047309, stellar_radius_rsun=1.155, inclination=86.71,
+                transittime=2456196.28836)
+    t = 2456196.28836 + np.linspace(-0.12, 0.12, 400)
+    curves = []
+    for coords in (dict(), dict(ra_deg=330.795, dec_deg=18.884)):
+        obs = observation.Observation()
+        pl = observation.Planet("HD 209458 b", **args, **coords)
+        wl = np.linspace(1.0, 1.7, 50)
+        obs.setup_target(pl, wl, np.full(50, 0.0146), np.ones(50), ldcoeffs=LD)
+        curves.append(obs.generate_lightcurves(t, depth=0.0146)[:, 0])
+    shift = float(tools.jd_to_hjd(2456196.28836, 330.795, 18.884) - 2456196.28836)      # days, +403 s here
+    # mid-transit in JD moves EARLIER by the correction when the ephemeris is heliocentric
+    mid = [np.sum(t * (1 - c)) / np.sum(1 - c) for c in curves]
+    assert abs((mid[0] - mid[1]) - shift) < 2e-5 and shift > 0.004
+    dd = obs.device_depths(t)
+    assert abs(dd.z_tr.argmin() - (1 - curves[1]).argmax()) <= 1
+
+
 @pytest.mark.gpu
 def test_device_depth_matrix_matches_numpy(gpu_ctx):
     import helpers

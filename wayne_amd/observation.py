@@ -30,8 +30,10 @@ class Planet(object):
     exodata Planet, observation.py:317-324)."""
 
     def __init__(self, name="planet", period=None, sma_au=None, stellar_radius_rsun=None, inclination=None,
-                 eccentricity=0.0, periastron=0.0, transittime=None, rp_over_rs=None, star_temperature=None):
+                 eccentricity=0.0, periastron=0.0, transittime=None, rp_over_rs=None, star_temperature=None,
+                 ra_deg=None, dec_deg=None):
         self.name = name
+        self.ra_deg, self.dec_deg = ra_deg, dec_deg        # target coordinates (J2000, degrees) for JD -> HJD
         self.P, self.a, self.Rs = period, sma_au, stellar_radius_rsun
         self.i, self.e, self.periastron = inclination, eccentricity, periastron
         self.transittime = transittime
@@ -144,8 +146,10 @@ class Observation(object):
 
     def generate_lightcurves(self, time_array, depth=False):
         """Normalised flux, shape (len(time_array), n_depths) (observation.py:293-357).
-        The reference converts JD to HJD with ephem (tools.py:233-271), which is not
-        available: times are used as given."""
+        The reference converts JD to HJD for the target's catalogue coordinates (observation.py:340,
+        tools.py:220-271); here that happens when the planet carries ra_deg / dec_deg (there is no
+        catalogue to look them up in), else times are used as given."""
+        time_array = self._to_hjd(time_array)
         spectrum = np.array([depth]) if depth else self.planet_spectrum
         rp_white = self.planet.rp_over_rs or float(np.sqrt(np.mean(self.planet_spectrum)))
         z_tr, hidden = lightcurve.depth_inputs(*(self._orbit_args() + (time_array, rp_white)))
@@ -154,8 +158,14 @@ class Observation(object):
     def device_depths(self, time_array):
         """The same per-sub-sample depths, as the recipe the GPU evaluates."""
         rp_white = self.planet.rp_over_rs or float(np.sqrt(np.mean(self.planet_spectrum)))
-        z_tr, hidden = lightcurve.depth_inputs(*(self._orbit_args() + (time_array, rp_white)))
+        z_tr, hidden = lightcurve.depth_inputs(*(self._orbit_args() + (self._to_hjd(time_array), rp_white)))
         return lightcurve.DeviceDepths(z_tr, hidden, self.planet_spectrum, self.ldcoeffs)
+
+    def _to_hjd(self, time_array):
+        p = self.planet
+        if getattr(p, "ra_deg", None) is None or getattr(p, "dec_deg", None) is None:
+            return time_array
+        return tools.jd_to_hjd(time_array, p.ra_deg, p.dec_deg)
 
     def show_lightcurve(self):
         """White light curve of the planned visit -> (times, model); the reference also plots it."""

@@ -57,8 +57,11 @@ def build_observation(cfg, base_dir=".", calibration=None, device=0):
     planet_spectrum_file = _get(target, "planet_spectrum_file")
     transmission = bool(planet_spectrum_file)
     depth_planet = wl_planet = None
+    # `ra` / `dec` (degrees, J2000) are an extension of the reference's schema: it reads them off the Open
+    # Exoplanet Catalogue entry of `name`; with them the light-curve times become heliocentric (observation.py:340)
     planet = observation.Planet(name=str(_get(target, "name", "planet")),
-                                star_temperature=_get(target, "star_temperature", 6100.0))
+                                star_temperature=_get(target, "star_temperature", 6100.0),
+                                ra_deg=_get(target, "ra", None), dec_deg=_get(target, "dec", None))
     if transmission:
         wl_planet, depth_planet = tools.load_and_sort_spectrum(path(planet_spectrum_file))
         wl_planet, depth_planet = tools.crop_spectrum(0.9, 1.8, wl_planet, depth_planet)      # run_visit.py:152-153

@@ -74,6 +74,32 @@ def crop_central_box(array, size):
     return array[i:n - i, i:n - i]
 
 
+def sun_ra_dec(jd):
+    """Apparent right ascension and declination of the Sun (radians, equinox of date) from the
+    Astronomical Almanac's low-precision formulae (0.01 deg between 1950 and 2050) -- what the reference
+    asks ephem for (tools.py:233-235)."""
+    n = np.asarray(jd, dtype=float) - 2451545.0
+    L = np.deg2rad((280.460 + 0.9856474 * n) % 360.0)           # mean longitude
+    g = np.deg2rad((357.528 + 0.9856003 * n) % 360.0)           # mean anomaly
+    lam = L + np.deg2rad(1.915) * np.sin(g) + np.deg2rad(0.020) * np.sin(2 * g)
+    eps = np.deg2rad(23.439 - 0.0000004 * n)
+    ra = np.arctan2(np.cos(eps) * np.sin(lam), np.cos(lam)) % (2 * np.pi)
+    dec = np.arcsin(np.sin(eps) * np.sin(lam))
+    return ra, dec
+
+
+def jd_to_hjd(jd, ra_deg, dec_deg):
+    """Julian date -> heliocentric Julian date for a target at (ra, dec) in degrees (tools.py:220-271:
+    HJD = JD - (1 AU / c) [sin d sin d_sun + cos d cos d_sun cos(a - a_sun)] / 86400, with the Sun
+    at exactly 1 AU as there).  Scalar or array."""
+    ra, dec = np.deg2rad(ra_deg), np.deg2rad(dec_deg)
+    ra_sun, dec_sun = sun_ra_dec(jd)
+    a = 149597870700.0 / 299792458.0
+    b = np.sin(dec) * np.sin(dec_sun)
+    c = np.cos(dec) * np.cos(dec_sun) * np.cos(ra - ra_sun)
+    return np.asarray(jd, dtype=float) - (a * (b + c)) / 86400.0
+
+
 def detect_orbits(exp_start_times, separation=0.028):
     """Indices at which a new HST orbit starts: gaps of >= `separation` days
     (~40 min) between consecutive exposure starts (tools.py:274-300)."""
