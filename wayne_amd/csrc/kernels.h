@@ -521,13 +521,15 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
 // k_throw : the electron thrower
 // ---------------------------------------------------------------------------
 // Electrons of sub-sample k are numbered bin-major exactly as the reference
-// numbers them (pyparallel_menu.c:87-108).  The E_k electrons are cut into
-// splits*T equal contiguous "slots" (T = 512 threads); workgroup (k, s) takes the slots
-// j*splits + s, its lane l / wave v takes j = l*(T/64) + v, so the 64 lanes
-// of a wave sit ~E_k/64 electrons apart, i.e. spread over the whole trace:
-// their LDS atomics rarely collide in a bank or on a pixel.  Each lane walks
-// its slot sequentially and re-loads bin parameters only when it crosses a
-// bin boundary (about once per counts[b] electrons).
+// numbers them (pyparallel_menu.c:87-108) and handed out in units (one RNG
+// block of 128 electrons; single electrons in replay mode).  B workgroups
+// share the units of sub-sample k evenly, workgroup (k, s) owning a contiguous
+// run -- a short slice of the trace, which is what its LDS tile covers.  Inside
+// it lane l / wave v takes local slot l*(T/64) + v (T = 512 threads), so the
+// 64 lanes of a wave stay spread over the slice: their LDS atomics rarely
+// collide in a bank or on a pixel.  Each lane walks its units sequentially and
+// re-loads bin parameters (from an LDS copy of the slice's bins) only when it
+// crosses a bin boundary.
 //
 // RNG_MODE 0 (replay): electron i belongs to the emulated OpenMP thread t with
 //   t*ssum/T <= i < (t+1)*ssum/T, stream seed 25234 + 17 t + test, and uses
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
 //   fp64 Box-Muller, fp64 positions -> bit-exact frames.
 // RNG_MODE 1 (Philox): electron e uses words 2j, 2j+1 (j = e mod 128) of the
 //   xoshiro128+ stream seeded by Philox block (e / 128, 0, k, exposure), stage
-//   STAGE_THROW (philox.h); slots are whole blocks, so the draws of an
+//   STAGE_THROW (philox.h); units are whole blocks, so the draws of an
 //   electron do not depend on the launch geometry.  fp32 Box-Muller on the
 //   hardware sin/cos/log2 units.
 //
