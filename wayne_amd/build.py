@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwayne_hip.so")
 SOURCES = [os.path.join(CSRC, "wayne_hip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("kernels.h", "philox.h", "samplers.h")] + [
+DEPS = SOURCES + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")) + [
     os.path.join(ROOT, "include", "wayne_hip.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -24,7 +24,7 @@ FLAGS = [
     # no fused multiply-adds the source does not spell out: the CPU oracle
     # must see the same roundings (samplers.h)
     "-ffp-contract=off",
-    "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function",
 ]
 

@@ -1,0 +1,318 @@
+// k_prep_wl, k_prep_sub, k_prep_fix: per-wavelength arrays, per-bin positions and counts (A6-A10)
+#pragma once
+#include "common.h"
+
+namespace wayne {
+
+// ---------------------------------------------------------------------------
+// k_prep_wl : A8 + the wavelength-only part of A9
+// ---------------------------------------------------------------------------
+__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o, uint32_t* misc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the exposure's status words (total electrons, overflow flag) start from zero: cleared here, by the
+  // first kernel of the exposure, instead of by a separate fill in front of it
+  if (i < 16) misc[i] = 0u;
+  if (i >= W) return;
+  const double x = wl[i];
+  o.ratio[i] = poly3(g.p_ratio, x);
+  o.sigl[i] = poly3(g.p_sigl, x);
+  o.sigh[i] = poly3(g.p_sigh, x);
+
+  // np.interp (grism.py:116-118): clamp outside the table, linear inside.
+  double s;
+  const int n = g.n_sens;
+  if (n <= 0) {
+    s = 1.0;
+  } else if (x <= g.sens_wl[0]) {
+    s = g.sens_val[0];
+  } else if (x >= g.sens_wl[n - 1]) {
+    s = g.sens_val[n - 1];
+  } else {
+    int lo = 0, hi = n - 1;  // sens_wl[lo] <= x < sens_wl[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (g.sens_wl[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double slope = (g.sens_val[lo + 1] - g.sens_val[lo]) / (g.sens_wl[lo + 1] - g.sens_wl[lo]);
+    s = slope * (x - g.sens_wl[lo]) + g.sens_val[lo];
+  }
+  o.sens[i] = s;
+
+  // tools.bin_centers_to_widths (tools.py:106-128): half-gaps to both
+  // neighbours; the end bins mirror their single neighbour.
+  double left, right;
+  if (W < 2) {
+    left = right = 0.0;
+  } else {
+    left = (i == 0) ? (wl[1] - wl[0]) / 2. : (wl[i] - wl[i - 1]) / 2.;
+    right = (i == W - 1) ? (wl[W - 1] - wl[W - 2]) / 2. : (wl[i + 1] - wl[i]) / 2.;
+  }
+  o.dlam[i] = left + right;
+}
+
+// ---------------------------------------------------------------------------
+// k_prep_sub : one workgroup per sub-sample
+// ---------------------------------------------------------------------------
+struct PrepArgs {
+  GrismDev g;
+  int W, K, N;               // bins, sub-samples, light-sensitive side
+  int sub_scale;             // 507 - SUBARRAY/2 (exposure_generator.py:630)
+  int margin;                // LDS tile margin (px)
+  int max_tile;              // LDS tile capacity (ints)
+  uint32_t seed, exposure;
+  uint32_t flags;
+  int split_min;             // > 0: WAYNE_RNG_SPLIT -- bins with >= split_min narrow electrons go to k_narrow
+  double scale_factor;
+  const double* wl;          // [W]
+  const double* flux;        // [W]
+  const double* depth;       // [K*W] or null
+  const double* x_ref;       // [K]
+  const double* y_ref;       // [K]
+  const double* dur_ms;      // [K]
+  const int32_t* replay_seed;  // [K]
+  const int32_t* sample_read;  // [K]
+  WlArrays wa;
+  // outputs
+  int32_t* counts;           // [K*W]
+  int32_t* nwide;            // [K*W]
+  int32_t* nsplit;           // [K*W] split mode: > 0 narrow electrons handed to k_narrow's multinomial,
+                             //        < 0 minus the electrons of a sparse bin (all thrown by k_narrow), else 0
+  uint32_t* prefix;          // [K*(W+1)] exclusive prefix of the electrons k_throw throws one by one
+  double* xpos;              // [K*W] frame coords (x_sub)
+  double* ypos;              // [K*W]
+  SubInfo* sub;              // [K]
+  unsigned long long* total_electrons;  // += E_k
+  int* status;               // set non-zero on overflow
+  uint32_t* chunk_total;     // [K * n_chunks] electrons (for k_throw) per chunk of kPrepThreads bins
+  double* chunk_box;         // [K * n_chunks * 4] xmin, xmax, ymin, ymax of the chunk's populated bins
+};
+
+constexpr int kPrepThreads = 512;
+constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
+constexpr int kSparseMax = 16;         // WAYNE_RNG_SPLIT: bins with fewer electrons are thrown lane-per-bin (k_narrow)
+
+__device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
+  // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
+    // wavelength_calibration_coeffs (grism.py:779-803)
+    const double* t = g.trace;
+    const double* b = g.wlsol;
+    const double m_t = t[3] + t[4] * x_ref + t[5] * y_ref + t[6] * (x_ref * x_ref) +
+                       t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);
+    const double c_t = t[0] + t[1] * x_ref + t[2] * y_ref;
+    const double m_w = b[3] + b[4] * x_ref + b[5] * y_ref + b[6] * (x_ref * x_ref) +
+                       b[7] * x_ref * y_ref + b[8] * (y_ref * y_ref);
+    const double c_w = (b[0] + b[1] * x_ref) + b[2] * y_ref;
+    // _get_x_to_wl_poly_coeffs (grism.py:553-602): line through the trace
+    // points at x_ref+10 and x_ref+20, wavelength in micron.
+    const double xa = x_ref + 10, xb = x_ref + 20;
+    const double ya = m_t * (xa - x_ref) + c_t + y_ref;  // x_to_y (grism.py:537)
+    const double yb = m_t * (xb - x_ref) + c_t + y_ref;
+    const double da = sqrt((ya - y_ref) * (ya - y_ref) + (xa - x_ref) * (xa - x_ref));
+    const double db = sqrt((yb - y_ref) * (yb - y_ref) + (xb - x_ref) * (xb - x_ref));
+    const double wa_ = (m_w * da + c_w) * 1e-4;  // angstrom -> micron
+    const double wb_ = (m_w * db + c_w) * 1e-4;
+    const double m_wl = (wb_ - wa_) / (xb - xa);
+    const double c_wl = wa_ - m_wl * xa;
+    o[0] = m_t; o[1] = c_t; o[2] = m_w; o[3] = c_w; o[4] = m_wl; o[5] = c_wl;
+}
+
+// One workgroup per (sub-sample, chunk of kPrepThreads bins): positions, counts,
+// sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the
+// chunk offsets.  K * ceil(W / 512) workgroups instead of K: the whole chip works.
+__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
+  const int k = blockIdx.x;
+  const int ch = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int W = a.W;
+  constexpr int NW = kPrepThreads / 64;
+  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
+  __shared__ uint32_t s_wsum[NW];   // per-wave totals
+  __shared__ double s_red[4][NW];
+
+  const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+  if (tid == 0) trace_coeffs(a.g, x_ref, y_ref, s_tr);
+  __syncthreads();
+  const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
+  const double dur = a.dur_ms[k];
+  const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE
+
+  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  bool overflow = false;
+  unsigned long long n_split_total = 0;   // per thread
+
+  const int w = ch * kPrepThreads + tid;
+  uint32_t c = 0;
+  if (w < W) {
+      const double wl = a.wl[w];
+    // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
+    // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
+    const double x = (wl - c_wl) / m_wl;
+    const double y = m_t * (x - x_ref) + c_t + y_ref;
+    const double xs = x - (double)a.sub_scale;
+    const double ys = y - (double)a.sub_scale;
+    a.xpos[(size_t)k * W + w] = xs;
+    a.ypos[(size_t)k * W + w] = ys;
+    // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
+    //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
+    double f = a.flux[w];
+    if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
+    double lam = f * a.wa.sens[w];
+    lam = lam * a.wa.dlam[w];
+    lam = lam * 1e4;
+    lam = lam * dur;
+    lam = lam * 1e-3;
+    lam = lam * a.scale_factor;
+    double cnt;
+    if (noisy) {
+      PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
+      cnt = poisson<ExactMath<double> >(lam, rng);   // np.random.poisson (:626)
+    } else {
+      cnt = rint(lam);                      // np.round, half to even (:628)
+    }
+    if (!(cnt >= 0.)) cnt = 0.;             // negative / NaN flux throws no electrons
+    if (cnt > 2147483647.) { cnt = 2147483647.; overflow = true; }
+    c = (uint32_t)cnt;
+    a.counts[(size_t)k * W + w] = (int32_t)c;
+    // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
+    double nw = (double)(int32_t)c * a.wa.ratio[w];
+    int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
+    a.nwide[(size_t)k * W + w] = nwi;
+    if (c > 0) {
+      xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
+      ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
+    }
+    // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one
+    // multinomial by k_narrow; k_throw keeps the wide electrons (and whole sparse bins)
+    if (a.nsplit) {
+      const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
+      const uint32_t narrow = c - wide;
+      const double sl = a.wa.sigl[w];
+      const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
+                         sl * 6.5 <= (double)kNarrowR;
+      // ... and a sparsely populated bin (long scans sampled finely: ~1 electron per bin and
+      // sub-sample) is thrown whole by the lane that owns it in k_narrow, from the bin's own
+      // Philox blocks: walking such bins electron by electron costs a bin fetch per electron
+      const bool sparse = a.split_min > 0 && c > 0 && c < (uint32_t)kSparseMax;
+      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : sparse ? -(int32_t)c : 0;
+      if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
+      if (sparse) { n_split_total += c; c = 0; }
+    }
+  }
+  // exclusive scan of c inside the chunk: shuffle scan per wave, wave totals through LDS
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  // bounding box of populated bins
+  for (int off = 32; off > 0; off >>= 1) {
+    xmin = fmin(xmin, __shfl_down(xmin, off));
+    xmax = fmax(xmax, __shfl_down(xmax, off));
+    ymin = fmin(ymin, __shfl_down(ymin, off));
+    ymax = fmax(ymax, __shfl_down(ymax, off));
+  }
+  if (lane == 0) {
+    s_red[0][wave] = xmin; s_red[1][wave] = xmax;
+    s_red[2][wave] = ymin; s_red[3][wave] = ymax;
+  }
+  __syncthreads();
+  uint64_t wave_off = 0, chunk_total = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t t = s_wsum[i];
+    if (i < wave) wave_off += t;
+    chunk_total += t;
+  }
+  if (chunk_total > 0xFFFFFFFFull) overflow = true;
+  if (w < W) a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)(wave_off + incl - c);   // chunk-local for now
+  if (overflow) atomicExch(a.status, 1);
+  // electrons handed to k_narrow: one atomic per workgroup (wave shuffle, then LDS)
+  for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
+  __shared__ unsigned long long s_split[NW];
+  if (lane == 0) s_split[wave] = n_split_total;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < NW; ++i) tot += s_split[i];
+    if (tot) atomicAdd(a.total_electrons, tot);
+    for (int i = 1; i < NW; ++i) {
+      xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
+      ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
+    }
+    const size_t ci = (size_t)k * gridDim.y + ch;
+    a.chunk_total[ci] = (uint32_t)chunk_total;
+    a.chunk_box[4 * ci + 0] = xmin; a.chunk_box[4 * ci + 1] = xmax;
+    a.chunk_box[4 * ci + 2] = ymin; a.chunk_box[4 * ci + 3] = ymax;
+  }
+}
+
+// One workgroup per sub-sample: chunk offsets -> global exclusive prefix, E_k,
+// bounding box -> LDS tile rectangle, SubInfo.
+__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks) {
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int W = a.W;
+  __shared__ uint32_t s_off[64];
+  __shared__ uint32_t s_E;
+  __shared__ int s_over;
+  if (tid == 0) {
+    uint64_t run = 0;
+    int over = 0;
+    for (int i = 0; i < n_chunks; ++i) {
+      s_off[i] = (uint32_t)run;
+      run += a.chunk_total[(size_t)k * n_chunks + i];
+      if (run > 0xFFFFFFFFull) over = 1;
+    }
+    s_E = (uint32_t)run;
+    s_over = over;
+  }
+  __syncthreads();
+  for (int w = tid; w < W; w += kPrepThreads) a.prefix[(size_t)k * (W + 1) + w] += s_off[w / kPrepThreads];
+  if (tid == 0) {
+    if (s_over) atomicExch(a.status, 1);
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int i = 0; i < n_chunks; ++i) {
+      const size_t ci = (size_t)k * n_chunks + i;
+      xmin = fmin(xmin, a.chunk_box[4 * ci + 0]); xmax = fmax(xmax, a.chunk_box[4 * ci + 1]);
+      ymin = fmin(ymin, a.chunk_box[4 * ci + 2]); ymax = fmax(ymax, a.chunk_box[4 * ci + 3]);
+    }
+    const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+    double tr[6];
+    trace_coeffs(a.g, x_ref, y_ref, tr);
+    const uint32_t E = s_E;
+    a.prefix[(size_t)k * (W + 1) + W] = E;
+    SubInfo si;
+    si.electrons = E;
+    si.read = a.sample_read[k];
+    si.replay_seed = a.replay_seed ? a.replay_seed[k] : 0;
+    si.pad_ = 0;
+    si.x_ref = x_ref; si.y_ref = y_ref;
+    si.a_t_i = 1. / tr[0];            // grism.py:367
+    si.a_w = tr[2]; si.b_w = tr[3];
+    si.inv_norm = 1. / sqrt(si.a_t_i * si.a_t_i + 1.);
+    // LDS tile: bounding box of the populated trace + margin, clipped to the
+    // frame's populated range [1, N) (pixel row / column 0 is never hit,
+    // pyparallel_menu.c:93), shrunk symmetrically if it exceeds the LDS budget
+    // (electrons outside the tile take the global-atomic path: speed only).
+    int tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    if (E > 0 && xmax >= xmin) {
+      int x0 = (int)floor(xmin) - a.margin, x1 = (int)floor(xmax) + a.margin + 1;
+      int y0 = (int)floor(ymin) - a.margin, y1 = (int)floor(ymax) + a.margin + 1;
+      x0 = max(x0, 1); y0 = max(y0, 1); x1 = min(x1, a.N); y1 = min(y1, a.N);
+      if (x1 > x0 && y1 > y0) {
+        tw = x1 - x0; th = y1 - y0;
+        while ((long long)tw * th > a.max_tile && th > 1) { y0 += 1; th -= 2; if (th < 1) th = 1; }
+        while ((long long)tw * th > a.max_tile && tw > 1) { x0 += 1; tw -= 2; if (tw < 1) tw = 1; }
+        tx0 = x0; ty0 = y0;
+      }
+    }
+    si.tx0 = tx0; si.ty0 = ty0; si.tw = tw; si.th = th;
+    a.sub[k] = si;
+    atomicAdd(a.total_electrons, (unsigned long long)E);
+  }
+}
+
+}  // namespace wayne

@@ -1,0 +1,343 @@
+// k_cosmic and k_ramp: cosmic rays, per-read and post-ramp stages (A13-A15)
+#pragma once
+#include "common.h"
+
+namespace wayne {
+
+// ---------------------------------------------------------------------------
+// k_cosmic : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
+// ---------------------------------------------------------------------------
+struct CosmicArgs {
+  int R, N, S;
+  uint32_t seed, exposure;
+  double rate;               // hits per second per 1024^2 pixels
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S]
+};
+
+__global__ __launch_bounds__(256) void k_cosmic(CosmicArgs a) {
+  const int r = blockIdx.x;
+  if (r >= a.R) return;
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) {
+    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
+    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
+    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
+    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
+    if (!(n >= 0.)) n = 0.;
+    if (n > 1e7) n = 1e7;
+    s_n = (uint32_t)n;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
+    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
+    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
+    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
+    const long long q = (long long)energy << kQBits;
+    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
+              (unsigned long long)q);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_ramp : fused up-the-ramp kernel, one thread per bordered pixel
+// ---------------------------------------------------------------------------
+struct RampArgs {
+  int R, N, S;
+  uint32_t seed, exposure, flags;
+  double sky_ct_s;           // <= 0: no sky
+  double noise_mean, noise_std;
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S] read and cleared
+  const float* pfl;          // [S*S] (bordered layout; border unused) or null
+  const float* sky;          // [S*S] or null
+  const float* lin[4];       // [S*S] or null
+  const float* dark_sci;     // [R*S*S] or null
+  const float* dark_err;
+  const double* zero_read;   // [S*S] or null
+  void* out;                 // [(R+1)*S*S] float or double
+  // sky background (see sky_draw): alias tables of Poisson(level_j * bg_count) for `sky_levels` levels
+  // of the master sky and every distinct read interval, for the reads whose bit is set in alias_mask
+  const uint32_t* sky_alias; // [n_tables <= kMaxReads][kSkyAlias] or null
+  uint32_t alias_mask;
+  int sky_levels;            // L
+  float sky_level[16];       // ascending levels of the master sky (quantiles of its positive pixels; [0] = min)
+  unsigned char sky_tab0[16];  // first table of read r (its level-0 table; level j is the j-th after it)
+};
+
+constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
+constexpr float kSkyPiece = 16.f; // largest mean drawn by one sequential search
+
+constexpr int kRampThreads = 256;
+constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
+
+// Box-Muller pair from two words.  EXACT mirrors the oracle's libm formula;
+// FAST uses the hardware units (sin / cos take revolutions, log is log2).
+template <bool FAST>
+__device__ __forceinline__ void bm_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
+  const float ua = u01f(w0), ub = u01f(w1);
+  if (FAST) {
+    const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
+    z0 = Rr * __builtin_amdgcn_cosf(ua);
+    z1 = Rr * __builtin_amdgcn_sinf(ua);
+  } else {
+    const float Rr = sqrtf(-2.0f * logf(ub));
+    const float ang = 6.283185307179586f * ua;
+    z0 = Rr * cosf(ang);
+    z1 = Rr * sinf(ang);
+  }
+}
+
+__device__ __forceinline__ double nonlinear_response(double px, float c1, float c2, float c3, float c4) {
+  // WFC3_IR.apply_non_linearity (detector.py:335-348): Newton-Raphson on
+  // u (1 + c1 + u (c2 + u (c3 + c4 u))) = px from u0 = px, until |du| < 1e-3.
+  // The reference iterates the whole frame until its slowest pixel converges;
+  // here each pixel stops on its own criterion (the extra iterations move a
+  // converged pixel by < 1e-9).  (1 + c1), 2*c2, 3*c3, 4*c4 are float32 in
+  // the reference because the coefficient planes are.  The residual is
+  // evaluated in fp64; the reciprocal of the derivative (within 2e-7 of
+  // 1 + small) in fp32, which changes an iterate by < 1e-7 of its step.
+  const double k1 = (double)(1.0f + c1);
+  const double k2 = (double)c2, k3 = (double)c3, k4 = (double)c4;
+  const float d1 = 1.0f + c1, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
+  double u0 = px, u1 = px;
+  for (int it = 0; it < 10000; ++it) {
+    const double f = fma(u0, fma(u0, fma(u0, fma(k4, u0, k3), k2), k1), -px);
+    const float uf = (float)u0;
+    const float fp_ = fmaf(uf, fmaf(uf, fmaf(uf, d4, d3), d2), d1);
+    const double step = f * (double)__builtin_amdgcn_rcpf(fp_);
+    u1 = u0 - step;
+    if (fabs(step) < 1e-3) break;
+    u0 = u1;
+  }
+  return u1;
+}
+
+// Sky background of one read interval (exposure_generator.py:488-495: pixel += poisson(master_sky *
+// bg_count)).  All pixels of the frame share bg_count and the master sky is flat to a few per cent, so
+// the draw is split with the additivity of Poisson variables:
+//     Poisson(sky_px * bg) = Poisson(level_j * bg) + Poisson((sky_px - level_j) * bg),
+// level_j the highest of L levels (quantiles of the master sky) not above sky_px.  The first term comes from an
+// alias table (Walker / Vose) shared by every pixel of that level -- one random word, one LDS read; the
+// second has a mean of a fraction of an electron to a few electrons and is drawn by inversion from 0
+// (one word, a two- or three-step search).  No rejection loop, hardly any divergence: ~50
+// instructions instead of ~180 for a transformed-rejection draw per pixel, and exactly Poisson.
+// Exposures with a read whose rate does not fit the table (long reads under a bright sky) take the
+// ALIAS = false variant of k_ramp: Poisson(lam) per pixel by Knuth / PTRS (sky_counts below).
+template <class M, bool PIECES, class RNG>
+__device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, float lam, RNG& rng) {
+  // shared part: N ~ Poisson(lam_level)
+  const uint32_t w = rng.next();
+  const uint32_t idx = w >> 24;
+  const uint32_t e = tab[idx];
+  float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
+  // the pixel's own part: Poisson(lam - lam_level) by sequential search from 0.  PIECES (chosen by the
+  // host when some pixel of the master sky lies far above its level -- a hot pixel): in pieces of mean
+  // <= kSkyPiece (additivity again), so that exp(-mean) stays far from underflow whatever the plane holds
+  float ld = lam - lam_level;
+  if (ld > 0.f) {
+    for (;;) {
+      const float piece = PIECES ? fminf(ld, kSkyPiece) : ld;
+      float u = M::u01(rng.next());
+      float pk = M::exp_(-piece);
+      float j = 0.f;
+      for (int it = 0; it < 512; ++it) {
+        if (u <= pk) break;
+        u = u - pk;
+        j = j + 1.f;
+        pk = pk * M::div_(piece, j);
+      }
+      k = k + j;
+      if (!PIECES) break;
+      ld = ld - piece;
+      if (!(ld > 0.f)) break;
+    }
+  }
+  return k;
+}
+
+// Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
+// (exposure_generator.py:488-495), from the pixel's seeded stream, written to
+// LDS.  Lanes advance through their reads independently ("lane-asynchronous"):
+// a lane whose trial is rejected retries while its neighbours move on to their
+// next read, so a wave runs ~R * 1.15 trial rounds instead of R * (the slowest
+// of 64 lanes).  The per-pixel draw sequence is sequential, so the result does
+// not depend on this scheduling.
+template <bool FAST>
+__device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int tid, bool active, float skyv,
+                                           const float* s_c, uint32_t (*s_sky)[kRampThreads]) {
+  typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
+  SeededStream rng(a.seed, STAGE_SKY, p, 0u, a.exposure);
+  int r = 0, mode = 0, guard = 0;
+  PtrsSetup<M> ps;
+  ps.lam = ps.b = ps.a = ps.vr = ps.loglam = ps.invalpha = 0.f;
+  float prod = 1.f, enlam = 0.f, kk = 0.f, lam = 0.f;
+  const int R = a.R;
+  while (__any(active)) {
+    if (active) {
+      float done = -1.f;
+      if (mode == 0) {
+        // master_sky *= bg_count is an in-place float32 multiply (:493)
+        lam = skyv * s_c[r];
+        if (!(lam > 0.f)) {
+          done = 0.f;
+        } else if (lam < 10.f) {
+          enlam = M::exp_(-lam); prod = 1.f; kk = 0.f; mode = 1;
+        } else if (lam < 256.f) {
+          if (lam != ps.lam) ps.init(lam);   // SPARS / STEP sequences repeat their read interval: same lam again
+          mode = 2;
+        } else {
+          done = (float)poisson<ExactMath<double> >((double)lam, rng);   // rare: long reads
+        }
+      }
+      if (mode == 1) {
+        prod = prod * M::u01(rng.next());
+        if (prod > enlam) kk = kk + 1.f; else done = kk;
+      } else if (mode == 2) {
+        const uint32_t w1 = rng.next();
+        const uint32_t w2 = rng.next();
+        float k;
+        if (ps.trial(w1, w2, k)) done = k;
+      }
+      if (++guard > 64 + 600 * kMaxReads && done < 0.f) done = floorf(lam + 0.5f);   // unreachable safety net
+      if (done >= 0.f) {
+        s_sky[r][tid] = (uint32_t)done;
+        mode = 0;
+        if (++r >= R) active = false;
+      }
+    }
+  }
+}
+
+// SKY: 0 = Poisson(lam) per pixel (sky_counts), 1 = alias tables + one-piece remainder, 2 = alias tables +
+// remainder in pieces (a master sky with hot pixels)
+template <class OutT, bool FAST, int SKY>
+__global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
+  constexpr bool ALIAS = SKY != 0;
+  typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
+  static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
+  __shared__ uint32_t s_tab[kMaxReads][kSkyAlias];   // ALIAS: alias tables; else: sky counts [read][thread]
+  __shared__ float s_c[kMaxReads + 1];
+  const int S = a.S;
+  const int tid = threadIdx.x;
+  const int p_raw = blockIdx.x * blockDim.x + tid;
+  const bool valid = p_raw < S * S;
+  const int p = valid ? p_raw : 0;
+  const int Y = p / S, X = p - Y * S;
+  const bool interior = valid && (X >= kBorder && X < S - kBorder && Y >= kBorder && Y < S - kBorder);
+  const size_t SS = (size_t)S * S;
+  OutT* out = (OutT*)a.out;
+  const bool clip = (a.flags & (1u << 3)) != 0;
+  const bool rdn = (a.flags & (1u << 4)) != 0;
+  const bool do_dark = (a.flags & (1u << 6)) != 0 && a.dark_sci && a.dark_err;
+  const bool do_lin = (a.flags & (1u << 2)) != 0 && a.lin[0];
+  const bool gainvar = (a.flags & (1u << 1)) != 0 && a.pfl;
+  const bool do_noise = (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
+  const bool do_sky = a.sky_ct_s > 0. && a.sky;
+
+  if (tid < a.R) s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);        // bg_count of read tid (:489-491)
+  if (ALIAS && do_sky)
+    for (int i = tid; i < kMaxReads * kSkyAlias; i += kRampThreads) (&s_tab[0][0])[i] = a.sky_alias[i];
+  float skyv = 0.f;
+  if (interior && do_sky) skyv = a.sky[p];
+  __syncthreads();
+  if (!ALIAS) {
+    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c, s_tab);
+    __syncthreads();
+  }
+  if (!valid) return;
+  // the pixel's sky level (constant over the reads): the highest level not above its sky value
+  int sky_lvl = 0;
+  if (ALIAS && skyv > 0.f)
+    for (int l = 1; l < a.sky_levels; ++l) sky_lvl += (a.sky_level[l] <= skyv) ? 1 : 0;
+  const float sky_base = a.sky_level[sky_lvl];
+
+  // per-pixel streams, seeded only when the stage is on (one Philox block each)
+  SeededStream rn, rg, rs;
+  if (ALIAS && skyv > 0.f) rs = SeededStream(a.seed, STAGE_SKY, (uint32_t)p, 0u, a.exposure);
+  if (rdn || do_dark) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
+
+  // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
+  // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
+  double z = (a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
+  if (clip) z = fmin(fmax(z, kMinCounts), kMaxCounts);
+  if (!interior) z = 0.;
+  {
+    float zd, zr;
+    const uint32_t w0 = rn.next(), w1 = rn.next();
+    double v = z;
+    if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }
+    out[p] = (OutT)v;
+  }
+
+  // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
+  // (detector.py:203-204), or the constant (exposure_generator.py:507-511);
+  // applied as a multiplication by its fp64 reciprocal
+  double inv_g = 1.0 / kGain;
+  float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  if (interior && gainvar) inv_g = 1.0 / (double)(2.35f / a.pfl[p]);
+  if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
+
+  // software-pipelined ramp: the planes of read r+1 are requested before the
+  // (VALU-heavy) work on read r so that HBM latency hides behind it
+  long long* __restrict__ accp = a.acc + p;
+  const float* __restrict__ dsp = a.dark_sci ? a.dark_sci + p : nullptr;
+  const float* __restrict__ dep = a.dark_err ? a.dark_err + p : nullptr;
+  const bool ld_dark = do_dark && interior;
+  long long q_next = interior ? accp[0] : 0;
+  float ds_next = ld_dark ? dsp[0] : 0.f, de_next = ld_dark ? dep[0] : 0.f;
+  double cum = 0.;
+  for (int r = 0; r < a.R; ++r) {
+    const long long q = q_next;
+    const float ds = ds_next, de = de_next;
+    if (r + 1 < a.R) {
+      if (interior) q_next = accp[(size_t)(r + 1) * SS];
+      if (ld_dark) { ds_next = dsp[(size_t)(r + 1) * SS]; de_next = dep[(size_t)(r + 1) * SS]; }
+    }
+    double px = 0.;
+    const uint32_t g0 = do_noise ? rg.next() : 0u, g1 = do_noise ? rg.next() : 0u;
+    if (interior) {
+      accp[(size_t)r * SS] = 0;      // leave the accumulator clean for the next exposure
+      px = (double)q * kInvQ;
+      if (do_noise) {                // _gen_noise (:477-484, :712-727)
+        const double dt = a.read_dt[r];
+        float z0, z1;
+        bm_pair<FAST>(g0, g1, z0, z1);
+        px = px + (a.noise_mean * dt + (a.noise_std * dt) * (double)z0);
+      }
+      if (skyv > 0.f) {                                  // += np.random.poisson(master_sky) (:495)
+        // master_sky *= bg_count is an in-place float32 multiply (:493)
+        const float lam = skyv * s_c[r];
+        if (ALIAS) {
+          if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[a.sky_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
+        } else {
+          px = px + (double)s_tab[r][tid];
+        }
+      }
+      px = px * inv_g;               // electrons -> DN (:507-511)
+    }
+    cum = cum + px;                  // cumulative_pixel_array += pixel_array_full (:378)
+    double v = cum;
+    float zd = 0.f, zr = 0.f;
+    const uint32_t w0 = rn.next(), w1 = rn.next();
+    if (rdn || ld_dark) bm_pair<FAST>(w0, w1, zd, zr);
+    if (interior) {
+      if (do_dark) {                 // detector.py:185-191
+        const double err = (de > 0.f) ? (double)de : (double)0.00001f;
+        v = v + ((double)ds + err * (double)zd);
+      }
+      if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4);
+      if (clip) v = fmin(fmax(v, kMinCounts), kMaxCounts);
+    } else {
+      v = 0.;                        // reset_reference_pixels (exposure.py:122-131)
+    }
+    v = v + z;                       // add_zero_read (exposure.py:94-104)
+    if (rdn) v = v + kReadNoise * (double)zr;   // add_read_noise (detector.py:193-198)
+    out[(size_t)(r + 1) * SS + p] = (OutT)v;
+  }
+}
+
+}  // namespace wayne
