@@ -184,7 +184,7 @@ void wayne_oracle_poisson_sky_step(const float *lam, int64_t n, uint32_t *state,
 }
 
 /* ---- sky background through shared alias tables -------------------------
- * (device: wayne_amd/csrc/kernels.h sky_draw; reference call site
+ * (device: wayne_amd/csrc/k_ramp.h sky_draw; reference call site
  *  exposure_generator.py:488-495, pixel += poisson(master_sky * bg_count)).
  * Poisson(sky_px * bg) = Poisson(level * bg) + Poisson((sky_px - level) * bg):
  * the first term from a Walker alias table shared by all pixels of one sky

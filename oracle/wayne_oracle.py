@@ -443,7 +443,7 @@ class PhiloxDraws(object):
         return lam >= 0. and lam + 8. * np.sqrt(lam) + 8. <= 255.
 
     def begin_sky(self, unit_sky, bg_counts):
-        """Plan the sky draws of an exposure (device: wayne_exposure_run_back + kernels.h sky_draw):
+        """Plan the sky draws of an exposure (device: wayne_exposure_upload + k_ramp.h sky_draw):
         L levels of the master sky per distinct read interval, one alias table of
         Poisson(level * bg_count) each; used when every table fits 256 entries."""
         unit = np.asarray(unit_sky, dtype=np.float32)
