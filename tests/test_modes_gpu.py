@@ -117,6 +117,48 @@ def test_g102_flat_quirk_switch():
     assert np.abs(frames[True] - frames[False]).max() > 1e-3      # the two cubes differ
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_random_switch_combinations_against_oracle(case):
+    # a different configuration, number of sub-samples and set of detector switches each time: the device
+    # and the oracle read the same descriptor semantics whatever the combination (bit-exact replay thrower,
+    # exact samplers, Philox-keyed noise on both sides)
+    rng = np.random.default_rng(1000 + case)
+    name = ["tiny", "tiny128", "tiny_g102", "small256", "stare256"][case % 5]
+    K = None if name in ("small256", "stare256") else int(rng.integers(1, 9))
+    v = helpers.make_visit(name, **({} if K is None else {"K": max(K, v_min_k(name))}))
+    over = dict(add_flat=bool(rng.integers(2)), add_gain_variations=bool(rng.integers(2)),
+                add_non_linear=bool(rng.integers(2)), clip_values_det_limits=bool(rng.integers(2)),
+                add_initial_bias=bool(rng.integers(2)), add_dark=bool(rng.integers(2)),
+                add_read_noise=bool(rng.integers(2)), add_stellar_noise=bool(rng.integers(2)),
+                sky_background=[0.0, 0.4, 7.5][int(rng.integers(3))],
+                cosmic_rate=[None, 30.0][int(rng.integers(2))],
+                scale_factor=float(rng.uniform(0.5, 3.0)))
+    if rng.integers(2):
+        over.update(noise_mean=float(rng.uniform(0.5, 3.0)), noise_std=float(rng.uniform(0.1, 1.0)))
+    kw = v.frame_kwargs(0, **over)
+    pg = helpers.product_generator(v, 0)
+    eo = helpers.oracle_generator(v)
+    N = v.detector.light_sensitive_size(v.SUBARRAY)
+    got = np.stack([r[0] for r in pg.scanning_frame(threads=3, rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                    exact_samplers=True, **kw).reads])
+    want = np.stack(eo.scanning_frame(threads=3, draws=wo.PhiloxDraws(v.seed, 0, N), thrower="oracle",
+                                      **helpers.oracle_kwargs(kw)))
+    assert got.shape == want.shape
+    d = np.abs(got - want)
+    bad = int((d > 1e-3 + 1e-6 * np.abs(want)).sum())
+    if over["add_stellar_noise"]:
+        # one differing Poisson count re-numbers the electrons of that sub-sample in the replay thrower
+        assert bad <= 0.02 * got.size, (over, bad)
+    else:
+        assert bad <= 3e-4 * got.size, (over, bad)
+    assert np.median(d) < 1e-4
+
+
+def v_min_k(name):
+    # at least one sub-sample per read
+    return {"tiny": 3, "tiny128": 4, "tiny_g102": 2}.get(name, 1)
+
+
 def test_abi_error_paths():
     v = helpers.make_visit("tiny")
     eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
