@@ -6,19 +6,39 @@
 One "step" = one whole exposure (1014x1014 frame, NSAMP = 16, 128-sub-sample
 spatial scan, 1e9 electrons: BASELINE.json configs[3], the configuration the
 metric is quoted on) synthesised by the HIP path: k_prep_wl, k_prep_sub,
-k_throw, k_cosmic, k_ramp.  All inputs and calibration planes are resident in
-HBM before the timed region; outputs stay in HBM (device-complete rate).
-Exposures are independent: with N ranks each rank runs its own K exposures
-(round-robin exposure indices, no collective in the data path) -> weak scaling.
+k_throw || k_narrow, k_cosmic, k_ramp.  All inputs and calibration planes are
+resident in HBM before the timed region; outputs stay in HBM (device-complete
+rate).  Exposures are independent: with N ranks each rank runs its own K
+exposures (round-robin exposure indices, no collective in the data path) ->
+weak scaling.
 
-Prints ONE JSON line on rank 0 (the driver's contract) with two extra objects:
+Launching.  Under torchrun (RANK / WORLD_SIZE set) this process is one rank.
+Without it, `--gpus N` with N > 1 makes THIS process a launcher: before torch
+or HIP is touched it starts N fresh child processes (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set), waits for them and relays rank 0's
+JSON line; a line that does not report N ranks is an error.  The ranks meet
+over gloo for the barrier and the max-over-ranks of the elapsed time -- there
+is nothing for RCCL to do in this path.
+
+The timed region is repeated REPS times (each repetition = exactly K steps
+bracketed by a barrier + device synchronisation, max over ranks); `value` is
+the median repetition, the others are listed in `repetitions`.
+
+Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
   roofline      the fused up-the-ramp kernel k_ramp against the HBM roof
   cpu_baseline  the reference's C thrower + the numpy restatement of the host
                 loop, timed on this box's host cores on a bounded sample
+  per_electron / out_f64 / two_streams / delivered / end_to_end
+                the same workload measured like-for-like with the reference
+                (every electron thrown; float64 reads) and through the host
+                pipeline (PCIe-inclusive) -- never `value`
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +48,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16
+REPS = 5
 
 
 def ramp_bytes(N, S, R, out_bytes):
@@ -47,6 +69,19 @@ def survey_bytes(N, S, R, K, W, out_bytes, A_fp):
     return R * (12 * N * N + 28 * S * S + out_bytes * S * S) + (4 + out_bytes) * S * S + 8 * K * W + 16 * A_fp
 
 
+def csrc_hash():
+    """Hash of everything the HIP library is built from: profile-derived numbers are only quoted
+    while the kernels they were measured on are the kernels in the tree."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "wayne_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/wayne_hip.h"]:
+        p = os.path.normpath(os.path.join(d, f))
+        if os.path.isfile(p):
+            h.update(os.path.basename(p).encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(visit, budget_s=20.0):
     """Time the CPU structure of the reference on a bounded sample of exposure 0 of the
     workload and extrapolate to one exposure: per sub-sample one C thrower call + the
@@ -60,7 +95,6 @@ def cpu_baseline(visit, budget_s=20.0):
     thrower = clib.psf_reference if clib.have_ref() else clib.psf_oracle
     kw = visit.frame_kwargs(0)
     draws = wo.LegacyDraws(visit.seed)
-    N = 1014 if visit.SUBARRAY == 1024 else visit.SUBARRAY
     wl = kw["wl"]
     i0, i1 = wo.crop_spectrum_ind(gr.wl_limits[0], gr.wl_limits[1], wl.copy())
     s_wl = wl[i0:i1]
@@ -82,15 +116,18 @@ def cpu_baseline(visit, budget_s=20.0):
         pixel_array += frame
         return time.perf_counter() - t, float(np.sum(counts)), pixel_array
 
-    # choose the faster OpenMP team size on this box (the reference's default yml uses 4)
+    # the fastest OpenMP team size on this box among 1, 2, 4, ... host_cpus (the reference's yml uses 4;
+    # its scatter loop is serial, so more threads only speed up the normal generation)
     ncpu = os.cpu_count() or 1
-    best = None
-    for th in sorted(set([1, min(4, ncpu)])):
+    tried = {}
+    th = 1
+    while th <= ncpu:
         threads_used[0] = th
         dt, ne, _ = one_subsample(0)
-        if best is None or dt < best[0]:
-            best = (dt, th)
-    threads_used[0] = best[1]
+        tried[th] = dt
+        th *= 2
+    best = min(tried, key=tried.get)
+    threads_used[0] = best
     t_sub, n_sub, electrons, pixel_array = [], 0, 0.0, None
     t0 = time.perf_counter()
     while n_sub < visit.K and (time.perf_counter() - t0) < budget_s * 0.6:
@@ -111,13 +148,48 @@ def cpu_baseline(visit, budget_s=20.0):
     t_post = (time.perf_counter() - t) / saved_R
     R = visit.NSAMP - 1
     per_exposure = float(np.mean(t_sub)) * visit.K + (t_read + t_post) * R
-    return {"value": 1.0 / per_exposure, "unit": "exposures/s", "cores": int(threads_used[0]), "kind": kind,
+    return {"value": 1.0 / per_exposure, "unit": "exposures/s", "cores": int(best), "kind": kind,
             "sample": "%s exposure 0: %d of %d sub-samples (%.3g electrons, %.2f s each: C thrower threads=%d + "
                       "numpy passes), 1 of %d per-read stages (%.2f s), post-ramp stage on 2 reads (%.2f s/read); "
                       "extrapolated to one exposure = %.1f s" % (visit.name, n_sub, visit.K, electrons,
-                                                                 float(np.mean(t_sub)), threads_used[0], R, t_read,
+                                                                 float(np.mean(t_sub)), best, R, t_read,
                                                                  t_post, per_exposure),
-            "host_cpus": ncpu, "thrower_electrons_per_s": electrons / float(np.sum(t_sub))}
+            "host_cpus": ncpu, "threads_tried_s_per_subsample": {str(k): round(v, 3) for k, v in tried.items()},
+            "thrower_electrons_per_s": electrons / float(np.sum(t_sub))}
+
+
+# ---------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ---------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Start n fresh rank processes (nothing in THIS process has touched torch or HIP), wait for them, relay
+    rank 0's JSON line.  Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), WAYNE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        sys.stdout.write(out0 or "")
+        return 1
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n or line.get("ranks_reported") != n:
+        sys.stderr.write("bench.py: --gpus %d but the line reports n_gpus=%s, ranks_reported=%s\n" % (
+            n, line.get("n_gpus"), line.get("ranks_reported")))
+        return 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -127,46 +199,49 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--out-f64", action="store_true", help="float64 reads (the reference's dtype)")
+    ap.add_argument("--out-f64", action="store_true", help="float64 reads (the reference's dtype) in the timed region")
     ap.add_argument("--thrower", default="split", choices=["split", "electron"],
                     help="split: narrow PSF component drawn as a multinomial (WAYNE_RNG_SPLIT, same distribution); "
                          "electron: every electron thrown individually (WAYNE_RNG_PHILOX)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="HIP streams in the timed region (1: kernels never co-run, so per-kernel event times are "
-                         "clean; the 2-stream rate is reported separately as two_streams)")
+                    help="HIP streams in the timed region (1: kernels of different exposures never co-run, so "
+                         "per-kernel event times are clean; the 2-stream rate is reported separately as two_streams)")
     ap.add_argument("--no-extra-pass", action="store_true",
-                    help="skip the additional two-stream pass (use under rocprofv3 so that the kernel statistics "
+                    help="skip the passes after the timed region (use under rocprofv3 so that the kernel statistics "
                          "cover the timed region only)")
     args = ap.parse_args()
-    os.environ["WAYNE_STREAMS"] = "2"        # the context always owns two streams; slots select them
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    os.environ["WAYNE_STREAMS"] = "2"        # the context always owns two streams; slots select them
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    n_gpus = max(world, 1)
+    n_gpus = world
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
     # one process per GPU; WAYNE_BENCH_SHARE_GPU=1 lets several ranks share device 0 (a rehearsal of the
-    # multi-process path on a one-GPU box, with the gloo backend since RCCL refuses duplicate devices)
+    # multi-process path on a one-GPU box)
     share = os.environ.get("WAYNE_BENCH_SHARE_GPU") == "1"
     device = 0 if share else local_rank
+    if device >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no GPU %d on this node (set WAYNE_BENCH_SHARE_GPU=1 to share device 0)" % (
+            rank, device))
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            # "nccl" is RCCL on ROCm; used for the barrier and the max-over-ranks of the elapsed time only
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", device))
+        # gloo: a barrier and a max-reduce of one double on the host -- the data path has no collective
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    from wayne_amd import _lib, calibration, detector, engine, grism, synthetic
+    from wayne_amd import _lib, calibration, detector, engine, grism, synthetic, visit as wvisit
+    from wayne_amd.exposure_generator import ExposureGenerator
 
     cal = calibration.CalibrationSet.synthetic(11)
     det = detector.WFC3_IR()
@@ -174,24 +249,22 @@ def main():
     gr = grism.G141(cal) if cfg["grism"] == "G141" else grism.G102(cal)
     total = args.warmup + args.steps
     # exposure j of this rank is exposure index rank + j * n_gpus of the visit (round-robin)
-    visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=min(total, 120) * n_gpus)
+    n_res = min(total, 120)      # exposures resident in HBM: one slot each (26 GB); a longer run cycles through them
+    visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=n_res * n_gpus)
     eng = engine.get_engine(device, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
     ctx = eng.ctx
-    # exposures resident in HBM: one slot each, at most 120 (26 GB); a longer run cycles through them again
-    n_res = min(total, 120)
 
-    from wayne_amd.exposure_generator import ExposureGenerator
-    out_dtype = np.float64 if args.out_f64 else np.float32
-    rng_mode = _lib.RNG_SPLIT if args.thrower == "split" else _lib.RNG_PHILOX
-    W = None
-    for j in range(n_res):
-        i = rank + j * n_gpus
-        eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
-                               device=device, seed=visit.seed, exposure_index=i)
-        desc = eg.build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode, **visit.frame_kwargs(i))
-        ctx.upload(j * (1 if args.streams == 2 else 2), desc)      # inputs resident in HBM before the timed region
-        W = desc.n_wl
-    ctx.synchronize()
+    def upload_all(stride, out_dtype, rng_mode):
+        W = None
+        for j in range(n_res):
+            i = rank + j * n_gpus
+            eg = ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
+                                   device=device, seed=visit.seed, exposure_index=i)
+            desc = eg.build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode, **visit.frame_kwargs(i))
+            ctx.upload(j * stride, desc)      # inputs resident in HBM before any timed region
+            W = desc.n_wl
+        ctx.synchronize()
+        return W
 
     def sync_all():
         ctx.synchronize()
@@ -199,33 +272,52 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def timed(slot_of, steps, warmup):
+        """Exactly `steps` exposures after `warmup` untimed ones, bracketed by barrier + synchronise;
+        returns the elapsed seconds (max over ranks)."""
+        for j in range(warmup):
+            ctx.run(slot_of(j))
+        sync_all()
+        t0 = time.perf_counter()
+        for j in range(warmup, warmup + steps):
+            ctx.run(slot_of(j))
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            dist.barrier()
+        return elapsed
+
+    out_dtype = np.float64 if args.out_f64 else np.float32
+    rng_mode = _lib.RNG_SPLIT if args.thrower == "split" else _lib.RNG_PHILOX
     # slot j runs on stream j % 2: with --streams 1 only even slots are used
     stride = 1 if args.streams == 2 else 2
+    W = upload_all(stride, out_dtype, rng_mode)
 
     def slot_of(j):
         return (j % n_res) * stride
 
-    for j in range(args.warmup):
-        ctx.run(slot_of(j))
-    sync_all()
     # timed region: HIP events around the roofline kernel only (every event pair costs a few microseconds
     # of stream time; the other kernels are timed in the breakdown pass below)
+    timed(slot_of, 0, args.warmup)
     ctx.profile_select(["k_ramp"])
     ctx.profile_enable(True)
     ctx.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
-    for j in range(args.warmup, total):
-        ctx.run(slot_of(j))
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    reps = [timed(slot_of, args.steps, 0) for _ in range(REPS)]
     prof_ramp = ctx.profile_get()
+    elapsed = float(np.median(reps))
+
+    ranks_reported = 1
+    if dist is not None:
+        got = [None] * world
+        dist.all_gather_object(got, (rank, args.steps))
+        ranks_reported = len(set(r for r, _ in got))
+        if ranks_reported != world or any(s != args.steps for _, s in got):
+            raise SystemExit("ranks disagree: %s" % (got,))
+
     # breakdown pass (not part of `value`): the same exposures again with every kernel timed
     ctx.profile_select(None)
     ctx.profile_reset()
@@ -237,52 +329,65 @@ def main():
     ctx.profile_enable(False)
     prof["k_ramp"] = {"launches": prof_ramp["k_ramp"]["launches"], "ms": prof_ramp["k_ramp"]["ms"]}   # timed region
 
-    # extra pass: the same exposures alternating over the context's two HIP streams
-    # (prep / ramp of one exposure co-run with the thrower of another)
-    two = None
-    if args.streams == 1 and n_gpus == 1 and not args.no_extra_pass:
-        for j in range(n_res):
-            ctx.upload(j, ExposureGenerator(det, gr, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY, calibration=cal,
-                                            device=device, seed=visit.seed, exposure_index=rank + j * n_gpus
-                                            ).build_descriptor(eng, out_dtype=out_dtype, rng_mode=rng_mode,
-                                                               **visit.frame_kwargs(rank + j * n_gpus)))
-        for j in range(args.warmup):
-            ctx.run(j % n_res)
-        sync_all()
-        t1 = time.perf_counter()
-        for j in range(args.warmup, total):
-            ctx.run(j % n_res)
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        two = args.steps / (time.perf_counter() - t1)
-        stride = 1
-
-    # delivered: the same exposures with their reads copied into pinned host memory (copy of exposure n
-    # overlapping the kernels of n + 1), as a visit driver consumes them
-    delivered = None
-    if two is not None and n_res >= 4:
-        pending = []
-        ring = 4                             # exposures in flight: their pinned buffers are allocated in the warm-up
-        for j in range(max(args.warmup, ring)):
-            ctx.run(j % ring)
-            ctx.fetch_async(j % ring)
-            ctx.wait(j % ring)
-        sync_all()
-        t2 = time.perf_counter()
-        for j in range(args.warmup, total):
-            slot = j % ring
-            ctx.run(slot)
-            ctx.fetch_async(slot)
-            pending.append(slot)
-            if len(pending) > 2:
-                ctx.wait(pending.pop(0))
-        while pending:
-            ctx.wait(pending.pop(0))
-        delivered = args.steps / (time.perf_counter() - t2)
-
     # sanity: the last exposure really produced a frame
-    reads = ctx.download(slot_of(total - 1) if two is None else (total - 1) % n_res)
+    reads = ctx.download(slot_of(total - 1))
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
+
+    extras = {}
+    if n_gpus == 1 and not args.no_extra_pass:
+        n_x = min(args.steps, 30)
+        out_mb = (eng.R + 1) * eng.S * eng.S * 4 / 1e6
+
+        def rate(sl, steps=n_x):
+            return steps / timed(sl, steps, args.warmup)
+
+        # (1) exposures alternating over the context's two HIP streams (prep / ramp of one under the thrower of the next)
+        if args.streams == 1:
+            upload_all(1, out_dtype, rng_mode)
+            extras["two_streams"] = {"value": rate(lambda j: j % n_res), "unit": "exposures/s",
+                                     "note": "same exposures alternating over two HIP streams"}
+        # (2) float64 reads, the reference's SCI dtype (exposure.py:133-214)
+        if not args.out_f64:
+            upload_all(2, np.float64, rng_mode)
+            extras["out_f64"] = {"value": rate(slot_of), "unit": "exposures/s",
+                                 "note": "float64 reads (%.0f MB written per exposure instead of %.0f), one stream" % (
+                                     2 * out_mb, out_mb)}
+        # (3) every electron thrown one by one, as the reference does (pyparallel_menu.c:87-108)
+        if args.thrower == "split":
+            upload_all(2, np.float32, _lib.RNG_PHILOX)
+            extras["per_electron"] = {"value": rate(slot_of), "unit": "exposures/s",
+                                      "note": "rng_mode PHILOX: all %.3g electrons thrown individually, f32 reads, "
+                                              "one stream" % (prof["electrons"] / max(n_break, 1))}
+            upload_all(2, np.float64, _lib.RNG_PHILOX)
+            extras["per_electron_f64"] = {"value": rate(slot_of), "unit": "exposures/s",
+                                          "note": "every electron thrown AND float64 reads: the reference's arithmetic "
+                                                  "shape, one stream"}
+        # (4) delivered: reads of resident exposures copied to pinned host memory through the VisitRunner pipeline
+        # (4 slots in rotation over both streams, device-to-host copies on the copy stream)
+        runner = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32)
+        upload_all(1, np.float32, _lib.RNG_SPLIT)
+        n_d = max(2 * n_x, 40)
+        runner.run_resident(8)                       # warm-up: pinned buffers are allocated on first use
+        sync_all()
+        t = time.perf_counter()
+        runner.run_resident(n_d)
+        dt = time.perf_counter() - t
+        extras["delivered"] = {"value": n_d / dt, "unit": "exposures/s", "GB_per_s": n_d * out_mb / dt / 1e3,
+                               "frac_of_pcie": n_d * out_mb / dt / 1e3 / PCIE_GBS,
+                               "note": "device-resident descriptors; reads copied to pinned host memory (PCIe-inclusive; "
+                                       "%.1f MB per exposure), VisitRunner pipeline" % out_mb}
+        # (5) end to end: descriptor build + upload + kernels + fetch per exposure, light curves on the device
+        runner_lc = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32, device_lc=True)
+        runner_lc.run(list(range(8)))
+        sync_all()
+        idx = [i % visit.n_exposures for i in range(n_d)]
+        t = time.perf_counter()
+        runner_lc.run(idx)
+        dt = time.perf_counter() - t
+        extras["end_to_end"] = {"value": n_d / dt, "unit": "exposures/s", "GB_per_s": n_d * out_mb / dt / 1e3,
+                                "frac_of_pcie": n_d * out_mb / dt / 1e3 / PCIE_GBS,
+                                "note": "per exposure: host descriptor (K-vectors) -> upload -> k_lightcurve + all kernels -> "
+                                        "reads in pinned host memory; VisitRunner, device light curves (no K x W upload)"}
 
     if rank == 0:
         N, S, R, K = eng.N, eng.S, eng.R, visit.K
@@ -299,6 +404,7 @@ def main():
         forked = args.thrower == "split" and os.environ.get("WAYNE_FORK_NARROW", "1") != "0"
         thrower_ms = throw_ms if forked else throw_ms + narrow_ms
         electrons = prof["electrons"] / max(n_break, 1)
+        rates = sorted(args.steps * n_gpus / e for e in reps)
         line = {
             "metric": "simulated WFC3-IR exposures/sec (1014x1014, NSAMP=16, spatial scan)",
             "value": args.steps * n_gpus / elapsed, "unit": "exposures/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -307,6 +413,11 @@ def main():
             "dtype": "f64 ramp arithmetic, f32 thrower, int32/int64 accumulation; %s reads" % (
                 "f64" if args.out_f64 else "f32"),
             "data": "synthetic",
+            "ranks_reported": ranks_reported,
+            "repetitions": {"n": REPS, "steps_each": args.steps, "values": [args.steps * n_gpus / e for e in reps],
+                            "median": rates[len(rates) // 2], "min": rates[0], "max": rates[-1],
+                            "note": "value = the median repetition; each is exactly `steps` exposures per rank between "
+                                    "barrier + synchronise, max over ranks"},
             "config": {"workload": "%s: %s spatial scan %g px/s, SUBARRAY=%d (frame %dx%d), %s NSAMP=%d, "
                                    "K=%d sub-samples, W=%d bins, %.3g electrons/exposure, all detector effects on "
                                    "(flat, sky, cosmic rays, gain, dark, non-linearity, clip, read noise), "
@@ -326,26 +437,33 @@ def main():
                         "electrons_per_s": electrons / (thrower_ms * 1e-3) if thrower_ms > 0 else None,
                         "note": "k_narrow runs beside k_throw on a side stream: the k_throw interval spans both"
                         if forked else "k_throw then k_narrow on one stream"},
-            "two_streams": None if two is None else {"value": two, "unit": "exposures/s",
-                                                     "note": "same exposures alternating over two HIP streams"},
-            "delivered": None if delivered is None else {
-                "value": delivered, "unit": "exposures/s",
-                "note": "reads copied to pinned host memory (PCIe-inclusive; %.1f MB per exposure)" % (
-                    (eng.R + 1) * eng.S * eng.S * (8 if args.out_f64 else 4) / 1e6)},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "k_ramp_traffic.json")
-        if os.path.exists(traffic_file):
-            t = json.load(open(traffic_file)).get("%s/%s" % (args.config, "f64" if args.out_f64 else "f32"))
-            if t:
-                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = t["source"]
-        issue_file = os.path.join(ROOT, "profiles", "valu_issue.json")
-        if os.path.exists(issue_file) and args.config == "cfg4" and args.thrower == "split":
-            # the thrower kernels are bound by VALU issue, not by HBM: committed PMC summary of this workload
-            v = json.load(open(issue_file))
-            line["thrower"]["valu_issue"] = {k: {"frac": x["valu_issue_frac"], "lane_utilisation": x["lane_utilisation"]}
-                                             for k, x in v["kernels"].items()}
-            line["thrower"]["valu_issue_source"] = "profiles/valu_issue.json (rocprofv3 --pmc SQ counters, profiles/r01/final_pmc_sq.json)"
+        line.update(extras)
+        # numbers that only a rocprofv3 --pmc run can give come from profiles/*.json, which
+        # scripts/collect_profiles.sh stamps with the hash of wayne_amd/csrc they were measured on: quoted only
+        # while that is the code in the tree
+        here = csrc_hash()
+        key = "%s/%s" % (args.config, "f64" if args.out_f64 else "f32")
+        tf = os.path.join(ROOT, "profiles", "k_ramp_traffic.json")
+        t = json.load(open(tf)) if os.path.exists(tf) else {}
+        if t.get(key) and t.get("csrc_hash") == here:
+            line["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = t[key]["source"]
+        else:
+            line["roofline"]["traffic_source"] = "null: " + (
+                "profiles/k_ramp_traffic.json was measured on csrc %s, the tree is %s" % (t.get("csrc_hash"), here)
+                if t else "no profiles/k_ramp_traffic.json")
+        vf = os.path.join(ROOT, "profiles", "valu_issue.json")
+        v = json.load(open(vf)) if os.path.exists(vf) else {}
+        if args.config == "cfg4" and args.thrower == "split":
+            if v.get("csrc_hash") == here:
+                line["thrower"]["valu_issue"] = {k: {"frac": x["valu_issue_frac"], "lane_utilisation": x["lane_utilisation"]}
+                                                 for k, x in v["kernels"].items()}
+                line["thrower"]["valu_issue_source"] = v.get("source", "profiles/valu_issue.json")
+            else:
+                line["thrower"]["valu_issue"] = None
+                line["thrower"]["valu_issue_source"] = "null: profiles/valu_issue.json was measured on csrc %s, the tree is %s" % (
+                    v.get("csrc_hash"), here)
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline(visit)
         else:

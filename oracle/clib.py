@@ -1,6 +1,7 @@
 """ctypes access to the oracle's C libraries.  TEST INFRASTRUCTURE ONLY.
 
-  libwayne_oracle.so        this repo's C restatement (oracle/psf_oracle.c, noise_oracle.c, split_oracle.c)
+  libwayne_oracle.so        this repo's C restatement (oracle/psf_oracle.c, noise_oracle.c, split_oracle.c,
+                            lc_oracle.c)
   _ref/libwayne_ref_psf.so  the reference's own wayne/pyparallel_menu.c compiled
                             unmodified by oracle/Makefile (present only where
                             /root/reference was available at build time, or
@@ -24,7 +25,8 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force=False):
     """(Re)build the oracle libraries with oracle/Makefile."""
-    srcs = [os.path.join(HERE, f) for f in ("psf_oracle.c", "noise_oracle.c", "split_oracle.c", "Makefile")]
+    srcs = [os.path.join(HERE, f) for f in ("psf_oracle.c", "noise_oracle.c", "split_oracle.c", "lc_oracle.c",
+                                             "Makefile")]
     stale = force or not os.path.exists(_ORACLE) or any(
         os.path.getmtime(s) > os.path.getmtime(_ORACLE) for s in srcs)
     if stale:
@@ -75,6 +77,12 @@ def lib():
                                              C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
         L.wayne_oracle_binomial_vec.restype = None
         L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+        L.wayne_oracle_lc_deficit.restype = None
+        L.wayne_oracle_lc_deficit.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_int, _f64p]
+        L.wayne_oracle_lc_hidden.restype = None
+        L.wayne_oracle_lc_hidden.argtypes = [C.c_int, _f64p, _f64p, _f64p]
+        L.wayne_oracle_lc_depths.restype = None
+        L.wayne_oracle_lc_depths.argtypes = [C.c_int, C.c_int, _f64p, C.c_void_p, _f64p, _f64p, C.c_int, _f64p]
         _lib = L
     return _lib
 
@@ -168,4 +176,39 @@ def philox4x32(ctr, key):
     key = np.ascontiguousarray(key, dtype=np.uint32)
     out = np.empty(4, dtype=np.uint32)
     lib().wayne_oracle_philox4x32(ctr, key, out)
+    return out
+
+
+def lc_deficit(z, p, ld, nodes=65):
+    """1 - transit flux, shape (len(z), len(p)): 2-D integration over the planet's disk (oracle/lc_oracle.c)."""
+    z = np.ascontiguousarray(z, dtype=np.float64).ravel()
+    p = np.ascontiguousarray(p, dtype=np.float64).ravel()
+    ld = np.ascontiguousarray(ld, dtype=np.float64)
+    assert ld.size == 4
+    out = np.empty((z.size, p.size))
+    lib().wayne_oracle_lc_deficit(z.size, p.size, z, p, ld, int(nodes), out)
+    return out
+
+
+def lc_hidden(z, p):
+    """Fraction of the planet's disk (radius p, separation z) inside the unit disk."""
+    z, p = np.broadcast_arrays(np.asarray(z, dtype=np.float64), np.asarray(p, dtype=np.float64))
+    zz, pp = np.ascontiguousarray(z).ravel(), np.ascontiguousarray(p).ravel()
+    out = np.empty(zz.size)
+    lib().wayne_oracle_lc_hidden(zz.size, zz, pp, out)
+    return out.reshape(z.shape)
+
+
+def lc_depths(z_tr, hidden, planet_spectrum, ld, nodes=65):
+    """planet_depths (K, W) of observation.py:349-355, 442-443 from the oracle's own model."""
+    z_tr = np.ascontiguousarray(z_tr, dtype=np.float64).ravel()
+    spec = np.ascontiguousarray(planet_spectrum, dtype=np.float64).ravel()
+    ld = np.ascontiguousarray(ld, dtype=np.float64)
+    hp = None
+    if hidden is not None:
+        hidden = np.ascontiguousarray(hidden, dtype=np.float64).ravel()
+        assert hidden.size == z_tr.size
+        hp = hidden.ctypes.data_as(C.c_void_p)
+    out = np.empty((z_tr.size, spec.size))
+    lib().wayne_oracle_lc_depths(z_tr.size, spec.size, z_tr, hp, spec, ld, int(nodes), out)
     return out

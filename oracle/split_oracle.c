@@ -175,7 +175,8 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
     if (n_wide < 0) n_wide = 0;
     if (n_wide > counts[b]) n_wide = counts[b];
     const int64_t n_narrow = counts[b] - n_wide;
-    const int split = split_min > 0 && n_narrow >= split_min && psf_sigmal[b] > 0.05 &&
+    /* (the chain counts in float32: bins beyond 2^24 narrow electrons stay with the per-electron thrower) */
+    const int split = split_min > 0 && n_narrow >= split_min && n_narrow <= 16777216 && psf_sigmal[b] > 0.05 &&
                       psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
     const float x = (float)x_pos[b], y = (float)y_pos[b];
     const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];

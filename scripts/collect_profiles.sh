@@ -1,9 +1,11 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh <tag>      -> gpurun_out/prof_<tag>/...
+#   bash scripts/collect_profiles.sh <tag> <commit>     -> gpurun_out/prof_<tag>/...
+# (<commit> = `git rev-parse HEAD` of the tree that was snapshotted: the GPU box has no .git)
 # kernel trace + stats, HBM traffic counters and SQ counters in SEPARATE passes (never --pmc with a trace).
 set -e
 TAG=${1:-final}
+COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -20,5 +22,7 @@ for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_THREAD_CYCLES_VA
 done
 python3 $R/scripts/summarize_pmc.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_hbm.json
 python3 $R/scripts/summarize_pmc.py $OUT/sq_* > $OUT/pmc_sq.json
+# the two files bench.py quotes, stamped with the commit and the hash of wayne_amd/csrc (copy them to profiles/)
+python3 $R/scripts/make_profile_stamps.py $OUT $COMMIT
 find $OUT -name "*_kernel_stats.csv" | head
 echo collected $OUT

@@ -30,3 +30,30 @@ def test_bench_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0
     assert d["value"] > 100 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0      # one GPU: value = 1000 / ms_per_step
+    # the like-for-like and host-pipeline numbers ride in the same line, and never replace `value`
+    rep = d["repetitions"]
+    assert rep["n"] >= 5 and len(rep["values"]) == rep["n"] and rep["min"] <= d["value"] <= rep["max"]
+    for key in ("per_electron", "per_electron_f64", "out_f64", "two_streams", "delivered", "end_to_end"):
+        assert d[key]["unit"] == "exposures/s" and d[key]["value"] > 10, key
+    assert d["per_electron"]["value"] < d["value"] and d["delivered"]["value"] < d["two_streams"]["value"]
+    assert 0 < d["end_to_end"]["frac_of_pcie"] < 1
+    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 1e8
+    assert "traffic_source" in d["roofline"]
+
+
+def test_launcher_refuses_a_rank_count_mismatch():
+    # CPU: under a launcher that set WORLD_SIZE, --gpus must agree with it (never a silent n_gpus = 1)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE (2) != --gpus (4)" in (out.stderr + out.stdout)
+
+
+def test_launcher_starts_n_ranks_and_fails_loudly_without_gpus():
+    # CPU: `--gpus 2` without WORLD_SIZE starts two rank processes; without a GPU both refuse, and the parent
+    # reports the failure instead of printing a one-GPU line
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert "rank exit codes" in out.stderr and "{" not in out.stdout

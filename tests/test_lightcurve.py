@@ -1,11 +1,93 @@
-"""Light curves.  pylightcurve is not installed, so the model is
-pinned by the analytic uniform-disk formula, a brute-force 2-D integration and known limits."""
+"""Light curves.  pylightcurve is not installed, so the checker is
+oracle/lc_oracle.c -- an independent 2-D integration of the Claret disk over the planet's area --
+pinned here to closed forms (uniform disk, the r^2 law, the small-planet limit of the quadratic law);
+the product's host model (wayne_amd/lightcurve.py) and the device kernel (k_lightcurve) are then
+compared with IT."""
 import numpy as np
 import pytest
 
+from oracle import clib
 from wayne_amd import lightcurve as lc
 
 LD = [0.800627, -0.757066, 0.897268, -0.384804]      # examples/...parameters.yml:26
+
+
+def lens_area(z, p):
+    """Area common to the unit disk and a disk of radius p at distance z (closed form)."""
+    z, p = np.broadcast_arrays(np.asarray(z, dtype=float), np.asarray(p, dtype=float))
+    out = np.zeros(z.shape)
+    inside = z <= 1 - p
+    out[inside] = np.pi * p[inside] ** 2
+    part = (z > 1 - p) & (z < 1 + p)
+    zz, pp = z[part], p[part]
+    k0 = np.arccos(np.clip((pp ** 2 + zz ** 2 - 1) / (2 * pp * zz), -1, 1))
+    k1 = np.arccos(np.clip((1 - pp ** 2 + zz ** 2) / (2 * zz), -1, 1))
+    out[part] = pp ** 2 * k0 + k1 - 0.5 * np.sqrt(np.maximum(4 * zz ** 2 - (1 + zz ** 2 - pp ** 2) ** 2, 0.0))
+    return out
+
+
+def test_oracle_uniform_disk_closed_form():
+    z = np.linspace(0, 1.4, 141) + 0.0037          # (off the exact contacts, where the arccos form below loses digits)
+    p = np.array([0.05, 0.12, 0.3])
+    got = clib.lc_deficit(z, p, [0, 0, 0, 0])
+    np.testing.assert_allclose(got, lens_area(z[:, None], p[None, :]) / np.pi, rtol=0, atol=1e-13)
+    assert got[-1].max() == 0.0 and got[0, 1] == pytest.approx(0.0144, abs=1e-15)
+    # at the contacts themselves: p^2 just inside, 0 just outside
+    for pp in p:
+        c = clib.lc_deficit(np.array([1 - pp, np.nextafter(1 - pp, 2), 1 + pp]), np.array([pp]), [0, 0, 0, 0])[:, 0]
+        np.testing.assert_allclose(c, [pp * pp, pp * pp, 0.0], rtol=0, atol=1e-13)
+
+
+def test_oracle_r2_law_closed_form():
+    # I = 1 - a4 (1 - mu^2) = 1 - a4 r^2: over a planet wholly inside the disk, int r^2 dA = pi p^2 (z^2 + p^2 / 2)
+    a4 = 0.6
+    z = np.array([0.0, 0.2, 0.5, 0.85])
+    p = np.array([0.05, 0.1, 0.15])
+    got = clib.lc_deficit(z, p, [0, 0, 0, a4])
+    zz, pp = z[:, None], p[None, :]
+    want = (pp ** 2 - a4 * pp ** 2 * (zz ** 2 + pp ** 2 / 2)) / (1 - a4 / 2)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
+
+
+def test_oracle_quadratic_law_small_planet_limit():
+    # quadratic law I = 1 - u1 (1 - mu) - u2 (1 - mu)^2 is the Claret law with a2 = u1 + 2 u2, a4 = -u2;
+    # a planet much smaller than the star blocks p^2 I(z) / (1 - u1/3 - u2/6), to O(p^2) relative
+    u1, u2 = 0.4, 0.25
+    ld = [0.0, u1 + 2 * u2, 0.0, -u2]
+    z = np.array([0.0, 0.3, 0.6, 0.9])
+    p = np.array([1e-3])
+    mu = np.sqrt(1 - z * z)
+    I = 1 - u1 * (1 - mu) - u2 * (1 - mu) ** 2
+    want = p[0] ** 2 * I / (1 - u1 / 3 - u2 / 6)
+    got = clib.lc_deficit(z, p, ld)[:, 0]
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    # the star's total flux the oracle normalises by: pi (1 - u1/3 - u2/6); a planet covering the star blocks it all
+    assert clib.lc_deficit(np.array([0.0]), np.array([1.0]), ld)[0, 0] == pytest.approx(1.0, abs=1e-12)
+
+
+def test_oracle_converged_and_hidden_fraction():
+    z = np.linspace(0, 1.15, 47)
+    p = np.array([0.1, 0.1215])
+    a, b = clib.lc_deficit(z, p, LD, nodes=65), clib.lc_deficit(z, p, LD, nodes=257)
+    assert np.abs(a - b).max() < 1e-14
+    zz, pp = z[:, None], p[None, :]
+    np.testing.assert_allclose(clib.lc_hidden(zz, pp), lens_area(zz, pp) / (np.pi * pp ** 2), rtol=0, atol=1e-7)
+    assert clib.lc_hidden(0.5, 0.1) == 1.0 and clib.lc_hidden(1.2, 0.1) == 0.0
+
+
+def test_host_model_against_oracle():
+    # the product's numpy model (24-node radial rule) against the oracle's 2-D integral, every z regime
+    rp = np.sqrt(0.0146)
+    z = np.concatenate([np.linspace(0, 1.2, 61), [1 - rp, 1 + rp, rp, 1.0]])
+    p = rp * np.array([0.9, 1.0, 1.1])
+    got = 1 - lc.transit_flux(z[:, None], p[None, :], LD)
+    np.testing.assert_allclose(got, clib.lc_deficit(z, p, LD), rtol=0, atol=5e-10)
+    spec = np.array([0.0144, 0.0146, 0.0149])
+    z_tr, hidden = np.array([0.3, 1.05, 11.0, 0.0]), np.array([0.0, 0.0, 1.0, 0.0])
+    np.testing.assert_allclose(lc.planet_depths(LD, spec, z_tr, hidden), clib.lc_depths(z_tr, hidden, spec, LD),
+                               rtol=0, atol=5e-10)
+    np.testing.assert_allclose(lc.uniform_overlap_fraction(z[:, None], p[None, :]),
+                               clib.lc_hidden(z[:, None], p[None, :]), rtol=0, atol=1e-7)
 
 
 def test_uniform_star_matches_lens_formula():
@@ -116,7 +198,7 @@ def test_observation_uses_heliocentric_times_when_it_knows_the_target():
 
 
 @pytest.mark.gpu
-def test_device_depth_matrix_matches_numpy(gpu_ctx):
+def test_device_depth_matrix_matches_oracle(gpu_ctx):
     import helpers
     from wayne_amd import _lib
     v = helpers.make_visit("small256")
@@ -136,7 +218,7 @@ def test_device_depth_matrix_matches_numpy(gpu_ctx):
     eng.ctx.run_back(0)
     from wayne_amd import tools
     i0, i1 = tools.crop_spectrum_ind(v.grism.wl_limits[0], v.grism.wl_limits[1], v.wl)
-    want = dd.host_matrix()[:, i0:i1]
+    want = clib.lc_depths(dd.z_tr, dd.hidden, dd.planet_spectrum[i0:i1], LD)     # oracle/lc_oracle.c
     assert got.shape == want.shape
     # float32 integrand on the device: a few 1e-9 of the flux
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-8)
@@ -172,7 +254,7 @@ def test_device_depths_interpolated_in_radius_ratio(gpu_ctx):
     got = eng.ctx.debug_depth(0)
     eng.ctx.run_back(0)
     i0, i1 = tools.crop_spectrum_ind(v.grism.wl_limits[0], v.grism.wl_limits[1], v.wl)
-    want = dd.host_matrix()[:, i0:i1]
+    want = clib.lc_depths(dd.z_tr, dd.hidden, dd.planet_spectrum[i0:i1], LD)     # oracle/lc_oracle.c
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-8)
     assert got[0].max() == 0.0 and got[5].min() > 0.01
     # a flat spectrum (one radius ratio for all wavelengths) takes the single-evaluation path
@@ -181,4 +263,5 @@ def test_device_depths_interpolated_in_radius_ratio(gpu_ctx):
     eng.ctx.run_front(0)
     got = eng.ctx.debug_depth(0)
     eng.ctx.run_back(0)
-    np.testing.assert_allclose(got, flat.host_matrix()[:, i0:i1], rtol=0, atol=2e-8)
+    np.testing.assert_allclose(got, clib.lc_depths(flat.z_tr, flat.hidden, flat.planet_spectrum[i0:i1], LD),
+                               rtol=0, atol=2e-8)

@@ -78,3 +78,50 @@ def test_host_draws_depend_only_on_seed_and_exposure():
     assert a[2].min() >= 0 and a[2].max() < 100000      # randint(0, 100000)
     z = np.concatenate([_lib.host_sample_draws(5, e, 4096)[0] for e in range(8)])
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+
+
+@pytest.mark.gpu
+def test_two_processes_generate_the_same_frames_as_one(tmp_path):
+    # the data-parallel axis of observation.py:403-405 with real frames: two processes (sharing device 0 on a
+    # one-GPU box) generate the round-robin shards of a 4-exposure visit; every frame equals, bit for bit, the
+    # one a single process generates -- the RNG counters carry the exposure index, nothing depends on the rank
+    import subprocess
+    import helpers
+    from wayne_amd import visit as wv
+    n_exp = 4
+    worker = os.path.join(ROOT, "tests", "_shard_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(n_exp), str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = {}
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        for name in z.files:
+            assert int(name[1:]) % 2 == r and int(name[1:]) not in got
+            got[int(name[1:])] = z[name]
+    assert sorted(got) == list(range(n_exp))
+    v = helpers.make_visit("tiny", n_exposures=n_exp)
+    single = wv.VisitRunner(v, device=0, out_dtype=np.float64).run(list(range(n_exp)), keep=True)
+    for i in range(n_exp):
+        np.testing.assert_array_equal(got[i], single[i])
+    assert np.abs(got[0] - got[1]).max() > 1.0
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    # `bench.py --gpus 2` without torchrun: the parent starts two rank processes itself (here both on device 0)
+    # and relays rank 0's line, which must report both ranks
+    import json
+    import subprocess
+    env = dict(os.environ, WAYNE_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reported"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 50 and abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["config"]["sharding"].startswith("round-robin")

@@ -34,7 +34,7 @@ class CalibrationSet(object):
         self.sens = {}        # grism -> (wl_um float64[n], val float64[n])
         self.pfl = None       # (1014, 1014) float32: pixel flat with the border cut (detector.py:203)
         self.lin = None       # (4, 1024, 1024) float32: c1..c4 (detector.py:58-67)
-        self.dark = {}        # (SUBARRAY, SAMPSEQ) -> (sci, err) each (n_reads_max, S, S) float32
+        self.dark = {}        # (SUBARRAY, SAMPSEQ) -> HDU list of the mode's super-dark (super_dark_hdus)
         self.dark_loader = None
         self.bias_256 = None  # (266, 266) float64
 
@@ -105,38 +105,64 @@ class CalibrationSet(object):
     def sensitivity(self, grism):
         return self.sens[grism]
 
-    def dark_frames(self, subarray, sampseq, read_times, detector=None):
-        """(sci, err), each (R, S, S) float32, for the R non-zero reads.
+    def super_dark_hdus(self, subarray, sampseq, detector=None):
+        """The mode's super-dark as the HDU list of the reference's file: [primary] + 5 extensions (SCI,
+        ERR, DQ, SAMP, TIME) per read, last read first, so that read NSAMP-index n has its SCI frame at
+        index -5 n and its error frame at -5 n + 1 (detector.py:183-190).  Entries are arrays or None.
+        This is DATA ACCESS only -- which frame belongs to which read is decided by the caller.
 
-        Real files: read i (1-based NSAMP index i+1) is HDU -5*(i+1) of the
-        mode's super-dark, its error the next HDU (detector.py:185-190).
-        Synthetic: 0.05 DN/s accumulated to the read time, error 0.02."""
-        R = len(read_times)
-        S = min(subarray + 10, 1024)
-        if self._synthetic_dark:
-            sci = np.empty((R, S, S), dtype=np.float32)
-            for r, t in enumerate(read_times):
-                sci[r] = 0.05 * t
-            return sci, np.full((R, S, S), 0.02, dtype=np.float32)
+        Synthetic: 0.05 DN/s with a +-20 % spatial pattern, error 0.02 with a +-50 % pattern and a
+        sprinkling of zero / negative error pixels (the reference replaces those by 1e-5)."""
         from .detector import WFC3_IR
-        det = detector or self._detector or WFC3_IR()
-        name = det.dark_file(subarray, sampseq)          # raises WFC3SimNoDarkFileError
-        h = fitsio.read(os.path.join(self._dir, name))
-        sci = np.stack([np.asarray(h[-5 * (i + 1)].data, dtype=np.float32) for i in range(1, R + 1)])
-        err = np.stack([np.asarray(h[-5 * (i + 1) + 1].data, dtype=np.float32) for i in range(1, R + 1)])
+        det = detector or getattr(self, "_detector", None) or WFC3_IR()
+        key = (subarray, sampseq)
+        if key in self.dark:
+            return self.dark[key]
+        if self._synthetic_dark:
+            times = det.modes_exp_table.get(subarray, {}).get(sampseq)
+            if not times:
+                det.dark_file(subarray, sampseq)                 # raises WFC3SimNoDarkFileError
+                raise ValueError("no exposure-time table for the mode")
+            S = min(subarray + 10, 1024)
+            yy, xx = np.mgrid[0:S, 0:S]
+            pat = (1.0 + 0.2 * np.sin(0.013 * yy + 0.5) * np.cos(0.017 * xx)).astype(np.float32)
+            err = (0.02 * (1.0 + 0.5 * np.cos(0.011 * (xx + 2 * yy)))).astype(np.float32)
+            err[(xx * 7 + yy * 13) % 997 == 0] = 0.0
+            err[(xx * 5 + yy * 11) % 1999 == 0] = -0.01
+            hdus = [None]
+            for t in [0.0] + list(times[:15]):                   # zero read + 15 reads, stored last read first
+                hdus[1:1] = [np.float32(0.05 * t) * pat, err, None, None, None]
+        else:
+            name = det.dark_file(subarray, sampseq)              # raises WFC3SimNoDarkFileError
+            hdus = [h.data for h in fitsio.read(os.path.join(self._dir, name))]
+        self.dark[key] = hdus
+        return hdus
+
+    def dark_frames(self, subarray, sampseq, read_times, detector=None):
+        """(sci, err), each (R, S, S) float32, for the R non-zero reads: read i (1-based NSAMP index
+        i + 1) is HDU -5 (i + 1) of the mode's super-dark, its error the next HDU (detector.py:185-190)."""
+        R = len(read_times)
+        h = self.super_dark_hdus(subarray, sampseq, detector)
+        sci = np.stack([np.asarray(h[-5 * (i + 1)], dtype=np.float32) for i in range(1, R + 1)])
+        err = np.stack([np.asarray(h[-5 * (i + 1) + 1], dtype=np.float32) for i in range(1, R + 1)])
         return sci, err
 
     def for_mode(self, grism, subarray, sampseq, read_times, add_initial_bias=True, detector=None,
-                 with_dark=True, flat_grism=None):
+                 with_dark=True, flat_grism=None, flat_shift=0):
         """Planes centre-cropped to the sub-array, as Context.set_calibration takes them.
         `flat_grism`: take the flat cube of another grism (the reference flat-fields G102 exposures with
-        the G141 cube, grism.py:428,453-454 -- `reference_quirks`)."""
+        the G141 cube, grism.py:428,453-454 -- `reference_quirks`).  `flat_shift`: roll the flat planes by
+        that many pixels down / right, so that frame pixel (y, x) finds the flat of (y - shift, x - shift)
+        with numpy's wrap-around: the reference's index offset (1014 - 1024) / 2 = -5 at the full array
+        (grism.py:362-363), kept only with `reference_quirks`."""
         N = 1014 if subarray == 1024 else subarray
         S = N + 10
         out = {"subarray": subarray, "n_reads": len(read_times)}
         fg = flat_grism or grism
         if fg in self.flat:
             out["flat"] = [np.ascontiguousarray(crop_central_box(p, N)) for p in self.flat[fg]]      # grism.py:406-407
+            if flat_shift:
+                out["flat"] = [np.ascontiguousarray(np.roll(p, (flat_shift, flat_shift), axis=(0, 1))) for p in out["flat"]]
         if self.pfl is not None:
             out["pfl"] = np.ascontiguousarray(crop_central_box(self.pfl, N))                          # detector.py:206-207
         if grism in self.sky:

@@ -90,6 +90,7 @@ struct PrepArgs {
 constexpr int kPrepThreads = 512;
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 constexpr int kSparseMax = 16;         // WAYNE_RNG_SPLIT: bins with fewer electrons are thrown lane-per-bin (k_narrow)
+constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
 
 __device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
   // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
       const uint32_t narrow = c - wide;
       const double sl = a.wa.sigl[w];
-      const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && sl > 0.05 &&
+      const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sl > 0.05 &&
                          sl * 6.5 <= (double)kNarrowR;
       // ... and a sparsely populated bin (long scans sampled finely: ~1 electron per bin and
       // sub-sample) is thrown whole by the lane that owns it in k_narrow, from the bin's own

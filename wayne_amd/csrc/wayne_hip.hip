@@ -72,6 +72,10 @@ struct Slot {
   size_t pinned_cap = 0;
   struct Misc { unsigned long long electrons; int status; int pad; };
   Misc* pinned_misc = nullptr;   // inside `pinned`: a copy into pageable memory would block the caller
+  // fetch_async copies on the context's copy stream: ev_ready = the slot's kernels are done, ev_copied = its
+  // reads are in `pinned`; the next k_ramp of the slot waits for ev_copied before it overwrites `out`
+  hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+  bool copy_pending = false;
   // sky alias tables of this exposure (k_ramp): device copy, pinned host copy, the lam_max they were built for
   DevBuf sky_tab;
   uint32_t* sky_tab_host = nullptr;
@@ -113,6 +117,10 @@ struct Slot {
     if (stage_ev) (void)hipEventDestroy(stage_ev);
     stage_ev = nullptr;
     stage_pending = false;
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
+    if (ev_copied) (void)hipEventDestroy(ev_copied);
+    ev_ready = ev_copied = nullptr;
+    copy_pending = false;
   }
 };
 
@@ -139,6 +147,9 @@ struct wayne_ctx {
   hipStream_t side[kStreams] = {nullptr, nullptr};
   hipEvent_t ev_fork[kStreams] = {nullptr, nullptr}, ev_join[kStreams] = {nullptr, nullptr};
   bool fork_narrow = true;
+  // device-to-host copies of finished exposures (fetch_async) have a stream of their own, so the kernels of the
+  // next exposures on a slot's stream never queue behind a 67 MB PCIe transfer
+  hipStream_t copy_stream = nullptr;
   int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
   std::string err;
   // grism
@@ -230,6 +241,7 @@ int sync_all(wayne_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->streams[i]));
     if (c->side[i]) HIP_TRY(c, hipStreamSynchronize(c->side[i]));
   }
+  if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   return WAYNE_OK;
 }
 
@@ -348,7 +360,8 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d) {
     if (d->rng_mode == WAYNE_RNG_SPLIT) {
       const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
       const double sl = poly3(g.p_sigl, x);
-      if (cnt - wide >= (double)kSplitMinHost && sl > 0.05 && sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
+      if (cnt - wide >= (double)kSplitMinHost && cnt - wide <= (double)kSplitMaxNarrow && sl > 0.05 &&
+          sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
       else if (cnt < (double)kSparseMax) cnt = 0.;                                                    // sparse bin: k_narrow
     }
     total += cnt;
@@ -536,6 +549,10 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
       c->fork_narrow = false;     // not fatal: k_narrow then follows k_throw on the main stream
   }
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) c->copy_stream = nullptr;
+  if (const char* e = std::getenv("WAYNE_COPY_STREAM")) {
+    if (std::atoi(e) == 0 && c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
+  }
   if (const char* e = std::getenv("WAYNE_FORK_NARROW")) c->fork_narrow = c->fork_narrow && std::atoi(e) != 0;
   if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
   if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
@@ -560,6 +577,7 @@ void wayne_ctx_destroy(wayne_ctx* c) {
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (int i = 0; i < kStreams; ++i) {
     (void)hipStreamDestroy(c->streams[i]);
     if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -632,7 +650,8 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
       if (rng_mode == WAYNE_RNG_SPLIT) {      // same rule as k_prep_sub
         const uint32_t wide = (uint32_t)std::min<int64_t>(std::max(nwide[i], 0), counts[i]);
         const uint32_t narrow = (uint32_t)counts[i] - wide;
-        if (narrow >= (uint32_t)kSplitMin && psf_sigmal[i] > 0.05 && psf_sigmal[i] * 6.5 <= (double)kNarrowR) {
+        if (narrow >= (uint32_t)kSplitMin && narrow <= kSplitMaxNarrow && psf_sigmal[i] > 0.05 &&
+            psf_sigmal[i] * 6.5 <= (double)kNarrowR) {
           nsplit[i] = (int32_t)narrow;
           thrown = wide;
           any_split = true;
@@ -813,6 +832,9 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   (void)hipSetDevice(c->device);
   use_slot_stream(c, slot);
   Slot& s = c->slots[slot];
+  // the slot is unusable until this call has succeeded: a failure half way leaves re-pointed views behind
+  s.uploaded = false;
+  s.front_done = false;
   int rc;
   const size_t KW = (size_t)K * W;
   {
@@ -912,6 +934,12 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   const wayne_exposure_desc& d = s.d;
   const int W = s.W, K = s.K, R = s.R, N = c->N, S = c->S;
   const size_t SS = (size_t)S * S;
+  if (s.copy_pending) {
+    // the previous reads and status word of this slot may still be on their way to the host (copy stream):
+    // nothing of the new exposure may touch them before (with >= 3 slots in rotation this never waits)
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_copied, 0));
+    s.copy_pending = false;
+  }
   if (s.acc_dirty) {
     HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
     s.acc_dirty = false;
@@ -1023,7 +1051,11 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.threads_compat = d.threads_compat;
     a.seed = d.seed; a.exposure = d.exposure_index; a.subsample0 = 0;
     a.flags = d.flags;
-    a.flat_off = (1014 - N) / 2;  // grism.py:363 (0 for the full array)
+    // grism.py:363: indices + (1014 - size) / 2 -- the same number as the frame offset 507 - SUBARRAY / 2
+    // (exposure_generator.py:630) for every sub-array, so the descriptor's sub_scale serves both: 0 for the
+    // full array, or the reference's -5 there when the caller keeps its quirks (the host then uploads the
+    // flat planes rolled by +5 px, numpy's wrap-around for the negative indices)
+    a.flat_off = d.sub_scale;
     a.flat_wmin = c->g.flat_wmin; a.flat_wmax = c->g.flat_wmax;
     a.flat_inv_range = 1.0 / (c->g.flat_wmax - c->g.flat_wmin);
     a.sub = s.sub.as<SubInfo>(); a.prefix = s.prefix.as<uint32_t>(); a.nwide = s.nwide.as<int32_t>();
@@ -1170,8 +1202,20 @@ int wayne_exposure_fetch_async(wayne_ctx* c, int slot) {
     s.pinned_cap = tail + 64;
   }
   s.pinned_misc = (Slot::Misc*)((char*)s.pinned + tail);
-  HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, c->stream));
+  hipStream_t cs = c->stream;
+  if (c->copy_stream) {
+    if (!s.ev_ready) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming));
+    if (!s.ev_copied) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(s.ev_ready, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, s.ev_ready, 0));
+    cs = c->copy_stream;
+  }
+  HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, cs));
+  HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, cs));
+  if (c->copy_stream) {
+    HIP_TRY(c, hipEventRecord(s.ev_copied, cs));
+    s.copy_pending = true;
+  }
   return WAYNE_OK;
 }
 
@@ -1182,7 +1226,8 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
   if (!s.uploaded || !s.pinned || !s.pinned_misc) return fail(c, WAYNE_E_STATE, "wait: fetch_async first");
   (void)hipSetDevice(c->device);
   use_slot_stream(c, slot);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->copy_stream && s.ev_copied) HIP_TRY(c, hipEventSynchronize(s.ev_copied));
+  else HIP_TRY(c, hipStreamSynchronize(c->stream));
   *host_reads = s.pinned;
   if (s.pinned_misc->status != 0)
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");

@@ -14,7 +14,7 @@ _engines = {}
 
 class Engine(object):
     def __init__(self, device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY,
-                 add_initial_bias=True, g102_flat_quirk=False):
+                 add_initial_bias=True, g102_flat_quirk=False, flat_shift=0):
         self.device = device
         self.grism, self.detector, self.calibration = grism, detector, calibration
         self.NSAMP, self.SAMPSEQ, self.SUBARRAY = NSAMP, SAMPSEQ, SUBARRAY
@@ -29,7 +29,8 @@ class Engine(object):
                            grism.psf_sigmal_poly.coeffs, grism.psf_sigmah_poly.coeffs,
                            sens_wl, sens_val, wmin, wmax)
         planes = calibration.for_mode(grism.name, SUBARRAY, SAMPSEQ, self.read_times,
-                                      add_initial_bias=add_initial_bias, detector=detector, flat_grism=flat_grism)
+                                      add_initial_bias=add_initial_bias, detector=detector, flat_grism=flat_grism,
+                                      flat_shift=flat_shift)
         self.has_dark = "dark_sci" in planes
         self.ctx.set_calibration(planes["subarray"], planes["n_reads"], flat=planes.get("flat"),
                                  pfl=planes.get("pfl"), sky=planes.get("sky"), lin=planes.get("lin"),
@@ -43,12 +44,15 @@ class Engine(object):
 
 def get_engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias=True,
                g102_flat_quirk=False):
-    """Cached engine per (device, grism, mode, calibration object)."""
+    """Cached engine per (device, grism, mode, calibration object).  `g102_flat_quirk` (the caller's
+    reference_quirks) selects the reference's flat handling: the G141 cube for G102 exposures, and at
+    SUBARRAY = 1024 its -5 px flat index offset (grism.py:362-363)."""
     quirk = bool(g102_flat_quirk) and grism.name == "G102"
-    key = (device, grism.name, NSAMP, SAMPSEQ, SUBARRAY, id(calibration), bool(add_initial_bias), quirk)
+    shift = 5 if (bool(g102_flat_quirk) and SUBARRAY == 1024) else 0
+    key = (device, grism.name, NSAMP, SAMPSEQ, SUBARRAY, id(calibration), bool(add_initial_bias), quirk, shift)
     eng = _engines.get(key)
     if eng is None:
-        eng = Engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias, quirk)
+        eng = Engine(device, grism, detector, calibration, NSAMP, SAMPSEQ, SUBARRAY, add_initial_bias, quirk, shift)
         _engines[key] = eng
     return eng
 

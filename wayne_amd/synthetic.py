@@ -176,6 +176,20 @@ class Visit(object):
         t = self.exp_start_days[i] + self.sample_mid_points / 86400e3
         return transit_shape(t)[:, None] * self.depth0[None, :]
 
+    # orbit of the synthetic planet for the device light curves (HD 209458 b-like: examples/...parameters.yml)
+    ORBIT = dict(period=3.524746, sma_over_rs=8.81, eccentricity=0.0, inclination=86.71, periastron=0.0)
+    LD = (0.800627, -0.757066, 0.897268, -0.384804)     # examples/...parameters.yml:26
+
+    def device_depths(self, i):
+        """The light-curve inputs of exposure i for the device (K orbit phases, the planet's spectrum,
+        four limb-darkening coefficients) instead of the K x W matrix of planet_signal(i): a physical
+        transit of the same depth spectrum (observation.py:293-357)."""
+        from . import lightcurve
+        t = self.exp_start_days[i] + self.sample_mid_points / 86400e3
+        z_tr, hidden = lightcurve.depth_inputs(mid_time=0.0, time_array=t, rp_white=np.sqrt(self.depth0.mean()),
+                                               **self.ORBIT)
+        return lightcurve.DeviceDepths(z_tr, hidden, self.depth0, self.LD)
+
     def scale_factor(self, i):
         return 1.0 - 0.002 * np.exp(-i / 6.0)     # a hook-like visit trend
 

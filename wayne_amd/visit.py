@@ -39,10 +39,15 @@ def descriptor_digest(desc):
 class VisitRunner(object):
     """Generate the exposures `indices` of a synthetic.Visit-like object on one GPU."""
 
-    def __init__(self, visit, device=0, out_dir=None, out_dtype=np.float32, frame_overrides=None):
+    DEPTH = 4     # exposures in flight: slots 0..3 in rotation, alternating over the context's two streams
+
+    def __init__(self, visit, device=0, out_dir=None, out_dtype=np.float32, frame_overrides=None, device_lc=False):
+        """`device_lc`: hand the device the K + W + 4 numbers of the light-curve model (visit.device_depths)
+        instead of a K x W transit-depth matrix computed on the host."""
         self.visit, self.device, self.out_dir = visit, device, out_dir
         self.out_dtype = out_dtype
         self.frame_overrides = frame_overrides or {}
+        self.device_lc = device_lc
         self.rng_mode = 2            # WAYNE_RNG_SPLIT
         self._eng = None
 
@@ -59,16 +64,22 @@ class VisitRunner(object):
                                  device=self.device, seed=v.seed, exposure_index=i,
                                  filename="%04d_raw.fits" % (i + 1))
 
+    def frame_kwargs(self, i):
+        over = dict(self.frame_overrides)
+        if self.device_lc:
+            over["planet_signal"] = self.visit.device_depths(i)
+        return self.visit.frame_kwargs(i, **over)
+
     def descriptor(self, i, eng=None):
         return self.generator(i).build_descriptor(eng, out_dtype=self.out_dtype, rng_mode=self.rng_mode,
-                                                  **self.visit.frame_kwargs(i, **self.frame_overrides))
+                                                  **self.frame_kwargs(i))
 
     def run(self, indices, keep=False, on_reads=None):
-        """Synthesise the given exposures as a pipeline over the context's two HIP streams and
-        pinned host buffers: while exposure n's kernels and its device-to-host copy run, the host
-        prepares and uploads exposure n+1 into the other slot.  `on_reads(i, reads)` is called with
-        a view of the pinned buffer (copy it to keep it); keep=True returns {index: copy};
-        FITS files are written when out_dir is set."""
+        """Synthesise the given exposures as a pipeline over the context's two HIP streams, its copy
+        stream and pinned host buffers: while the kernels of exposure n and the device-to-host copy of
+        exposure n-1 run, the host prepares and uploads exposure n+1 into the next slot.
+        `on_reads(i, reads)` is called with a view of the pinned buffer (copy it to keep it);
+        keep=True returns {index: copy}; FITS files are written when out_dir is set."""
         eng = self.engine()
         ctx = eng.ctx
         results = {}
@@ -82,13 +93,33 @@ class VisitRunner(object):
                 self._pool = None
         return results
 
+    def run_resident(self, n, on_reads=None):
+        """The same pipeline over descriptors that are ALREADY in slots 0..DEPTH-1 (uploaded by the
+        caller): n exposures, kernels + copy to pinned host memory, no host preparation or upload."""
+        ctx = self.engine().ctx
+        pending = []
+        for j in range(n):
+            slot = j % self.DEPTH
+            if len(pending) == self.DEPTH:
+                s_old = pending.pop(0)
+                reads = ctx.wait(s_old)
+                if on_reads is not None:
+                    on_reads(s_old, reads)
+            ctx.run(slot)
+            ctx.fetch_async(slot)
+            pending.append(slot)
+        for s_old in pending:
+            reads = ctx.wait(s_old)
+            if on_reads is not None:
+                on_reads(s_old, reads)
+
     def _run_pipeline(self, eng, ctx, indices, results, pending, keep, on_reads):
         for n, i in enumerate(indices):
-            slot = n % 2
+            slot = n % self.DEPTH
             gen = self.generator(i)
             desc = gen.build_descriptor(eng, out_dtype=self.out_dtype, rng_mode=self.rng_mode,
-                                        **self.visit.frame_kwargs(i, **self.frame_overrides))
-            if len(pending) == 2:          # the slot about to be reused must be drained first
+                                        **self.frame_kwargs(i))
+            if len(pending) == self.DEPTH:          # the slot about to be reused must be drained first
                 self._finish(ctx, pending.pop(0), results, keep, on_reads)
             ctx.upload(slot, desc)
             ctx.run(slot)                  # asynchronous on the slot's stream
