@@ -249,7 +249,7 @@ def main():
     gr = grism.G141(cal) if cfg["grism"] == "G141" else grism.G102(cal)
     total = args.warmup + args.steps
     # exposure j of this rank is exposure index rank + j * n_gpus of the visit (round-robin)
-    n_res = min(total, 120)      # exposures resident in HBM: one slot each (26 GB); a longer run cycles through them
+    n_res = max(min(total, 120), 4)   # exposures resident in HBM: one slot each (26 GB); a longer run cycles through them
     visit = synthetic.Visit(args.config, det, gr, cal, n_exposures=n_res * n_gpus)
     eng = engine.get_engine(device, gr, det, cal, visit.NSAMP, visit.SAMPSEQ, visit.SUBARRAY)
     ctx = eng.ctx
@@ -330,7 +330,7 @@ def main():
     prof["k_ramp"] = {"launches": prof_ramp["k_ramp"]["launches"], "ms": prof_ramp["k_ramp"]["ms"]}   # timed region
 
     # sanity: the last exposure really produced a frame
-    reads = ctx.download(slot_of(total - 1))
+    reads = ctx.download(slot_of(args.steps - 1))
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
 
     extras = {}
@@ -378,7 +378,7 @@ def main():
                                        "%.1f MB per exposure), VisitRunner pipeline" % out_mb}
         # (5) end to end: descriptor build + upload + kernels + fetch per exposure, light curves on the device
         runner_lc = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32, device_lc=True)
-        runner_lc.run(list(range(8)))
+        runner_lc.run([i % visit.n_exposures for i in range(8)])
         sync_all()
         idx = [i % visit.n_exposures for i in range(n_d)]
         t = time.perf_counter()

@@ -77,6 +77,8 @@ def lib():
                                              C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
         L.wayne_oracle_binomial_vec.restype = None
         L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+        L.wayne_oracle_xo_pairs.restype = None
+        L.wayne_oracle_xo_pairs.argtypes = [_u32p, C.c_int64, _u32p]
         L.wayne_oracle_lc_deficit.restype = None
         L.wayne_oracle_lc_deficit.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_int, _f64p]
         L.wayne_oracle_lc_hidden.restype = None

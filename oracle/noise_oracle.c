@@ -26,6 +26,8 @@
 
 void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t wayne_oracle_xo_next(uint32_t state[4]);
+void wayne_oracle_xo_next2(uint32_t state[4], uint32_t out[2]);
+float wayne_oracle_rev12(uint32_t x);
 
 /* A word source: either consecutive Philox blocks (counter word 1 = block
  * index) or a Philox-seeded xoshiro128+ state (`xo` != NULL). */
@@ -55,6 +57,19 @@ static uint32_t wo_next(wo_stream *s) {
   uint32_t v = s->buf[4 - s->have];
   s->have -= 1;
   return v;
+}
+
+/* A PAIR of words (the U, V of a rejection trial; angle and radius of a normal pair): one state transition
+ * of a seeded stream (device: SeededStream::next2), two consecutive words of a Philox stream. */
+static void wo_next2(wo_stream *s, uint32_t *a, uint32_t *b) {
+  if (s->xo) {
+    uint32_t w[2];
+    wayne_oracle_xo_next2(s->xo, w);
+    *a = w[0]; *b = w[1];
+    return;
+  }
+  *a = wo_next(s);
+  *b = wo_next(s);
 }
 
 static float wo_u01f(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
@@ -106,8 +121,10 @@ static double wo_poisson_d(double lam, wo_stream *rng) {
   const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
   const double vr = 0.9277 - 3.6224 / (b - 2.0);
   for (int it = 0; it < 256; ++it) {
-    const double U = wo_u01d(wo_next(rng)) - 0.5;
-    const double V = wo_u01d(wo_next(rng));
+    uint32_t wu, wv;
+    wo_next2(rng, &wu, &wv);
+    const double U = wo_u01d(wu) - 0.5;
+    const double V = wo_u01d(wv);
     const double us = 0.5 - fabs(U);
     const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
     if (us >= 0.07 && V <= vr) return k;
@@ -136,8 +153,10 @@ static float wo_poisson_f(float lam, wo_stream *rng) {
   const float invalpha = 1.1239f + 1.1328f / (b - 3.4f);
   const float vr = 0.9277f - 3.6224f / (b - 2.0f);
   for (int it = 0; it < 256; ++it) {
-    const float U = wo_u01f(wo_next(rng)) - 0.5f;
-    const float V = wo_u01f(wo_next(rng));
+    uint32_t wu, wv;
+    wo_next2(rng, &wu, &wv);
+    const float U = wo_u01f(wu) - 0.5f;
+    const float V = wo_u01f(wv);
     const float us = 0.5f - fabsf(U);
     const float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
     if (us >= 0.07f && V <= vr) return k;
@@ -242,16 +261,22 @@ void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const
   for (int64_t i = 0; i < n; ++i) {
     if (!(lam[i] > 0.0f)) { out[i] = 0.0; continue; }
     uint32_t *st = state + 4 * i;
-    const uint32_t w = wayne_oracle_xo_next(st);
+    uint32_t pair[2];
+    wayne_oracle_xo_next2(st, pair);      /* table word, and the first uniform of the remainder */
+    const uint32_t w = pair[0];
+    uint32_t wr = pair[1];
     const uint32_t col = w >> 24;
     const uint32_t entry = tables[(size_t)table_of[i] * 256 + col];
     float k = (float)(((w & 0xFFFFFFu) < (entry & 0xFFFFFFu)) ? col : (entry >> 24));
     /* the remainder in pieces of mean <= 16: Poisson variables add */
     float rest = lam[i] - lam_level[i];
+    int first = 1;
     while (rest > 0.0f) {
       const float part = rest < 16.0f ? rest : 16.0f;
       rest = rest - part;
-      float u = wo_u01f(wayne_oracle_xo_next(st));
+      if (!first) wr = wayne_oracle_xo_next(st);   /* further pieces: one more word each */
+      first = 0;
+      float u = wo_u01f(wr);
       float term = expf(-part);
       float j = 0.0f;
       for (int it = 0; it < 512 && u > term; ++it) {
@@ -265,14 +290,15 @@ void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const
   }
 }
 
-/* One Box-Muller pair per pixel from its next two stream words (fp32, libm). */
+/* One Box-Muller pair per pixel from its stream's next PAIR of words (fp32, libm): the angle from the top
+ * 23 bits of the first, the radius from the second. */
 void wayne_oracle_normal_step(int64_t n, uint32_t *state, float *z0, float *z1) {
   for (int64_t i = 0; i < n; ++i) {
-    const uint32_t w0 = wayne_oracle_xo_next(state + 4 * i);
-    const uint32_t w1 = wayne_oracle_xo_next(state + 4 * i);
-    const float ua = wo_u01f(w0), ub = wo_u01f(w1);
+    uint32_t w[2];
+    wayne_oracle_xo_next2(state + 4 * i, w);
+    const float ub = wo_u01f(w[1]);
     const float R = sqrtf(-2.0f * logf(ub));
-    const float ang = 6.283185307179586f * ua;
+    const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
     z0[i] = R * cosf(ang);
     z1[i] = R * sinf(ang);
   }

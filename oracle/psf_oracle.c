@@ -163,6 +163,36 @@ static inline uint32_t wo_xo_next(wo_xo *g) {
   return r;
 }
 
+/* Two words per state transition (device: SeededStream::next2): a = s0 + s3, the xoshiro128+ output, and
+ * b = s1 + s2, the same scrambler on the other two state words, both taken BEFORE the state advances. */
+static inline void wo_xo_next2(wo_xo *g, uint32_t *a, uint32_t *b) {
+  *b = g->s[1] + g->s[2];
+  *a = wo_xo_next(g);
+}
+
+void wayne_oracle_xo_next2(uint32_t state[4], uint32_t out[2]) {
+  wo_xo g;
+  memcpy(g.s, state, sizeof g.s);
+  wo_xo_next2(&g, &out[0], &out[1]);
+  memcpy(state, g.s, sizeof g.s);
+}
+
+/* n consecutive pairs of one stream (for the statistical tests of the pair output) */
+void wayne_oracle_xo_pairs(uint32_t state[4], int64_t n, uint32_t *out /* 2n */) {
+  wo_xo g;
+  memcpy(g.s, state, sizeof g.s);
+  for (int64_t i = 0; i < n; ++i) wo_xo_next2(&g, &out[2 * i], &out[2 * i + 1]);
+  memcpy(state, g.s, sizeof g.s);
+}
+
+/* The top 23 bits of a word as a float in [1, 2): the angle of a Box-Muller draw in revolutions + 1. */
+float wayne_oracle_rev12(uint32_t x) {
+  const uint32_t bits = (x >> 9) | 0x3f800000u;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
 uint32_t wayne_oracle_xo_next(uint32_t state[4]) {
   wo_xo g;
   memcpy(g.s, state, sizeof g.s);
@@ -176,8 +206,10 @@ uint32_t wayne_oracle_xo_next(uint32_t state[4]) {
  * exactly the reference's numbering, pyparallel_menu.c:87-108) belongs to
  * block e/128; the block's stream is xoshiro128+ seeded by Philox counter
  * (e/128, 0, subsample, exposure), key (seed, STAGE_THROW); electron j = e%128
- * of the block takes the stream's words 2j (angle) and 2j+1 (radius):
- *    z_x = R cos(2 pi u_a), z_y = R sin(2 pi u_a), R = sqrt(-2 ln u_b)
+ * of the block takes the stream's j-th PAIR of words (a: angle, b: radius):
+ *    u_a = top 23 bits of a / 2^23,  u_b = b 2^-32 + 2^-33,
+ *    R sigma = sqrt((-2 ln2 sigma^2) log2 u_b)         (= sqrt(-2 ln u_b) sigma)
+ *    x = fma(cos(2 pi u_a), R sigma, x_pos),  y = fma(sin(2 pi u_a), R sigma, y_pos)
  * in fp32 (the device uses v_sin/v_cos/v_log hardware approximations, so
  * device-vs-oracle agreement is "all but a ~1e-4 fraction of electrons land
  * in the same pixel", asserted and counted in tests/test_psf_gpu.py).
@@ -204,16 +236,14 @@ int wayne_oracle_psf_philox(const int32_t *counts, int size,
         const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
         wayne_oracle_philox4x32(ctr, key, g.s);
       }
-      const uint32_t ra = wo_xo_next(&g);
-      const uint32_t rb = wo_xo_next(&g);
-      const float ua = wo_u01(ra), ub = wo_u01(rb);
-      const float R = sqrtf(-2.0f * logf(ub));
-      const float ang = 6.283185307179586f * ua;
-      const float zx = R * cosf(ang), zy = R * sinf(ang);
+      uint32_t ra, rb;
+      wo_xo_next2(&g, &ra, &rb);
+      const float ang = 6.283185307179586f * (wayne_oracle_rev12(ra) - 1.0f);
       const float sig = (j < n_wide) ? psf_sigmah[b] : psf_sigmal[b];
-      /* explicit fma: the device contracts z*sig+pos into v_fma_f32 */
-      const int xp = wo_trunc_int((double)fmaf(zx, sig, x_pos[b]));
-      const int yp = wo_trunc_int((double)fmaf(zy, sig, y_pos[b]));
+      const float c = (-1.3862943611198906f * sig) * sig;
+      const float Rs = sqrtf(c * log2f(wo_u01(rb)));
+      const int xp = wo_trunc_int((double)fmaf(cosf(ang), Rs, x_pos[b]));
+      const int yp = wo_trunc_int((double)fmaf(sinf(ang), Rs, y_pos[b]));
       if (xp > 0 && xp < nr && yp > 0 && yp < nc) out[yp * nc + xp] += 1;
     }
   }

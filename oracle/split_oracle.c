@@ -33,6 +33,8 @@
 
 void wayne_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t wayne_oracle_xo_next(uint32_t state[4]);
+void wayne_oracle_xo_next2(uint32_t state[4], uint32_t out[2]);
+float wayne_oracle_rev12(uint32_t x);
 
 enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_STAGE_SPARSE = 10, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
 
@@ -83,8 +85,10 @@ float wayne_oracle_binomial_f(float n, float p, uint32_t state[4]) {
     const float fixed = (m + 0.5f) * logf((m + 1.0f) / (r * nm)) + so_fc(m) + so_fc(n - m);
     x = floorf(n * p + 0.5f);
     for (int it = 0; it < 256; ++it) {
-      const float U = so_u01(wayne_oracle_xo_next(state)) - 0.5f;
-      const float V = so_u01(wayne_oracle_xo_next(state));
+      uint32_t w[2];
+      wayne_oracle_xo_next2(state, w);        /* one pair of words per trial */
+      const float U = so_u01(w[0]) - 0.5f;
+      const float V = so_u01(w[1]);
       const float us = 0.5f - fabsf(U);
       const float k = floorf((2.0f * a / us + b) * U + c);
       if (us >= 0.07f && V <= vr) { x = k; break; }
@@ -206,13 +210,14 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
         const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
         wayne_oracle_philox4x32(ctr, key_t, g);
       }
-      const float ua = so_u01(wayne_oracle_xo_next(g));
-      const float ub = so_u01(wayne_oracle_xo_next(g));
-      const float R = sqrtf(-2.0f * logf(ub));
-      const float ang = 6.283185307179586f * ua;
+      uint32_t w[2];
+      wayne_oracle_xo_next2(g, w);            /* pair j of the block: angle, radius (wayne_oracle_psf_philox) */
+      const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
       const float sig = (j < n_wide) ? sh : sl;
-      const int xp = so_trunc(fmaf(R * cosf(ang), sig, x));
-      const int yp = so_trunc(fmaf(R * sinf(ang), sig, y));
+      const float c = (-1.3862943611198906f * sig) * sig;
+      const float Rs = sqrtf(c * log2f(so_u01(w[1])));
+      const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
+      const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
       if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
     }
     if (!split) continue;
@@ -232,11 +237,10 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
       left -= in_col;
       const int col = ic + so_cell_offset(c);
       float col_left = in_col;
-      float q_before = 1.0f;   /* rows: running 1 - sum of the masses visited (not the two tails) */
       for (int r = 0; r < SO_CELLS && col_left > 0.0f; ++r) {
-        const float m = wayne_oracle_binomial_f(col_left, so_clamp01(Q[r] / q_before), st);
+        /* row r given that none of the rows before it was hit: its mass over the two tails still unvisited */
+        const float m = wayne_oracle_binomial_f(col_left, so_clamp01(Q[r] / Qb[r]), st);
         col_left -= m;
-        q_before -= Q[r];
         const int row = jc + so_cell_offset(r);
         if (m > 0.0f && col > 0 && col < n && row > 0 && row < n) out[(size_t)row * n + col] += (int32_t)m;
       }

@@ -230,7 +230,13 @@ class Grism(object):
         flatfield[indices] = (f0[indices] + (f1[indices] * wl_array_norm) + (f2[indices] * wl_array_norm_2) +
                               (f3[indices] * wl_array_norm_3))
         if size is not None:
-            flatfield = crop_central_box(flatfield, min(size, 1014))
+            if size > 1014 and reference_quirks:
+                # crop_central_box(flatfield, 1024) is EMPTY in the reference (index -5: array[-5:5]) and the
+                # multiplication that follows raises; the crop it stands for -- cropped[y, x] =
+                # flatfield[y + off, x + off], as for every sub-array -- is a shift by off = -5 here
+                flatfield = np.roll(flatfield, (-off, -off), axis=(0, 1))
+            else:
+                flatfield = crop_central_box(flatfield, min(size, 1014))
         return flatfield
 
     def get_master_sky(self, size=None):

@@ -230,7 +230,8 @@ def test_noise_statistics_small256():
     reads = np.stack([r[0] for r in exp.reads])
     # reference pixels: pure read noise N(0, 14.1/2.35) on every read (exposure.py:61-68, 122-131)
     border = np.concatenate([reads[:, :5, :].ravel(), reads[:, -5:, :].ravel()])
-    assert abs(border.mean()) < 0.1 and abs(border.std() - 14.1 / 2.35) < 0.1
+    # (10640 border samples of sigma 6: the mean scatters by 0.058)
+    assert abs(border.mean()) < 0.25 and abs(border.std() - 14.1 / 2.35) < 0.15
     # zero read interior = clipped bias + read noise
     assert abs(np.median(reads[0][5:-5, 5:-5]) - np.median(np.clip(v.calibration.bias_256, -20, 78000)[5:-5, 5:-5])) < 2.0
     # sky-only corner far from the spectrum: mean of the first read = sky*dt/gain + dark, in DN

@@ -107,10 +107,13 @@ def test_cfg5_every_switch_on_same_counters():
 
 def test_cfg5_default_split_thrower_same_counters():
     # the production default (split thrower + alias-table sky) against oracle/split_oracle.c on the same counters;
-    # a moved electron shows as +-1 e- in two pixels of every later read
-    v, got, want, rec, orec = both("cfg5", K=16, thrower="split", rng_mode=_lib.RNG_SPLIT, scale_factor=40.0)
+    # a moved electron shows as +-1 e- in two pixels of every later read.  First without cosmic rays, so that the
+    # accumulators hold the thrower's electrons only (k_cosmic adds its hits to the same accumulators) ...
+    v, got, want, rec, orec = both("cfg5", K=16, thrower="split", rng_mode=_lib.RNG_SPLIT, scale_factor=40.0,
+                                   cosmic_rate=None)
     acc_o = np.stack(orec["acc"])
     total = acc_o.sum()
+    assert total > 5e7 and (rec["counts"] * 0.7 > 32).mean() > 0.5          # most bins take the multinomial path
     moved = np.abs(rec["acc"] - acc_o).sum() / 2
     flipped_bins = int((rec["counts"] != np.stack(orec["counts"])).sum())
     assert flipped_bins <= 3
@@ -120,6 +123,14 @@ def test_cfg5_default_split_thrower_same_counters():
     bad = int((d > 0.05 + 1e-6 * np.abs(want)).sum())
     assert bad <= (2e-3 if flipped_bins == 0 else 0.02) * got.size
     assert np.median(d) < 5e-3
+    # ... then with every switch of cfg5 on
+    v, got, want, rec, orec = both("cfg5", K=16, thrower="split", rng_mode=_lib.RNG_SPLIT, scale_factor=40.0)
+    flipped_bins = int((rec["counts"] != np.stack(orec["counts"])).sum())
+    d = np.abs(got - want)
+    bad = int((d > 0.05 + 1e-6 * np.abs(want)).sum())
+    assert flipped_bins <= 3 and bad <= (2e-3 if flipped_bins == 0 else 0.02) * got.size
+    assert np.median(d) < 5e-3
+    assert ((got[-1] - got[0]) > 3000).sum() > 500                           # the cosmic rays are there
 
 
 def test_cfg2_staring_every_switch_on():

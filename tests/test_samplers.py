@@ -292,3 +292,36 @@ def test_sky_plan_of_the_exposure_oracle():
     d2 = wo.PhiloxDraws(3, 1, 64)
     d2.begin_sky(unit, [400.0] * 3)
     assert d2._sky_plan is None
+
+
+def test_seeded_stream_pair_output():
+    # SeededStream::next2: a = s0 + s3 and b = s1 + s2 of ONE state transition.  The words of a pair and of
+    # consecutive pairs must behave as independent uniforms for what the path asks of them: the top bits that
+    # become floats (chi^2 on 64 x 64 cells of (a, b), of (b_t, a_t+1) and of (a_t, a_t+1)), means, and no linear
+    # correlation; streams seeded from neighbouring Philox counters must not track each other
+    L = clib.lib()
+    n = 1 << 21
+    st = np.ascontiguousarray(clib.philox4x32([7, 0, 3, 1], [1963, 2]))
+    w = np.empty(2 * n, dtype=np.uint32)
+    L.wayne_oracle_xo_pairs(st, n, w)
+    a, b = w[0::2], w[1::2]
+    for u, v in ((a, b), (b[:-1], a[1:]), (a[:-1], a[1:]), (b[:-1], b[1:])):
+        cells = np.bincount(((u >> 26).astype(np.int64) << 6) | (v >> 26).astype(np.int64), minlength=4096)
+        stat = ((cells - u.size / 4096.0) ** 2 / (u.size / 4096.0)).sum()
+        assert stats.chi2.sf(stat, 4095) > P_MIN
+        assert abs(np.corrcoef(u.astype(float), v.astype(float))[0, 1]) < 5 / np.sqrt(u.size)
+    for u in (a, b):
+        x = u.astype(float) / 2.0 ** 32
+        assert abs(x.mean() - 0.5) < 5 / np.sqrt(12.0 * n) and stats.kstest(x[:200000], "uniform").pvalue > P_MIN
+        # every bit is fair
+        for bit in (0, 1, 8, 16, 23, 31):
+            ones = int(((u >> bit) & 1).sum())
+            assert abs(ones - n / 2) < 5 * np.sqrt(n / 4)
+    # 4096 streams seeded from consecutive counters, first pair of each
+    first = np.empty((4096, 2), dtype=np.uint32)
+    for i in range(4096):
+        s_i = np.ascontiguousarray(clib.philox4x32([i, 0, 3, 1], [1963, 2]))
+        L.wayne_oracle_xo_pairs(s_i, 1, first[i])
+    x = first.astype(float) / 2.0 ** 32
+    assert stats.kstest(x[:, 0], "uniform").pvalue > P_MIN and stats.kstest(x[:, 1], "uniform").pvalue > P_MIN
+    assert abs(np.corrcoef(x[:-1, 0], x[1:, 0])[0, 1]) < 5 / 64.0

@@ -32,8 +32,10 @@ template <int FLUSH, bool FAST>
 __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   __shared__ int tile[kNarrowTile];
-  __shared__ float s_q[kNarrowCells][kNarrowThreads];   // row probabilities of each lane's bin
+  __shared__ float s_q[kNarrowCells][kNarrowThreads];   // CONDITIONAL row probabilities of each lane's bin (see below)
   __shared__ int s_box[4];
+  __shared__ float s_fc[10];                            // stirling_tail(0..9), indexed per lane in the rejection sampler
+  if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
   const int k = blockIdx.y;
   const int tid = threadIdx.x;
   const int w = blockIdx.x * kNarrowThreads + tid;
@@ -68,15 +70,22 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const bool any_multi = __any(n0 > 0);
   const float inv_s = 1.f / sg;
   if (any_multi) {
-    // row probabilities, centre-out: c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)
+    // rows, centre-out (c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)): what the chain needs of row c is the
+    // probability of landing in it GIVEN that none of the rows before it was hit, mass_c / (mass not yet visited) --
+    // the same for every column of the bin (x and y are independent), so it is computed once, here, with the
+    // not-yet-visited mass taken as the sum of the two remaining tails (a running 1 - sum would lose the far rows
+    // to cancellation)
     {
       const float f = y - (float)jc0;
       float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
       s_q[0][tid] = 1.f - up - lo;
       for (int c = 1; c < kNarrowCells; ++c) {
         const int d = (c + 1) >> 1;
-        if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); s_q[c][tid] = up - nx; up = nx; }
-        else       { const float nx = upper_tail(((float)d + f) * inv_s);       s_q[c][tid] = lo - nx; lo = nx; }
+        const float rem = up + lo;
+        float Q;
+        if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); Q = up - nx; up = nx; }
+        else       { const float nx = upper_tail(((float)d + f) * inv_s);       Q = lo - nx; lo = nx; }
+        s_q[c][tid] = fminf(fmaxf(M::div_(Q, rem), 0.f), 1.f);
       }
     }
   }
@@ -99,22 +108,19 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       float n_col = 0.f;
       if (n_rem > 0.f) {
         const float pc = fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
-        n_col = binomial<M>(n_rem, pc, rng);
+        n_col = binomial<M>(n_rem, pc, rng, s_fc);
         n_rem -= n_col;
       }
       if (!__any(n_col > 0.f)) continue;
       // rows of this column
-      float m_rem = n_col, qrem = 1.f;
+      float m_rem = n_col;
       for (int r = 0; r < kNarrowCells; ++r) {
         if (!__any(m_rem > 0.f)) break;
-        const float Q = s_q[r][tid];
         float m = 0.f;
         if (m_rem > 0.f) {
-          const float qc = fminf(fmaxf(M::div_(Q, qrem), 0.f), 1.f);
-          m = binomial<M>(m_rem, qc, rng);
+          m = binomial<M>(m_rem, s_q[r][tid], rng, s_fc);
           m_rem -= m;
         }
-        qrem -= Q;
         if (m > 0.f) {
           const int e = (r + 1) >> 1;
           const int rj = (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e);

@@ -77,14 +77,15 @@ constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
 // FAST uses the hardware units (sin / cos take revolutions, log is log2).
 template <bool FAST>
 __device__ __forceinline__ void bm_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
-  const float ua = u01f(w0), ub = u01f(w1);
+  // angle: the top 23 bits of w0 as a float in [1, 2) -- revolutions, one instruction -- radius from u01f(w1)
+  const float rev = rev12(w0), ub = u01f(w1);
   if (FAST) {
     const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
-    z0 = Rr * __builtin_amdgcn_cosf(ua);
-    z1 = Rr * __builtin_amdgcn_sinf(ua);
+    z0 = Rr * __builtin_amdgcn_cosf(rev);
+    z1 = Rr * __builtin_amdgcn_sinf(rev);
   } else {
     const float Rr = sqrtf(-2.0f * logf(ub));
-    const float ang = 6.283185307179586f * ua;
+    const float ang = 6.283185307179586f * (rev - 1.0f);
     z0 = Rr * cosf(ang);
     z1 = Rr * sinf(ang);
   }
@@ -128,8 +129,9 @@ __device__ __forceinline__ double nonlinear_response(double px, float c1, float 
 // ALIAS = false variant of k_ramp: Poisson(lam) per pixel by Knuth / PTRS (sky_counts below).
 template <class M, bool PIECES, class RNG>
 __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, float lam, RNG& rng) {
-  // shared part: N ~ Poisson(lam_level)
-  const uint32_t w = rng.next();
+  // shared part: N ~ Poisson(lam_level) from the first word of the pair, the remainder's first uniform from the second
+  uint32_t w, wr;
+  rng.next2(w, wr);
   const uint32_t idx = w >> 24;
   const uint32_t e = tab[idx];
   float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
@@ -140,7 +142,7 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   if (ld > 0.f) {
     for (;;) {
       const float piece = PIECES ? fminf(ld, kSkyPiece) : ld;
-      float u = M::u01(rng.next());
+      float u = M::u01(wr);
       float pk = M::exp_(-piece);
       float j = 0.f;
       for (int it = 0; it < 512; ++it) {
@@ -153,6 +155,7 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
       if (!PIECES) break;
       ld = ld - piece;
       if (!(ld > 0.f)) break;
+      wr = rng.next();           // further pieces: one more word each
     }
   }
   return k;
@@ -196,8 +199,8 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
         prod = prod * M::u01(rng.next());
         if (prod > enlam) kk = kk + 1.f; else done = kk;
       } else if (mode == 2) {
-        const uint32_t w1 = rng.next();
-        const uint32_t w2 = rng.next();
+        uint32_t w1, w2;
+        rng.next2(w1, w2);
         float k;
         if (ps.trial(w1, w2, k)) done = k;
       }
@@ -214,7 +217,9 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
 // SKY: 0 = Poisson(lam) per pixel (sky_counts), 1 = alias tables + one-piece remainder, 2 = alias tables +
 // remainder in pieces (a master sky with hot pixels)
 template <class OutT, bool FAST, int SKY>
-__global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
+__global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ramp(RampArgs a) {
+  // (8 waves per SIMD = 64 VGPRs: the kernel hides its plane loads behind other waves' arithmetic; at 66 VGPRs
+  // and 7 waves it measured 0.116 ms instead of 0.108)
   constexpr bool ALIAS = SKY != 0;
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
@@ -267,7 +272,8 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
   if (!interior) z = 0.;
   {
     float zd, zr;
-    const uint32_t w0 = rn.next(), w1 = rn.next();
+    uint32_t w0, w1;
+    rn.next2(w0, w1);
     double v = z;
     if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }
     out[p] = (OutT)v;
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
       if (ld_dark) { ds_next = dsp[(size_t)(r + 1) * SS]; de_next = dep[(size_t)(r + 1) * SS]; }
     }
     double px = 0.;
-    const uint32_t g0 = do_noise ? rg.next() : 0u, g1 = do_noise ? rg.next() : 0u;
+    uint32_t g0 = 0u, g1 = 0u;
+    if (do_noise) rg.next2(g0, g1);
     if (interior) {
       accp[(size_t)r * SS] = 0;      // leave the accumulator clean for the next exposure
       px = (double)q * kInvQ;
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(kRampThreads) void k_ramp(RampArgs a) {
     cum = cum + px;                  // cumulative_pixel_array += pixel_array_full (:378)
     double v = cum;
     float zd = 0.f, zr = 0.f;
-    const uint32_t w0 = rn.next(), w1 = rn.next();
+    uint32_t w0, w1;
+    rn.next2(w0, w1);
     if (rdn || ld_dark) bm_pair<FAST>(w0, w1, zd, zr);
     if (interior) {
       if (do_dark) {                 // detector.py:185-191

@@ -103,6 +103,30 @@ __device__ __forceinline__ double flat_value(const ThrowArgs& a, const SubInfo& 
   return (double)(float)f;
 }
 
+// What the per-electron loop needs of a bin, as one 32-byte record (two LDS reads)
+struct ThrowBin {
+  float x, y;             // trace position (frame coordinates)
+  float ch, cl;           // -2 ln2 sigma_h^2, -2 ln2 sigma_l^2
+  uint32_t bin_end;       // first electron (sub-sample numbering) after this bin
+  uint32_t wide_end;      // first electron of the bin that takes sigma_l
+  uint32_t pad_[2];
+};
+
+__device__ __forceinline__ ThrowBin load_throw_bin(const uint32_t* P, const int32_t* NW, const double* XP, const double* YP,
+                                                   const double* sigl, const double* sigh, int b) {
+  ThrowBin r;
+  r.x = (float)XP[b]; r.y = (float)YP[b];
+  const float sh = (float)sigh[b], sl = (float)sigl[b];
+  r.ch = (-1.3862943611198906f * sh) * sh;
+  r.cl = (-1.3862943611198906f * sl) * sl;
+  const uint32_t start = P[b];
+  r.bin_end = P[b + 1];
+  // N = (int)(counts * ratio) may exceed the bin's count (ratio > 1: every electron wide, pyparallel_menu.c:89-98)
+  r.wide_end = start + min((uint32_t)max(NW[b], 0), r.bin_end - start);
+  r.pad_[0] = r.pad_[1] = 0;
+  return r;
+}
+
 template <int FLUSH>
 __device__ __forceinline__ void deposit_global(const ThrowArgs& a, const SubInfo& si, int x, int y, int n) {
   if (FLUSH == 0) {
@@ -195,18 +219,11 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   // different electrons, so nearly every iteration of a wave has some lane fetching a new bin --
   // from LDS that costs ~100 cycles instead of a ~1 us round trip to L2 / HBM)
   const bool p_cached = nb <= kThrowPCache;
-  __shared__ float s_par[RNG_MODE == 1 ? 4 * kThrowPCache : 4];
-  __shared__ int s_nw[RNG_MODE == 1 ? kThrowPCache : 4];
+  __shared__ ThrowBin s_bin[RNG_MODE == 1 ? kThrowPCache : 1];
   if (p_cached) {
     for (int i = tid; i < nb; i += kThrowThreads) s_P[i] = P[b0 + i];
     if (RNG_MODE == 1)
-      for (int i = tid; i < nb - 1; i += kThrowThreads) {
-        s_par[i] = (float)XP[b0 + i];
-        s_par[kThrowPCache + i] = (float)YP[b0 + i];
-        s_par[2 * kThrowPCache + i] = (float)a.sigl[b0 + i];
-        s_par[3 * kThrowPCache + i] = (float)a.sigh[b0 + i];
-        s_nw[i] = max(NW[b0 + i], 0);
-      }
+      for (int i = tid; i < nb - 1; i += kThrowThreads) s_bin[i] = load_throw_bin(P, NW, XP, YP, a.sigl, a.sigh, b0 + i);
   }
   // the workgroup's tile: trace positions of its first and last bin +- margin, clipped to the
   // sub-sample's rectangle (already inside [1, N)) and to the LDS budget
@@ -261,46 +278,51 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
       }
       b = lo; bin_start = P[b]; bin_end = P[b + 1];
     }
-    uint32_t wide_end = (RNG_MODE == 1 && p_cached) ? 0u : bin_start + (uint32_t)max(NW[b], 0);
+    uint32_t wide_end = (RNG_MODE == 1) ? 0u : bin_start + (uint32_t)max(NW[b], 0);
 
     if (RNG_MODE == 1) {
-      float x, y, sl, sh;
-      if (p_cached) {
-        const int i = b - b0;
-        x = s_par[i]; y = s_par[kThrowPCache + i]; sl = s_par[2 * kThrowPCache + i]; sh = s_par[3 * kThrowPCache + i];
-        wide_end = bin_start + (uint32_t)s_nw[i];
-      } else {
-        x = (float)XP[b]; y = (float)YP[b];
-        sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
-      }
-      while (e < e_end) {
-        // one seeded stream per block of kThrowBlock electrons
-        SeededStream rng(a.seed, STAGE_THROW, e / kThrowBlock, (uint32_t)k + a.subsample0, a.exposure);
-        const uint32_t blk_end = min(e_end, (e / kThrowBlock + 1u) * kThrowBlock);
-        for (; e < blk_end; ++e) {
-          if (e >= bin_end) {
-            if (p_cached) {
-              int i = b - b0;
-              do { ++i; bin_start = bin_end; bin_end = s_P[i + 1]; } while (bin_end <= e && i + 2 < nb);
-              b = b0 + i;
-              x = s_par[i]; y = s_par[kThrowPCache + i]; sl = s_par[2 * kThrowPCache + i]; sh = s_par[3 * kThrowPCache + i];
-              wide_end = bin_start + (uint32_t)s_nw[i];
+      // The lane throws its units (whole blocks of kThrowBlock electrons) one after the other.  Inside a
+      // block the loop counter is wave-uniform (a scalar); what differs between lanes is where the bin or
+      // the sigma changes, so each lane keeps ONE number -- `stop`, the in-block index of its next such
+      // event (or of the end of its electrons) -- and the per-electron work is the draw, the deposit and one
+      // compare.  The body of the event branch runs when some lane of the wave needs it (~1 in 6 iterations
+      // at ~350 wide electrons per bin) and is two LDS reads.
+      ThrowBin cur;
+      cur.x = cur.y = -1e30f; cur.ch = cur.cl = 0.f; cur.bin_end = bin_start; cur.wide_end = bin_start;
+      int bi = b - 1;                       // bin index of `cur`: the first event loads bin b
+      for (uint64_t u = ub; u < ue; ++u) {
+        const uint32_t e0 = (uint32_t)(u * kThrowBlock);
+        const uint32_t limit = min((uint32_t)kThrowBlock, E - e0);     // electrons of this block
+        SeededStream rng(a.seed, STAGE_THROW, (uint32_t)u, (uint32_t)k + a.subsample0, a.exposure);
+        uint32_t stop = 0;                  // force the event branch at j = 0
+        float c = 0.f, x = -1e30f, y = -1e30f;
+        for (uint32_t j = 0; j < kThrowBlock; ++j) {
+          if (j >= stop) {
+            const uint32_t e = e0 + j;
+            if (j >= limit) {               // past the last electron of the sub-sample: draw on, deposit nothing
+              x = y = -1e30f; c = 0.f; stop = 0xFFFFFFFFu;
             } else {
-              do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
-              wide_end = bin_start + (uint32_t)max(NW[b], 0);
-              x = (float)XP[b]; y = (float)YP[b];
-              sl = (float)a.sigl[b]; sh = (float)a.sigh[b];
+              while (e >= cur.bin_end && bi + 1 <= b1) {   // next populated bin
+                ++bi;
+                cur = p_cached ? s_bin[bi - b0] : load_throw_bin(P, NW, XP, YP, a.sigl, a.sigh, bi);
+              }
+              // the first n_wide electrons of a bin take the wide gaussian (pyparallel_menu.c:89-98)
+              const bool wide = e < cur.wide_end;
+              c = wide ? cur.ch : cur.cl;
+              x = cur.x; y = cur.y;
+              const uint32_t seg_end = wide ? cur.wide_end : cur.bin_end;
+              stop = min(seg_end - e0, limit);
+              if (e >= cur.bin_end) { x = y = -1e30f; c = 0.f; stop = 0xFFFFFFFFu; }   // inconsistent prefix: nothing to throw
             }
           }
-          const float ua = u01f(rng.next());
-          const float ub = u01f(rng.next());
-          // R = sqrt(-2 ln ub) = sqrt(-2 ln2 log2 ub); sin/cos take revolutions
-          const float R = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
-          const float zx = R * __builtin_amdgcn_cosf(ua);
-          const float zy = R * __builtin_amdgcn_sinf(ua);
-          const float sig = (e < wide_end) ? sh : sl;   // first N electrons: wide gaussian (:89-98)
-          const int xi = (int)fmaf(zx, sig, x);          // C truncation toward zero (:91-92)
-          const int yi = (int)fmaf(zy, sig, y);
+          uint32_t wa, wb;
+          rng.next2(wa, wb);
+          // Box-Muller with the sigma folded in: R sigma = sqrt(-2 ln(ub)) sigma = sqrt((-2 ln2 sigma^2) log2(ub));
+          // sin / cos take revolutions, and any window of length 1 will do: [1, 2) straight from the bits
+          const float rev = rev12(wa);
+          const float Rs = __builtin_amdgcn_sqrtf(c * __builtin_amdgcn_logf(u01f(wb)));
+          const int xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, x);   // C truncation toward zero (:91-92)
+          const int yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, y);
           const int lx = xi - tx0, ly = yi - ty0;
           // the tile lies inside [1, N) x [1, N), so this one test implies the
           // reference's 0 < pos < n bounds (:93) on the fast path

@@ -25,6 +25,7 @@ namespace wayne {
 template <class T> struct ExactMath;
 template <> struct ExactMath<float> {
   typedef float type;
+  static constexpr bool fast = false;
   static WAYNE_HD float u01(uint32_t x) { return u01f(x); }
   static WAYNE_HD float log_(float x) { return logf(x); }
   static WAYNE_HD float exp_(float x) { return expf(x); }
@@ -40,6 +41,7 @@ template <> struct ExactMath<float> {
 };
 template <> struct ExactMath<double> {
   typedef double type;
+  static constexpr bool fast = false;
   static WAYNE_HD double u01(uint32_t x) { return u01d(x); }
   static WAYNE_HD double log_(double x) { return log(x); }
   static WAYNE_HD double exp_(double x) { return exp(x); }
@@ -56,6 +58,7 @@ template <> struct ExactMath<double> {
 #if defined(__HIP_DEVICE_COMPILE__)
 struct FastMath {
   typedef float type;
+  static constexpr bool fast = true;
   static __device__ __forceinline__ float u01(uint32_t x) { return u01f(x); }
   static __device__ __forceinline__ float log_(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
   static __device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
@@ -156,8 +159,8 @@ WAYNE_HD typename M::type poisson(typename M::type lam, RNG& rng) {
   PtrsSetup<M> ps;
   ps.init(lam);
   for (int it = 0; it < 256; ++it) {
-    const uint32_t w1 = rng.next();
-    const uint32_t w2 = rng.next();
+    uint32_t w1, w2;
+    rng.next2(w1, w2);
     T k;
     if (ps.trial(w1, w2, k)) return k;
   }
@@ -181,17 +184,23 @@ static const double kStirlingSmall[10] = {
     0.0810614667953272,  0.0413406959554092, 0.0276779256849983, 0.02079067210376509, 0.0166446911898211,
     0.0138761288230707,  0.0118967099458917, 0.0104112652619720, 0.00925546218271273, 0.00833056343336287};
 
+// `small`: the table of the ten exact values in the caller's fastest memory (k_narrow keeps a float copy in LDS:
+// the lanes index it with different k, which from the constant array would be a global load per trial)
 template <class M>
-WAYNE_HD typename M::type stirling_tail(typename M::type k) {
+WAYNE_HD typename M::type stirling_tail(typename M::type k, const float* small = nullptr) {
   typedef typename M::type T;
-  if (k < (T)10) return (T)kStirlingSmall[(int)k];   // exact values for k = 0..9
+  if (k < (T)10) return small ? (T)small[(int)k] : (T)kStirlingSmall[(int)k];   // exact values for k = 0..9
   const T kp1 = k + (T)1;
+  if (M::fast) {   // one reciprocal instead of three divisions
+    const T r1 = M::div_((T)1, kp1), r2 = r1 * r1;
+    return r1 * ((T)(1.0 / 12) - r2 * ((T)(1.0 / 360) - r2 * (T)(1.0 / 1260)));
+  }
   const T kp1sq = kp1 * kp1;
   return M::div_((T)(1.0 / 12) - M::div_((T)(1.0 / 360) - M::div_((T)(1.0 / 1260), kp1sq), kp1sq), kp1);
 }
 
 template <class M, class RNG>
-WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& rng) {
+WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& rng, const float* small = nullptr) {
   typedef typename M::type T;
   if (!(n > (T)0) || !(p > (T)0)) return (T)0;
   if (p >= (T)1) return n;
@@ -223,11 +232,13 @@ WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& 
     const T r = M::div_(p, q);
     // the terms of the acceptance bound that do not depend on the trial
     const T nm = n - m + (T)1;
-    const T bound_m = (m + (T)0.5) * M::log_(M::div_(m + (T)1, r * nm)) + stirling_tail<M>(m) + stirling_tail<M>(n - m);
+    const T bound_m = (m + (T)0.5) * M::log_(M::div_(m + (T)1, r * nm)) + stirling_tail<M>(m, small) + stirling_tail<M>(n - m, small);
     x = M::floor_(n * p + (T)0.5);   // returned only if the (unreachable) iteration cap is hit
     for (int it = 0; it < 256; ++it) {
-      const T U = M::u01(rng.next()) - (T)0.5;
-      const T V = M::u01(rng.next());
+      uint32_t wu, wv;
+      rng.next2(wu, wv);
+      const T U = M::u01(wu) - (T)0.5;
+      const T V = M::u01(wv);
       const T us = (T)0.5 - M::abs_(U);
       const T k = M::floor_((M::div_((T)2 * a, us) + b) * U + c);
       if (us >= (T)0.07 && V <= vr) { x = k; break; }
@@ -235,7 +246,7 @@ WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& 
       const T v = M::log_(M::div_(V * alpha, M::div_(a, us * us) + b));
       const T nk = n - k + (T)1;
       const T ub = bound_m + (n + (T)1) * M::log_(M::div_(nm, nk)) +
-                   (k + (T)0.5) * M::log_(M::div_(r * nk, k + (T)1)) - stirling_tail<M>(k) - stirling_tail<M>(n - k);
+                   (k + (T)0.5) * M::log_(M::div_(r * nk, k + (T)1)) - stirling_tail<M>(k, small) - stirling_tail<M>(n - k, small);
       if (v <= ub) { x = k; break; }
     }
   }

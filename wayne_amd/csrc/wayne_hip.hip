@@ -72,10 +72,6 @@ struct Slot {
   size_t pinned_cap = 0;
   struct Misc { unsigned long long electrons; int status; int pad; };
   Misc* pinned_misc = nullptr;   // inside `pinned`: a copy into pageable memory would block the caller
-  // fetch_async copies on the context's copy stream: ev_ready = the slot's kernels are done, ev_copied = its
-  // reads are in `pinned`; the next k_ramp of the slot waits for ev_copied before it overwrites `out`
-  hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
-  bool copy_pending = false;
   // sky alias tables of this exposure (k_ramp): device copy, pinned host copy, the lam_max they were built for
   DevBuf sky_tab;
   uint32_t* sky_tab_host = nullptr;
@@ -117,10 +113,6 @@ struct Slot {
     if (stage_ev) (void)hipEventDestroy(stage_ev);
     stage_ev = nullptr;
     stage_pending = false;
-    if (ev_ready) (void)hipEventDestroy(ev_ready);
-    if (ev_copied) (void)hipEventDestroy(ev_copied);
-    ev_ready = ev_copied = nullptr;
-    copy_pending = false;
   }
 };
 
@@ -147,9 +139,6 @@ struct wayne_ctx {
   hipStream_t side[kStreams] = {nullptr, nullptr};
   hipEvent_t ev_fork[kStreams] = {nullptr, nullptr}, ev_join[kStreams] = {nullptr, nullptr};
   bool fork_narrow = true;
-  // device-to-host copies of finished exposures (fetch_async) have a stream of their own, so the kernels of the
-  // next exposures on a slot's stream never queue behind a 67 MB PCIe transfer
-  hipStream_t copy_stream = nullptr;
   int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
   std::string err;
   // grism
@@ -241,7 +230,6 @@ int sync_all(wayne_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->streams[i]));
     if (c->side[i]) HIP_TRY(c, hipStreamSynchronize(c->side[i]));
   }
-  if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   return WAYNE_OK;
 }
 
@@ -549,10 +537,6 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
       c->fork_narrow = false;     // not fatal: k_narrow then follows k_throw on the main stream
   }
-  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) c->copy_stream = nullptr;
-  if (const char* e = std::getenv("WAYNE_COPY_STREAM")) {
-    if (std::atoi(e) == 0 && c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
-  }
   if (const char* e = std::getenv("WAYNE_FORK_NARROW")) c->fork_narrow = c->fork_narrow && std::atoi(e) != 0;
   if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
   if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
@@ -577,7 +561,6 @@ void wayne_ctx_destroy(wayne_ctx* c) {
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
-  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (int i = 0; i < kStreams; ++i) {
     (void)hipStreamDestroy(c->streams[i]);
     if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -934,12 +917,6 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   const wayne_exposure_desc& d = s.d;
   const int W = s.W, K = s.K, R = s.R, N = c->N, S = c->S;
   const size_t SS = (size_t)S * S;
-  if (s.copy_pending) {
-    // the previous reads and status word of this slot may still be on their way to the host (copy stream):
-    // nothing of the new exposure may touch them before (with >= 3 slots in rotation this never waits)
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_copied, 0));
-    s.copy_pending = false;
-  }
   if (s.acc_dirty) {
     HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
     s.acc_dirty = false;
@@ -1202,20 +1179,11 @@ int wayne_exposure_fetch_async(wayne_ctx* c, int slot) {
     s.pinned_cap = tail + 64;
   }
   s.pinned_misc = (Slot::Misc*)((char*)s.pinned + tail);
-  hipStream_t cs = c->stream;
-  if (c->copy_stream) {
-    if (!s.ev_ready) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming));
-    if (!s.ev_copied) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(s.ev_ready, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, s.ev_ready, 0));
-    cs = c->copy_stream;
-  }
-  HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, cs));
-  HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, cs));
-  if (c->copy_stream) {
-    HIP_TRY(c, hipEventRecord(s.ev_copied, cs));
-    s.copy_pending = true;
-  }
+  // The copy follows the slot's kernels on the slot's own stream: while it runs (1.2 ms at 55 GB/s for a full
+  // frame) the kernels of the exposure in the next slot run on the other stream.  (A separate copy stream fed by
+  // events was measured: 660-700 exposures/s instead of 810-826 -- scripts/probe_pipeline.py.)
+  HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, c->stream));
   return WAYNE_OK;
 }
 
@@ -1226,8 +1194,7 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
   if (!s.uploaded || !s.pinned || !s.pinned_misc) return fail(c, WAYNE_E_STATE, "wait: fetch_async first");
   (void)hipSetDevice(c->device);
   use_slot_stream(c, slot);
-  if (c->copy_stream && s.ev_copied) HIP_TRY(c, hipEventSynchronize(s.ev_copied));
-  else HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   *host_reads = s.pinned;
   if (s.pinned_misc->status != 0)
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");

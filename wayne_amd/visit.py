@@ -39,7 +39,9 @@ def descriptor_digest(desc):
 class VisitRunner(object):
     """Generate the exposures `indices` of a synthetic.Visit-like object on one GPU."""
 
-    DEPTH = 4     # exposures in flight: slots 0..3 in rotation, alternating over the context's two streams
+    # exposures in flight: slots 0..DEPTH-1 in rotation, alternating over the context's two streams (an even number
+    # keeps the streams balanced; scripts/probe_pipeline.py: 2 -> 826 /s, 3 -> 646, 4 -> 809 for resident descriptors)
+    DEPTH = 4
 
     def __init__(self, visit, device=0, out_dir=None, out_dtype=np.float32, frame_overrides=None, device_lc=False):
         """`device_lc`: hand the device the K + W + 4 numbers of the light-curve model (visit.device_depths)
@@ -75,9 +77,9 @@ class VisitRunner(object):
                                                   **self.frame_kwargs(i))
 
     def run(self, indices, keep=False, on_reads=None):
-        """Synthesise the given exposures as a pipeline over the context's two HIP streams, its copy
-        stream and pinned host buffers: while the kernels of exposure n and the device-to-host copy of
-        exposure n-1 run, the host prepares and uploads exposure n+1 into the next slot.
+        """Synthesise the given exposures as a pipeline over the context's two HIP streams and pinned
+        host buffers: while the kernels of exposure n run on one stream and the device-to-host copy of
+        exposure n-1 on the other, the host prepares and uploads exposure n+1 into the next slot.
         `on_reads(i, reads)` is called with a view of the pinned buffer (copy it to keep it);
         keep=True returns {index: copy}; FITS files are written when out_dir is set."""
         eng = self.engine()
