@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 2
+#define WAYNE_ABI_VERSION 3
 
 /* status codes */
 #define WAYNE_OK 0
@@ -41,10 +41,11 @@ extern "C" {
 /* rng_mode */
 #define WAYNE_RNG_REPLAY 0 /* glibc rand_r streams + OpenMP partition of the reference: bit-exact */
 #define WAYNE_RNG_PHILOX 1 /* Philox-keyed streams, every electron thrown individually */
-#define WAYNE_RNG_SPLIT 2  /* production default, three routes by bin population: >= 32 narrow
-                              electrons -> the narrow component is ONE multinomial draw (binomial
-                              chains), the wide component is thrown as in mode 1; < 16 electrons ->
-                              the bin's own Philox blocks (one lane per bin); otherwise as mode 1.
+#define WAYNE_RNG_SPLIT 2  /* production default: a bin with >= 32 narrow electrons has its narrow
+                              component drawn as ONE multinomial (binomial chains, k_narrow); what is left
+                              to throw one by one -- its wide electrons, or the whole of a bin that does
+                              not qualify -- is thrown by the bin's own lane from the bin's own stream
+                              (k_lane), or, beyond 4096 such electrons, shared out as in mode 1.
                               Same distribution of the frame, several times less work            */
 
 /* wayne_exposure_desc.flags -- the keyword switches of
@@ -248,7 +249,7 @@ int wayne_exposure_run_back(wayne_ctx *ctx, int slot);
 
 /* ---- measurement ------------------------------------------------------- */
 
-#define WAYNE_PROF_KERNELS 7
+#define WAYNE_PROF_KERNELS 8
 typedef struct wayne_profile {
   /* per kernel: launches and total milliseconds measured with HIP events on
    * the context stream since wayne_profile_reset */

@@ -153,11 +153,11 @@ def psf_philox_oracle(counts, x, y, ratio, sl, sh, nr, nc, seed, exposure, subsa
     return out
 
 
-def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, split_min=32, sparse_max=16):
+def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, split_min=32, lane_max=4096):
     """The thrower's default mode (WAYNE_RNG_SPLIT) on the CPU, same counters as the device."""
     counts, x, y, ratio, sl, sh = _prep(counts, x, y, ratio, sl, sh)
     out = np.empty(n * n, dtype=np.int32)
-    rc = lib().wayne_oracle_psf_split(counts, counts.size, x, y, ratio, sl, sh, n, int(split_min), int(sparse_max),
+    rc = lib().wayne_oracle_psf_split(counts, counts.size, x, y, ratio, sl, sh, n, int(split_min), int(lane_max),
                                       int(seed), int(exposure), int(subsample), out)
     if rc != 0:
         raise ValueError("wayne_oracle_psf_split: status %d" % rc)

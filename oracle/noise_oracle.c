@@ -290,7 +290,7 @@ void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const
   }
 }
 
-/* One Box-Muller pair per pixel from its stream's next PAIR of words (fp32, libm): the angle from the top
+/* One Box-Muller pair per pixel from its stream's next PAIR of words (fp32, libm): the angle from the low
  * 23 bits of the first, the radius from the second. */
 void wayne_oracle_normal_step(int64_t n, uint32_t *state, float *z0, float *z1) {
   for (int64_t i = 0; i < n; ++i) {

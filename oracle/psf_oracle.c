@@ -185,9 +185,9 @@ void wayne_oracle_xo_pairs(uint32_t state[4], int64_t n, uint32_t *out /* 2n */)
   memcpy(state, g.s, sizeof g.s);
 }
 
-/* The top 23 bits of a word as a float in [1, 2): the angle of a Box-Muller draw in revolutions + 1. */
+/* The low 23 bits of a word as a float in [1, 2): the angle of a Box-Muller draw in revolutions + 1. */
 float wayne_oracle_rev12(uint32_t x) {
-  const uint32_t bits = (x >> 9) | 0x3f800000u;
+  const uint32_t bits = (x & 0x7fffffu) | 0x3f800000u;
   float f;
   memcpy(&f, &bits, 4);
   return f;
@@ -207,7 +207,7 @@ uint32_t wayne_oracle_xo_next(uint32_t state[4]) {
  * block e/128; the block's stream is xoshiro128+ seeded by Philox counter
  * (e/128, 0, subsample, exposure), key (seed, STAGE_THROW); electron j = e%128
  * of the block takes the stream's j-th PAIR of words (a: angle, b: radius):
- *    u_a = top 23 bits of a / 2^23,  u_b = b 2^-32 + 2^-33,
+ *    u_a = low 23 bits of a / 2^23,  u_b = b 2^-32 + 2^-33,
  *    R sigma = sqrt((-2 ln2 sigma^2) log2 u_b)         (= sqrt(-2 ln u_b) sigma)
  *    x = fma(cos(2 pi u_a), R sigma, x_pos),  y = fma(sin(2 pi u_a), R sigma, y_pos)
  * in fp32 (the device uses v_sin/v_cos/v_log hardware approximations, so

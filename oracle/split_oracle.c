@@ -36,7 +36,7 @@ uint32_t wayne_oracle_xo_next(uint32_t state[4]);
 void wayne_oracle_xo_next2(uint32_t state[4], uint32_t out[2]);
 float wayne_oracle_rev12(uint32_t x);
 
-enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_STAGE_SPARSE = 10, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
+enum { SO_STAGE_THROW = 2, SO_STAGE_NARROW = 9, SO_STAGE_LANE = 10, SO_WINDOW = 6, SO_CELLS = 2 * SO_WINDOW + 1 };
 
 static float so_u01(uint32_t x) { return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
 
@@ -152,24 +152,37 @@ static int so_trunc(float v) {
 /*
  * The whole thrower in split mode for one sub-sample.  Bins with at least
  * `split_min` narrow electrons (and 0.05 < sigma_l <= 6/6.5) hand them to the
- * multinomial.  Bins with fewer than `sparse_max` electrons are thrown from
- * their own counters: electron j takes words 2(j&1), 2(j&1)+1 of Philox block
- * (bin, j/2, sub-sample, exposure), stage SPARSE (a finely sampled scan has
- * ~1 electron per bin and sub-sample; the device gives such bins one lane
- * each).  Everything else -- the wide electrons of the split bins, and the
- * in-between bins whole -- is thrown one by one from STAGE_THROW streams
- * exactly as wayne_oracle_psf_philox does, numbered bin-major over the
- * electrons thrown that way.
+ * multinomial.  What is left to throw one by one -- the wide electrons of such a
+ * bin, or the whole of a bin that does not qualify -- is thrown from the bin's
+ * OWN streams when it is at most `lane_max` electrons (the device gives each bin a
+ * lane, k_lane): the j-th wide electron takes pair j of the xoshiro128+ stream
+ * seeded by Philox block (bin, 0, sub-sample, exposure), stage LANE, the j-th
+ * narrow one pair j of the stream seeded by block (bin, 1, ...).  Beyond `lane_max`
+ * the electrons are numbered bin-major over the bins thrown that way and drawn
+ * from the STAGE_THROW block streams exactly as wayne_oracle_psf_philox does.
+ * Either way: the first n_wide electrons of a bin take sigma_h
+ * (pyparallel_menu.c:89-107), same arithmetic as wayne_oracle_psf_philox.
  */
+static void so_throw_one(uint32_t g[4], float x, float y, float sig, int n, int32_t *out) {
+  uint32_t w[2];
+  wayne_oracle_xo_next2(g, w);            /* one pair per electron: angle, radius */
+  const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
+  const float c = (-1.3862943611198906f * sig) * sig;
+  const float Rs = sqrtf(c * log2f(so_u01(w[1])));
+  const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
+  const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
+  if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
+}
+
 int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos, const double *y_pos,
                            const double *psf_ratio, const double *psf_sigmal, const double *psf_sigmah,
-                           int n, int split_min, int sparse_max, uint32_t seed, uint32_t exposure,
+                           int n, int split_min, int lane_max, uint32_t seed, uint32_t exposure,
                            uint32_t subsample, int32_t *out) {
   if (size < 0 || n <= 0) return -1;
   memset(out, 0, (size_t)n * (size_t)n * sizeof(int32_t));
   const uint32_t key_t[2] = {seed, SO_STAGE_THROW};
   const uint32_t key_n[2] = {seed, SO_STAGE_NARROW};
-  const uint32_t key_s[2] = {seed, SO_STAGE_SPARSE};
+  const uint32_t key_l[2] = {seed, SO_STAGE_LANE};
   uint64_t e = 0;
   uint32_t g[4] = {0, 0, 0, 0};
   for (int b = 0; b < size; ++b) {
@@ -185,40 +198,25 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
     const float x = (float)x_pos[b], y = (float)y_pos[b];
     const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
 
-    if (!split && split_min > 0 && counts[b] > 0 && counts[b] < sparse_max) {
-      uint32_t w4[4] = {0, 0, 0, 0};
-      for (int j = 0; j < counts[b]; ++j) {
-        if ((j & 1) == 0) {
-          const uint32_t ctr[4] = {(uint32_t)b, (uint32_t)(j >> 1), subsample, exposure};
-          wayne_oracle_philox4x32(ctr, key_s, w4);
-        }
-        const float ua = so_u01(w4[2 * (j & 1)]), ub = so_u01(w4[2 * (j & 1) + 1]);
-        const float R = sqrtf(-2.0f * logf(ub));
-        const float ang = 6.283185307179586f * ua;
-        const float sig = (j < n_wide) ? sh : sl;
-        const int xp = so_trunc(fmaf(R * cosf(ang), sig, x));
-        const int yp = so_trunc(fmaf(R * sinf(ang), sig, y));
-        if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
-      }
-      continue;
-    }
-
     /* one by one */
     const int64_t thrown = split ? n_wide : counts[b];
-    for (int64_t j = 0; j < thrown; ++j, ++e) {
-      if ((e & 127u) == 0) {
-        const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
-        wayne_oracle_philox4x32(ctr, key_t, g);
+    if (split_min > 0 && thrown <= lane_max) {
+      const int64_t n_w = n_wide < thrown ? n_wide : thrown;
+      for (uint32_t part = 0; part < 2; ++part) {
+        const uint32_t ctr[4] = {(uint32_t)b, part, subsample, exposure};
+        uint32_t gl[4];
+        wayne_oracle_philox4x32(ctr, key_l, gl);
+        const int64_t cnt = part ? thrown - n_w : n_w;
+        for (int64_t j = 0; j < cnt; ++j) so_throw_one(gl, x, y, part ? sl : sh, n, out);
       }
-      uint32_t w[2];
-      wayne_oracle_xo_next2(g, w);            /* pair j of the block: angle, radius (wayne_oracle_psf_philox) */
-      const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
-      const float sig = (j < n_wide) ? sh : sl;
-      const float c = (-1.3862943611198906f * sig) * sig;
-      const float Rs = sqrtf(c * log2f(so_u01(w[1])));
-      const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
-      const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
-      if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
+    } else {
+      for (int64_t j = 0; j < thrown; ++j, ++e) {
+        if ((e & 127u) == 0) {
+          const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
+          wayne_oracle_philox4x32(ctr, key_t, g);
+        }
+        so_throw_one(g, x, y, (j < n_wide) ? sh : sl, n, out);
+      }
     }
     if (!split) continue;
 

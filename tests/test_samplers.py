@@ -150,7 +150,7 @@ def test_split_oracle_matches_per_electron_oracle_in_distribution():
     rng = np.random.default_rng(3)
     W, N = 60, 64
     counts = rng.integers(0, 4000, W).astype(np.int32)
-    counts[::7] = rng.integers(0, 40, counts[::7].size)        # sparse bins stay per-electron
+    counts[::7] = rng.integers(0, 40, counts[::7].size)        # thin bins are thrown whole, one by one
     x = np.linspace(8.3, 55.1, W)
     y = 30.2 + 0.01 * (x - 8)
     ratio = np.full(W, 0.22)
@@ -172,28 +172,35 @@ def test_split_oracle_matches_per_electron_oracle_in_distribution():
     assert 0.85 < z.std() < 1.15
 
 
-def test_split_oracle_sparse_bins_fall_back_to_per_electron_streams():
-    # below split_min narrow electrons nothing is split: identical to the per-electron oracle
+def test_split_oracle_unsplit_bins_without_lanes_are_the_per_electron_thrower():
+    # below split_min narrow electrons nothing is split; with the lane rule off (lane_max = 0) such bins are
+    # numbered and thrown exactly as the per-electron oracle does
     W, N = 30, 48
     counts = np.full(W, 30, np.int32)
     x = np.linspace(5.5, 40.5, W)
     y = np.full(W, 20.25)
     ratio = np.full(W, 0.2)
     sl, sh = np.full(W, 0.7), np.full(W, 2.5)
-    a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
+    a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1, lane_max=0)
     b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
     np.testing.assert_array_equal(a, b)
-    # a PSF too wide for the +-6 px window is never split either
+    # a PSF too wide for the +-6 px window is never split either; 5000 electrons exceed a lane's cap (4096),
+    # so these bins are shared out from the block streams: the per-electron thrower again
     counts[:] = 5000
     sl[:] = 1.0
     a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
     b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
     np.testing.assert_array_equal(a, b)
+    # ... and at 4000 electrons each bin is thrown from its own stream: a different sample of the same distribution
+    counts[:] = 4000
+    a = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=2, subsample=1)
+    b = clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 2, 1)
+    assert not np.array_equal(a, b) and abs(int(a.sum()) - int(b.sum())) < 6 * np.sqrt(b.sum())
 
 
-def test_split_oracle_sparse_bins_use_their_own_counters():
-    # bins with fewer than 16 electrons: per-bin Philox blocks (stage SPARSE).  Same distribution as
-    # the per-electron thrower; a bin's electrons do not depend on what the other bins hold.
+def test_split_oracle_lane_bins_use_their_own_streams():
+    # one-by-one electrons of a bin (here: thin bins thrown whole) come from the bin's own stream (stage LANE).
+    # Same distribution as the per-electron thrower; a bin's electrons do not depend on what the other bins hold.
     rng = np.random.default_rng(5)
     W, N = 400, 64
     counts = rng.integers(0, 16, W).astype(np.int32)
@@ -214,7 +221,7 @@ def test_split_oracle_sparse_bins_use_their_own_counters():
     assert big.sum() > 100
     assert abs(z.mean()) < 5 / np.sqrt(big.sum()) and 0.8 < z.std() < 1.2
     # with the rule switched off the same call is the per-electron thrower, bit for bit
-    off = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2, sparse_max=0)
+    off = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2, lane_max=0)
     np.testing.assert_array_equal(off, clib.psf_philox_oracle(counts, x, y, ratio, sl, sh, N, N, 3, 1, 2))
     # locality: emptying every other bin leaves the electrons of the remaining bins where they were
     one = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed=3, exposure=1, subsample=2)

@@ -103,9 +103,9 @@ def test_split_mode_against_oracle_same_counters(gpu_ctx, name, scale):
         assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
 
 
-def test_sparse_bins_against_oracle_same_counters(gpu_ctx):
-    # a finely sampled scan: 0-15 electrons per bin -> every bin is thrown by its own lane from its own
-    # Philox blocks (stage SPARSE); mixed with a few dense bins that take the other two routes
+def test_thin_bins_against_oracle_same_counters(gpu_ctx):
+    # a finely sampled scan: 0-15 electrons per bin -> every bin is thrown whole by its own lane from its own
+    # stream (stage LANE); mixed with a few dense bins whose narrow electrons take the multinomial
     from oracle import clib
     rng = np.random.default_rng(8)
     W, N = 5000, 256
@@ -121,7 +121,7 @@ def test_sparse_bins_against_oracle_same_counters(gpu_ctx):
         assert got.sum() == want.sum() == counts.sum()
         moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
         assert moved <= 2 + 5e-4 * counts.sum(), "%d of %d electrons moved" % (moved, counts.sum())
-    # only sparse bins: nothing is left for the per-electron kernel
+    # only thin bins: nothing for the multinomial, nothing for k_throw
     counts = rng.integers(0, 16, W).astype(np.int32)
     want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, 9, 1, 2)
     got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 9, rng_mode=_lib.RNG_SPLIT, exposure=1, subsample=2)
@@ -161,13 +161,36 @@ def test_split_mode_deterministic_sparse_and_edges(gpu_ctx):
     assert f[0, :].sum() == 0 and f[:, 0].sum() == 0                     # row / column 0 never populated (:93)
     ref = np.mean([gpu_ctx.psf_apply(*args[:-1], 50 + s, rng_mode=_lib.RNG_PHILOX).sum() for s in range(4)])
     assert abs(a.sum() - ref) < 6 * np.sqrt(ref)                         # same loss off the edges
-    # in-between bins (>= 16 electrons, < 32 of them narrow) are thrown one by one from the STAGE_THROW
-    # blocks: there the two modes coincide exactly
-    small = load_golden_psf("s64_t1")
-    c = np.clip(small["counts"] // 3, 16, 31).astype(np.int32)
-    s1 = gpu_ctx.psf_apply(c, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3, rng_mode=_lib.RNG_PHILOX)
-    s2 = gpu_ctx.psf_apply(c, small["x"], small["y"], small["ratio"], small["sl"], small["sh"], 64, 64, 3, rng_mode=_lib.RNG_SPLIT)
+    # a bin with more one-by-one electrons than a lane takes (4096) is shared out from the STAGE_THROW block
+    # streams: with a PSF too wide to split, the two modes then coincide exactly
+    from oracle import clib
+    W = 40
+    c = np.full(W, 5000, np.int32)
+    x, y = np.linspace(8.5, 50.5, W), np.full(W, 30.25)
+    ratio, sl, sh = np.full(W, 0.2), np.full(W, 1.0), np.full(W, 2.5)
+    s1 = gpu_ctx.psf_apply(c, x, y, ratio, sl, sh, 64, 64, 3, rng_mode=_lib.RNG_PHILOX)
+    s2 = gpu_ctx.psf_apply(c, x, y, ratio, sl, sh, 64, 64, 3, rng_mode=_lib.RNG_SPLIT)
     np.testing.assert_array_equal(s1, s2)
+    # mixed: heavy bins (k_throw), lane bins (k_lane) and split bins (k_narrow + k_lane) in one call, against the oracle
+    c[::3] = 3000
+    sl[::2] = 0.7
+    want = clib.psf_split_oracle(c, x, y, ratio, sl, sh, 64, 3, 0, 0)
+    got = gpu_ctx.psf_apply(c, x, y, ratio, sl, sh, 64, 64, 3, rng_mode=_lib.RNG_SPLIT)
+    assert abs(int(got.sum()) - int(want.sum())) <= 3
+    assert int(np.abs(got.astype(np.int64) - want).sum()) // 2 <= 2 + 2e-3 * want.sum()
+
+
+def test_bin_beyond_the_float32_chain_is_thrown_one_by_one(gpu_ctx):
+    # more than 2^24 narrow electrons in one bin: k_narrow's chain counts in float32, so such a bin is not split
+    # (and, far beyond a lane's cap, shared out by k_throw): every electron arrives
+    n, N = (1 << 24) + 12345, 64
+    f = gpu_ctx.psf_apply([n], [30.4], [33.6], [0.0], [0.6], [5.0], N, N, 4, rng_mode=_lib.RNG_SPLIT).reshape(N, N)
+    assert f.sum() == n
+    px, py = cell_probs(30.4, 0.6, 0, N), cell_probs(33.6, 0.6, 0, N)
+    expect = n * np.outer(py, px)
+    big = expect > 100
+    chi2 = ((f[big] - expect[big]) ** 2 / expect[big]).sum()
+    assert chi2 < big.sum() + 6 * np.sqrt(2 * big.sum()) + 20
 
 
 def test_exposure_split_vs_per_electron():

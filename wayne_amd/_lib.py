@@ -24,7 +24,7 @@ F_ADD_DARK = 1 << 6
 F_ADD_INITIAL_BIAS = 1 << 7
 F_OUT_F64 = 1 << 16
 F_EXACT_SAMPLERS = 1 << 17
-PROF_KERNELS = 7
+PROF_KERNELS = 8
 
 
 class WayneError(RuntimeError):
@@ -127,7 +127,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
-        if L.wayne_abi_version() != 2:
+        if L.wayne_abi_version() != 3:
             raise ImportError("libwayne_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -1,4 +1,4 @@
-// k_narrow: narrow PSF component as multinomials, sparse bins lane per bin
+// k_narrow: narrow PSF component as multinomials; k_lane: a bin's one-by-one electrons thrown by its own lane
 #pragma once
 #include "common.h"
 #include "k_throw.h"
@@ -36,16 +36,16 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   __shared__ int s_box[4];
   __shared__ float s_fc[10];                            // stirling_tail(0..9), indexed per lane in the rejection sampler
   if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
-  const int k = blockIdx.y;
+  const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
-  const int w = blockIdx.x * kNarrowThreads + tid;
+  const int w = (int)a.chunk_order[blockIdx.y] * kNarrowThreads + tid;
   const SubInfo si = a.sub[k];
-  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // > 0 multinomial, < 0 sparse bin
-  if (!__syncthreads_or(n0 != 0)) return;
+  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // narrow electrons of the bin's multinomial
+  if (!__syncthreads_or(n0 > 0)) return;
 
   float x = 0.f, y = 0.f, sg = 1.f;
   int ic0 = 0, jc0 = 0;
-  if (n0 != 0) {
+  if (n0 > 0) {
     x = (float)a.xpos[(size_t)k * a.W + w];
     y = (float)a.ypos[(size_t)k * a.W + w];
     sg = (float)a.sigl[w];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   // workgroup tile = bounding box of its bins' windows, clipped to [1, N)
   if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
   __syncthreads();
-  if (n0 != 0) {
+  if (n0 > 0) {
     atomicMin(&s_box[0], ic0 - kNarrowR); atomicMax(&s_box[1], ic0 + kNarrowR + 1);
     atomicMin(&s_box[2], jc0 - kNarrowR); atomicMax(&s_box[3], jc0 + kNarrowR + 1);
   }
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const int tarea = tw * th;
   for (int i = tid; i < tarea; i += kNarrowThreads) tile[i] = 0;
 
-  // (waves that hold only sparse or empty bins skip the multinomial altogether)
+  // (waves without a multinomial bin skip the work altogether)
   const bool any_multi = __any(n0 > 0);
   const float inv_s = 1.f / sg;
   if (any_multi) {
@@ -133,41 +133,120 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       }
     }
   }
-  // sparse bins: electron j of the bin takes words 2(j&1), 2(j&1)+1 of Philox block (w, j/2, k, exposure),
-  // stage STAGE_SPARSE; the first n_wide electrons get sigma_h as everywhere (pyparallel_menu.c:89-107)
-  {
-    const int cs = (n0 < 0) ? -n0 : 0;
-    int nw = 0;
-    float sh = 1.f;
-    if (cs > 0) { nw = max(a.nwide[(size_t)k * a.W + w], 0); sh = (float)a.sigh[w]; }
-    for (int j = 0; __any(j < cs); j += 2) {
-      if (j < cs) {
-        const u32x4 r = philox4x32_10((uint32_t)w, (uint32_t)(j >> 1), (uint32_t)k + a.subsample0, a.exposure,
-                                      a.seed, STAGE_SPARSE);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (j + h < cs) {
-            const float ua = u01f(r.v[2 * h]), ub = u01f(r.v[2 * h + 1]);
-            const float R = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
-            const float sig = (j + h < nw) ? sh : sg;
-            const int xi = (int)fmaf(R * __builtin_amdgcn_cosf(ua), sig, x);
-            const int yi = (int)fmaf(R * __builtin_amdgcn_sinf(ua), sig, y);
-            const int lx = xi - tx0, ly = yi - ty0;
-            if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-              atomicAdd(&tile[ly * tw + lx], 1);
-            else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
-              deposit_global<FLUSH>(a, si, xi, yi, 1);
-          }
-        }
-      }
-    }
-  }
   __syncthreads();
   for (int i = tid; i < tarea; i += kNarrowThreads) {
     const int n = tile[i];
     if (n > 0) {
       const int ly = i / tw, lx = i - ly * tw;
       deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, n);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lane : a bin's one-by-one electrons, thrown by the bin's own lane
+// ---------------------------------------------------------------------------
+// In split mode what is left to throw electron by electron is, per bin, a few hundred wide-PSF
+// electrons (sigma_h ~ 5-6 px: too spread out for a multinomial to pay) or the whole of a thinly
+// populated bin.  Sharing those out over lanes by electron number (k_throw) costs a prefix search per
+// workgroup and a bin change every few hundred electrons somewhere in every wave; here lane = bin, as in
+// k_narrow: position and sigma are loop constants, neighbouring bins hold nearly the same number of
+// electrons (the spectrum is smooth), and the per-electron work is the draw and the deposit alone.
+// Electron j of the bin takes pair j of the bin's STAGE_LANE stream; the first n_wide electrons take
+// sigma_h (pyparallel_menu.c:89-107).  Same arithmetic as k_throw's Philox mode.
+constexpr int kLaneThreads = 256;
+static_assert(kLaneThreads == kNarrowThreads, "k_lane and k_narrow share ThrowArgs::chunk_order");
+// The tile must hold practically every electron: one that falls outside takes the global-atomic path INSIDE the
+// loop (four flat-plane loads, the fp64 flat polynomial, a 64-bit atomic: microseconds of latency with the other
+// 63 lanes of the wave idle).  At a margin of 22 px (3.7 sigma_h) 3 % of the wave-iterations had such a lane and
+// the kernel ran at 220 cycles per iteration instead of ~135; 30 px is 5 sigma_h.
+constexpr int kLaneMargin = 30;
+constexpr int kLaneTile = 4608;         // ints of LDS (18 KB): 256 bins span ~10 px of the trace, + 2 x margin, by 2 x margin + a few rows
+
+template <int FLUSH>
+__global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
+  __shared__ int tile[kLaneTile];
+  __shared__ int s_box[4];
+  const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
+  const int tid = threadIdx.x;
+  const int w = (int)a.chunk_order[blockIdx.y] * kLaneThreads + tid;
+  const size_t kw = (size_t)k * a.W + (w < a.W ? w : 0);
+  const int n = (w < a.W) ? a.nlane[kw] : 0;
+  if (!__syncthreads_or(n > 0)) return;
+  const SubInfo si = a.sub[k];
+
+  float x = -1e30f, y = -1e30f, ch = 0.f, cl = 0.f;
+  int nw = 0;
+  if (n > 0) {
+    x = (float)a.xpos[kw];
+    y = (float)a.ypos[kw];
+    const float sh = (float)a.sigh[w], sl = (float)a.sigl[w];
+    ch = (-1.3862943611198906f * sh) * sh;
+    cl = (-1.3862943611198906f * sl) * sl;
+    nw = min(max(a.nwide[kw], 0), n);
+  }
+  // workgroup tile: bounding box of its bins' positions +- margin, clipped to [1, N) and to the LDS budget
+  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
+  __syncthreads();
+  if (n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f) {
+    const int ic = (int)floorf(x), jc = (int)floorf(y);
+    atomicMin(&s_box[0], ic - kLaneMargin); atomicMax(&s_box[1], ic + kLaneMargin + 1);
+    atomicMin(&s_box[2], jc - kLaneMargin); atomicMax(&s_box[3], jc + kLaneMargin + 1);
+  }
+  __syncthreads();
+  int tx0 = max(s_box[0], 1), tx1 = min(s_box[1], a.N), ty0 = max(s_box[2], 1), ty1 = min(s_box[3], a.N);
+  int tw = max(tx1 - tx0, 0), th = max(ty1 - ty0, 0);
+  while ((long long)tw * th > kLaneTile && th > 1) { ty0 += 1; th = max(th - 2, 1); }
+  while ((long long)tw * th > kLaneTile && tw > 1) { tx0 += 1; tw = max(tw - 2, 1); }
+  if ((long long)tw * th > kLaneTile) { tw = 0; th = 0; }
+  const int tarea = tw * th;
+  for (int i = tid; i < tarea; i += kLaneThreads) tile[i] = 0;
+  __syncthreads();
+
+  // Two parts, each from a stream of its own, so that sigma is a loop constant: the wide electrons, then the
+  // narrow ones (none for a bin whose narrow electrons went to k_narrow).  Inside a part the wave first runs
+  // the iterations EVERY lane has (no per-lane test at all: neighbouring bins hold nearly the same number of
+  // electrons), then the tail, where the stream still advances in every lane and only the deposit is
+  // suppressed (position far off the frame) for the lanes that are done.
+  const int tw4 = tw * 4;
+  auto throw_one = [&](SeededStream& rng, float c, float px, float py) {
+    uint32_t wa, wb;
+    rng.next2(wa, wb);
+    const float rev = rev12(wa);
+    const float Rs = __builtin_amdgcn_sqrtf(c * __builtin_amdgcn_logf(u01f(wb)));
+    const int xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);   // C truncation toward zero (:91-92)
+    const int yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
+    const int lx = xi - tx0, ly = yi - ty0;
+    if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+      atomicAdd((int*)((char*)tile + (__umul24(ly, tw4) + (lx << 2))), 1);
+    else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)               // (:93)
+      deposit_global<FLUSH>(a, si, xi, yi, 1);
+  };
+#pragma unroll 1
+  for (int part = 0; part < 2; ++part) {
+    const int cnt = part ? n - nw : nw;
+    int cmin = cnt, cmax = cnt;
+    for (int off = 32; off > 0; off >>= 1) {
+      cmin = min(cmin, __shfl_xor(cmin, off));
+      cmax = max(cmax, __shfl_xor(cmax, off));
+    }
+    cmin = __builtin_amdgcn_readfirstlane(cmin);
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    if (cmax <= 0) continue;
+    const float c = part ? cl : ch;
+    SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure, (uint32_t)part);
+    for (int j = 0; j < cmin; ++j) throw_one(rng, c, x, y);
+    for (int j = cmin; j < cmax; ++j) {
+      const bool live = j < cnt;
+      throw_one(rng, c, live ? x : -1e30f, live ? y : -1e30f);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < tarea; i += kLaneThreads) {
+    const int m = tile[i];
+    if (m > 0) {
+      const int ly = i / tw, lx = i - ly * tw;
+      deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, m);
     }
   }
 }

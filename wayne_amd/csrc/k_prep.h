@@ -75,8 +75,8 @@ struct PrepArgs {
   // outputs
   int32_t* counts;           // [K*W]
   int32_t* nwide;            // [K*W]
-  int32_t* nsplit;           // [K*W] split mode: > 0 narrow electrons handed to k_narrow's multinomial,
-                             //        < 0 minus the electrons of a sparse bin (all thrown by k_narrow), else 0
+  int32_t* nsplit;           // [K*W] split mode: narrow electrons handed to k_narrow's multinomial (else 0)
+  int32_t* nlane;            // [K*W] split mode: electrons the bin's own lane throws one by one in k_lane (else 0)
   uint32_t* prefix;          // [K*(W+1)] exclusive prefix of the electrons k_throw throws one by one
   double* xpos;              // [K*W] frame coords (x_sub)
   double* ypos;              // [K*W]
@@ -89,7 +89,7 @@ struct PrepArgs {
 
 constexpr int kPrepThreads = 512;
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
-constexpr int kSparseMax = 16;         // WAYNE_RNG_SPLIT: bins with fewer electrons are thrown lane-per-bin (k_narrow)
+constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
 constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
 
 __device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
@@ -183,21 +183,22 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
       ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
     }
-    // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one
-    // multinomial by k_narrow; k_throw keeps the wide electrons (and whole sparse bins)
+    // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one multinomial by k_narrow;
+    // what is left to throw one by one -- its wide electrons, or the whole of a bin that does not qualify --
+    // is thrown by the bin's own lane in k_lane (no prefix search, no bin changes inside a lane's loop);
+    // only a bin with more than kLaneMax such electrons is shared out by k_throw
     if (a.nsplit) {
       const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
       const uint32_t narrow = c - wide;
       const double sl = a.wa.sigl[w];
       const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sl > 0.05 &&
                          sl * 6.5 <= (double)kNarrowR;
-      // ... and a sparsely populated bin (long scans sampled finely: ~1 electron per bin and
-      // sub-sample) is thrown whole by the lane that owns it in k_narrow, from the bin's own
-      // Philox blocks: walking such bins electron by electron costs a bin fetch per electron
-      const bool sparse = a.split_min > 0 && c > 0 && c < (uint32_t)kSparseMax;
-      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : sparse ? -(int32_t)c : 0;
-      if (split) { c = wide; n_split_total += narrow; }   // c: electrons left for k_throw
-      if (sparse) { n_split_total += c; c = 0; }
+      const uint32_t ind = split ? wide : c;                 // electrons thrown one by one
+      const bool lane = a.split_min > 0 && ind <= (uint32_t)kLaneMax;
+      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
+      a.nlane[(size_t)k * W + w] = lane ? (int32_t)ind : 0;
+      n_split_total += (split ? narrow : 0u) + (lane ? ind : 0u);
+      c = lane ? 0u : ind;                                   // c: electrons left for k_throw
     }
   }
   // exclusive scan of c inside the chunk: shuffle scan per wave, wave totals through LDS

@@ -77,7 +77,7 @@ constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
 // FAST uses the hardware units (sin / cos take revolutions, log is log2).
 template <bool FAST>
 __device__ __forceinline__ void bm_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
-  // angle: the top 23 bits of w0 as a float in [1, 2) -- revolutions, one instruction -- radius from u01f(w1)
+  // angle: 23 bits of w0 as a float in [1, 2) -- revolutions, one instruction -- radius from u01f(w1)
   const float rev = rev12(w0), ub = u01f(w1);
   if (FAST) {
     const float Rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ub));
@@ -91,28 +91,44 @@ __device__ __forceinline__ void bm_pair(uint32_t w0, uint32_t w1, float& z0, flo
   }
 }
 
-__device__ __forceinline__ double nonlinear_response(double px, float c1, float c2, float c3, float c4) {
+// The state that lets the Newton solve of read r start next to its root (see nonlinear_response)
+struct NlState {
+  float v_prev;     // the previous read's incoming value
+  float gap;        // v_prev - u_prev: what the non-linearity took off it
+  float bend;       // 1 - 1/f'(u_prev): how that gap grows per DN
+};
+
+__device__ __forceinline__ double nonlinear_response(double px, float c1, float c2, float c3, float c4, NlState& st) {
   // WFC3_IR.apply_non_linearity (detector.py:335-348): Newton-Raphson on
-  // u (1 + c1 + u (c2 + u (c3 + c4 u))) = px from u0 = px, until |du| < 1e-3.
-  // The reference iterates the whole frame until its slowest pixel converges;
-  // here each pixel stops on its own criterion (the extra iterations move a
-  // converged pixel by < 1e-9).  (1 + c1), 2*c2, 3*c3, 4*c4 are float32 in
-  // the reference because the coefficient planes are.  The residual is
-  // evaluated in fp64; the reciprocal of the derivative (within 2e-7 of
-  // 1 + small) in fp32, which changes an iterate by < 1e-7 of its step.
+  // u (1 + c1 + u (c2 + u (c3 + c4 u))) = px, until |du| < 1e-3.
+  // The reference starts every read from u0 = px and iterates the whole frame until its slowest pixel
+  // converges; here each pixel stops on its own criterion, and starts from the previous read's root
+  // moved along the previous read's slope, u0 = px - gap - (px - v_prev) bend: the value of a pixel
+  // grows by a few DN to a few hundred DN per read, so u0 is within ~c2 dv^2 of the root and the first
+  // step is already below 1e-3 (one evaluation instead of two or three; read 1 starts from px).  The
+  // iteration converges quadratically, so whatever the start the result is the root to < 1e-9 DN.
+  // (1 + c1), 2*c2, 3*c3, 4*c4 are float32 in the reference because the coefficient planes are.  The
+  // residual is evaluated in fp64; the reciprocal of the derivative (within 2e-7 of 1 + small) in fp32,
+  // which changes an iterate by < 1e-7 of its step.
   const double k1 = (double)(1.0f + c1);
   const double k2 = (double)c2, k3 = (double)c3, k4 = (double)c4;
   const float d1 = 1.0f + c1, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
-  double u0 = px, u1 = px;
+  const float pxf = (float)px;
+  double u0 = px - (double)fmaf(pxf - st.v_prev, st.bend, st.gap), u1 = u0;
+  float rinv = 1.0f;
   for (int it = 0; it < 10000; ++it) {
     const double f = fma(u0, fma(u0, fma(u0, fma(k4, u0, k3), k2), k1), -px);
     const float uf = (float)u0;
     const float fp_ = fmaf(uf, fmaf(uf, fmaf(uf, d4, d3), d2), d1);
-    const double step = f * (double)__builtin_amdgcn_rcpf(fp_);
+    rinv = __builtin_amdgcn_rcpf(fp_);
+    const double step = f * (double)rinv;
     u1 = u0 - step;
     if (fabs(step) < 1e-3) break;
     u0 = u1;
   }
+  st.v_prev = pxf;
+  st.gap = (float)(px - u1);
+  st.bend = 1.0f - rinv;
   return u1;
 }
 
@@ -140,6 +156,26 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   // <= kSkyPiece (additivity again), so that exp(-mean) stays far from underflow whatever the plane holds
   float ld = lam - lam_level;
   if (ld > 0.f) {
+    if (M::fast && !PIECES) {
+      // One piece of mean <= kSkyPiece, in practice a fraction of an electron: count how many of the first
+      // cumulative probabilities e^-m (1, 1 + m, 1 + m + m^2/2, ...) lie below u -- four compares, no loop,
+      // no division -- and only when u lies beyond them all (for m = 1: 4e-3 of the draws) continue the search.
+      const float u = M::u01(wr);
+      float t = M::exp_(-ld), cdf = t, j = 0.f;
+      j += (u > cdf) ? 1.f : 0.f;  t = t * ld;               cdf += t;
+      j += (u > cdf) ? 1.f : 0.f;  t = t * (ld * 0.5f);       cdf += t;
+      j += (u > cdf) ? 1.f : 0.f;  t = t * (ld * 0.33333334f); cdf += t;
+      j += (u > cdf) ? 1.f : 0.f;
+      if (u > cdf) {
+        for (int it = 4; it < 512; ++it) {
+          t = t * M::div_(ld, (float)it);
+          cdf += t;
+          if (!(u > cdf)) break;
+          j = j + 1.f;
+        }
+      }
+      return k + j;
+    }
     for (;;) {
       const float piece = PIECES ? fminf(ld, kSkyPiece) : ld;
       float u = M::u01(wr);
@@ -225,6 +261,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
   __shared__ uint32_t s_tab[kMaxReads][kSkyAlias];   // ALIAS: alias tables; else: sky counts [read][thread]
   __shared__ float s_c[kMaxReads + 1];
+  __shared__ int s_tab0[kMaxReads + 1];   // first alias table of read r (a per-read index into the kernel arguments would be a global load)
   const int S = a.S;
   const int tid = threadIdx.x;
   const int p_raw = blockIdx.x * blockDim.x + tid;
@@ -242,7 +279,10 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   const bool do_noise = (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
   const bool do_sky = a.sky_ct_s > 0. && a.sky;
 
-  if (tid < a.R) s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);        // bg_count of read tid (:489-491)
+  if (tid < a.R) {
+    s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);                       // bg_count of read tid (:489-491)
+    s_tab0[tid] = (int)a.sky_tab0[tid];
+  }
   if (ALIAS && do_sky)
     for (int i = tid; i < kMaxReads * kSkyAlias; i += kRampThreads) (&s_tab[0][0])[i] = a.sky_alias[i];
   float skyv = 0.f;
@@ -296,6 +336,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   long long q_next = interior ? accp[0] : 0;
   float ds_next = ld_dark ? dsp[0] : 0.f, de_next = ld_dark ? dep[0] : 0.f;
   double cum = 0.;
+  NlState nl = {0.f, 0.f, 0.f};
   for (int r = 0; r < a.R; ++r) {
     const long long q = q_next;
     const float ds = ds_next, de = de_next;
@@ -319,7 +360,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
         // master_sky *= bg_count is an in-place float32 multiply (:493)
         const float lam = skyv * s_c[r];
         if (ALIAS) {
-          if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[a.sky_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
+          if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[s_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
         } else {
           px = px + (double)s_tab[r][tid];
         }
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
         const double err = (de > 0.f) ? (double)de : (double)0.00001f;
         v = v + ((double)ds + err * (double)zd);
       }
-      if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4);
+      if (do_lin) v = nonlinear_response(v, c1, c2, c3, c4, nl);
       if (clip) v = fmin(fmax(v, kMinCounts), kMaxCounts);
     } else {
       v = 0.;                        // reset_reference_pixels (exposure.py:122-131)

@@ -36,8 +36,9 @@ enum Stage : uint32_t {
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
   STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's
                       //   narrow-PSF electrons over pixels (k_narrow, rng_mode WAYNE_RNG_SPLIT)
-  STAGE_SPARSE = 10,  // Philox block  (bin w, j / 2, sub-sample k, exposure): words 2(j&1), 2(j&1)+1 -> electron j of a
-                      //   sparsely populated bin (fewer than kSparseMax electrons; rng_mode WAYNE_RNG_SPLIT)
+  STAGE_LANE = 10,    // seeded stream (bin w, part, sub-sample k, exposure): pair j -> j-th electron of the part, of the
+                      //   electrons a bin's own lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT).  part 0: the
+                      //   bin's wide-PSF electrons; part 1: the narrow ones of a bin that was not split
 };
 constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 
@@ -101,8 +102,8 @@ struct PhiloxStream {
 struct SeededStream {
   uint32_t s0, s1, s2, s3;
   WAYNE_HD SeededStream() : s0(0), s1(0), s2(0), s3(0) {}
-  WAYNE_HD SeededStream(uint32_t seed, uint32_t stage, uint32_t c0, uint32_t c2, uint32_t c3) {
-    const u32x4 b = philox4x32_10(c0, 0u, c2, c3, seed, stage);
+  WAYNE_HD SeededStream(uint32_t seed, uint32_t stage, uint32_t c0, uint32_t c2, uint32_t c3, uint32_t c1 = 0u) {
+    const u32x4 b = philox4x32_10(c0, c1, c2, c3, seed, stage);
     s0 = b.v[0]; s1 = b.v[1]; s2 = b.v[2]; s3 = b.v[3];
   }
   WAYNE_HD uint32_t next() {
@@ -134,10 +135,12 @@ struct SeededStream {
   }
 };
 
-// uint32 -> [1, 2) by writing the top 23 bits into a float's mantissa: the argument of v_sin_f32 /
-// v_cos_f32 in REVOLUTIONS (period 1, so [1, 2) is as good as [0, 1)); one instruction (v_lshr_or_b32).
+// uint32 -> [1, 2) by writing 23 of its bits into a float's mantissa: the argument of v_sin_f32 /
+// v_cos_f32 in REVOLUTIONS (period 1, so [1, 2) is as good as [0, 1)).  The LOW 23 bits, so that it is one
+// instruction (v_and_or_b32; gfx950 has no shift-right-or): the weak lowest bits of a xoshiro+ word end up in the
+// last mantissa bits of the angle, 2^-23 of a revolution.
 WAYNE_HD float rev12(uint32_t x) {
-  const uint32_t bits = (x >> 9) | 0x3f800000u;
+  const uint32_t bits = (x & 0x7fffffu) | 0x3f800000u;
 #if defined(__HIP_DEVICE_COMPILE__)
   return __uint_as_float(bits);
 #else

@@ -21,9 +21,9 @@ using namespace wayne;
 
 namespace {
 
-enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE, PK_NARROW };
-const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub", "k_throw",
-                                                    "k_cosmic",  "k_ramp",     "k_lightcurve", "k_narrow"};
+enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE, PK_NARROW, PK_LANE };
+const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub",   "k_throw",  "k_cosmic",
+                                                    "k_ramp",    "k_lightcurve", "k_narrow", "k_lane"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -65,7 +65,7 @@ struct Slot {
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
   DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;   // views into in_dev (depth: owned when computed by k_lightcurve)
   DevBuf ratio, sigl, sigh, sens, dlam;
-  DevBuf counts, nwide, nsplit, prefix, xpos, ypos, sub, chunk_total, chunk_box;
+  DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   DevBuf in_dev;          // device mirror of the staging arena: the descriptor's arrays arrive in ONE copy
   void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait), followed by a copy of `misc`
@@ -86,6 +86,7 @@ struct Slot {
   std::vector<double> read_dt_host;
   double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
+  unsigned char chunk_order[kMaxChunks] = {0};   // chunks of 256 bins, most electrons first (ThrowArgs::chunk_order)
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
   char* stage = nullptr;
@@ -94,7 +95,7 @@ struct Slot {
   bool stage_pending = false;
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
-                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
+                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &nlane, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
                       &misc, &sky_tab, &in_dev})
       b->release();
     if (sky_tab_host) (void)hipHostFree(sky_tab_host);
@@ -157,7 +158,7 @@ struct wayne_ctx {
   std::map<uint32_t, std::vector<uint32_t> > alias_cache;        // float bits of lam_max -> alias table
   Slot slots[kSlots];
   // psf_apply scratch
-  DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
+  DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_nlane, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
   // profiling
   bool prof_on = false;
   unsigned prof_mask = ~0u;   // kernels timed while prof_on (wayne_profile_select)
@@ -318,11 +319,14 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
   return WAYNE_OK;
 }
 
-// Expected number of electrons k_throw throws one by one in the longest sub-sample of an exposure
+// Expected number of electrons k_throw shares out (split mode: only the bins beyond a lane's cap, normally none)
+// in the longest sub-sample of an exposure
 // (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
 // the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
-double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d) {
+double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order) {
   const int W = d->n_wl, K = d->n_samples;
+  const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
+  std::vector<double> chunk_e((size_t)n_chunks, 0.);
   double dur_max = 0.;
   for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
   const GrismDev& g = c->g;
@@ -345,15 +349,21 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d) {
     const double right = (i == W - 1) ? (d->wl_um[W - 1] - d->wl_um[W - 2]) / 2. : (d->wl_um[i + 1] - x) / 2.;
     double cnt = d->flux[i] * sens * (left + right) * 1e4 * dur_max * 1e-3 * d->scale_factor;
     if (!(cnt > 0.)) continue;
+    chunk_e[(size_t)(i / kNarrowThreads)] += cnt;
     if (d->rng_mode == WAYNE_RNG_SPLIT) {
       const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
       const double sl = poly3(g.p_sigl, x);
       if (cnt - wide >= (double)kSplitMinHost && cnt - wide <= (double)kSplitMaxNarrow && sl > 0.05 &&
           sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
-      else if (cnt < (double)kSparseMax) cnt = 0.;                                                    // sparse bin: k_narrow
+      if (cnt <= 0.9 * (double)kLaneMax) cnt = 0.;    // thrown by the bin's own lane (k_lane); 10 % headroom for the noise
     }
     total += cnt;
   }
+  // chunks by expected electrons, most first (stable for ties)
+  std::vector<int> order((size_t)n_chunks);
+  for (int i = 0; i < n_chunks; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return chunk_e[a_] > chunk_e[b_]; });
+  for (int i = 0; i < n_chunks && i < kMaxChunks; ++i) chunk_order[i] = (unsigned char)order[i];
   return total;
 }
 
@@ -472,9 +482,17 @@ static_assert(kSplitMin == kSplitMinHost, "split threshold");
 
 template <int FLUSH>
 int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
-  const dim3 grid((unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads), (unsigned)a.K);
+  const dim3 grid((unsigned)a.K, (unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads));
   if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
   else hipLaunchKernelGGL((k_narrow<FLUSH, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return WAYNE_OK;
+}
+
+template <int FLUSH>
+int launch_lane(wayne_ctx* c, const ThrowArgs& a) {
+  const dim3 grid((unsigned)a.K, (unsigned)((a.W + kLaneThreads - 1) / kLaneThreads));
+  hipLaunchKernelGGL((k_lane<FLUSH>), grid, dim3(kLaneThreads), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
 }
@@ -557,7 +575,7 @@ void wayne_ctx_destroy(wayne_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& s : c->slots) s.release();
   for (DevBuf* b : {&c->counters, &c->sens_wl, &c->sens_val, &c->pfl, &c->sky, &c->dark_sci, &c->dark_err, &c->zero_read,
-                    &c->pa_prefix, &c->pa_nwide, &c->pa_nsplit, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
+                    &c->pa_prefix, &c->pa_nwide, &c->pa_nsplit, &c->pa_nlane, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
                     &c->pa_frame})
     b->release();
   for (int i = 0; i < 4; ++i) { c->flat[i].release(); c->lin[i].release(); }
@@ -618,10 +636,10 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
 
   if (total > 0) {
     std::vector<uint32_t> prefix((size_t)size + 1);
-    std::vector<int32_t> nwide((size_t)size), nsplit((size_t)size, 0);
+    std::vector<int32_t> nwide((size_t)size), nsplit((size_t)size, 0), nlane((size_t)size, 0);
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     uint32_t run = 0;
-    bool any_split = false;
+    bool any_split = false, any_lane = false;
     for (int i = 0; i < size; ++i) {
       prefix[i] = run;
       const double nw = (double)counts[i] * psf_ratio[i];  // N = counts*ratio (:89)
@@ -633,16 +651,15 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
       if (rng_mode == WAYNE_RNG_SPLIT) {      // same rule as k_prep_sub
         const uint32_t wide = (uint32_t)std::min<int64_t>(std::max(nwide[i], 0), counts[i]);
         const uint32_t narrow = (uint32_t)counts[i] - wide;
-        if (narrow >= (uint32_t)kSplitMin && narrow <= kSplitMaxNarrow && psf_sigmal[i] > 0.05 &&
-            psf_sigmal[i] * 6.5 <= (double)kNarrowR) {
-          nsplit[i] = (int32_t)narrow;
-          thrown = wide;
-          any_split = true;
-        } else if (counts[i] > 0 && counts[i] < kSparseMax) {   // sparse bin: thrown whole by k_narrow
-          nsplit[i] = -counts[i];
-          thrown = 0;
-          any_split = true;
-        }
+        const bool split = narrow >= (uint32_t)kSplitMin && narrow <= kSplitMaxNarrow && psf_sigmal[i] > 0.05 &&
+                           psf_sigmal[i] * 6.5 <= (double)kNarrowR;
+        const uint32_t ind = split ? wide : (uint32_t)counts[i];
+        const bool lane = ind <= (uint32_t)kLaneMax;
+        nsplit[i] = split ? (int32_t)narrow : 0;
+        nlane[i] = lane ? (int32_t)ind : 0;
+        thrown = lane ? 0u : ind;
+        if (nsplit[i] > 0) any_split = true;
+        if (nlane[i] > 0) any_lane = true;
       }
       run += thrown;
       if (counts[i] > 0 && std::isfinite(x_pos[i]) && std::isfinite(y_pos[i])) {
@@ -655,7 +672,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     si.electrons = run;
     si.read = 0;
     si.replay_seed = (int)seed;
-    const int margin = 24;
+    const int margin = 30;
     if (xmax >= xmin) {
       auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
       int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
@@ -666,6 +683,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     if ((rc = upload(c, c->pa_prefix, prefix.data(), prefix.size()))) return rc;
     if ((rc = upload(c, c->pa_nwide, nwide.data(), nwide.size()))) return rc;
     if ((rc = upload(c, c->pa_nsplit, nsplit.data(), nsplit.size()))) return rc;
+    if ((rc = upload(c, c->pa_nlane, nlane.data(), nlane.size()))) return rc;
     if ((rc = upload(c, c->pa_x, x_pos, (size_t)size))) return rc;
     if ((rc = upload(c, c->pa_y, y_pos, (size_t)size))) return rc;
     if ((rc = upload(c, c->pa_sl, psf_sigmal, (size_t)size))) return rc;
@@ -687,15 +705,23 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.prefix = c->pa_prefix.as<uint32_t>();
     a.nwide = c->pa_nwide.as<int32_t>();
     a.nsplit = c->pa_nsplit.as<int32_t>();
+    a.nlane = c->pa_nlane.as<int32_t>();
     a.xpos = c->pa_x.as<double>(); a.ypos = c->pa_y.as<double>();
     a.sigl = c->pa_sl.as<double>(); a.sigh = c->pa_sh.as<double>();
     for (int i = 0; i < 4; ++i) a.flat[i] = nullptr;
     a.acc = nullptr;
     a.frame = c->pa_frame.as<int32_t>();
+    if ((size + kNarrowThreads - 1) / kNarrowThreads > kMaxChunks && (any_lane || any_split))
+      return fail(c, WAYNE_E_INVALID, "psf_apply: more than 32768 bins in split mode");
+    for (int i = 0; i < kMaxChunks; ++i) a.chunk_order[i] = (unsigned char)i;
     if (run > 0) {
       ProfScope ps(c, PK_THROW);
       rc = (rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 0>(c, a, lds_ints) : launch_throw<1, 0>(c, a, lds_ints);
       if (rc) return rc;
+    }
+    if (any_lane) {
+      ProfScope ps(c, PK_LANE);
+      if ((rc = launch_lane<0>(c, a))) return rc;
     }
     if (any_split) {
       ProfScope ps(c, PK_NARROW);
@@ -871,6 +897,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   HIP_TRY(c, s.counts.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.nwide.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.nsplit.reserve(KW * sizeof(int32_t)));
+  HIP_TRY(c, s.nlane.reserve(KW * sizeof(int32_t)));
   HIP_TRY(c, s.prefix.reserve((size_t)K * (W + 1) * sizeof(uint32_t)));
   HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
@@ -900,7 +927,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
-  s.est_thrown = estimate_thrown(c, d);
+  s.est_thrown = estimate_thrown(c, d, s.chunk_order);
   if ((rc = prepare_sky_tables(c, s))) return rc;
   s.uploaded = true;
   s.front_done = false;
@@ -953,7 +980,9 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
                        s.wl.as<double>(), wa, s.misc.as<uint32_t>());
     HIP_TRY(c, hipGetLastError());
   }
-  const int margin = d.thrower_margin > 0 ? d.thrower_margin : 24;   // ~4 sigma_h: sweep in scripts/sweep_throw.py
+  // margin of a thrower workgroup's tile around its slice of the trace: 5 sigma_h, so that practically no electron
+  // takes the in-loop global-atomic path (see k_lane)
+  const int margin = d.thrower_margin > 0 ? d.thrower_margin : 30;
   {
     PrepArgs a{};
     a.g = c->g;
@@ -971,6 +1000,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.wa = wa;
     a.counts = s.counts.as<int32_t>(); a.nwide = s.nwide.as<int32_t>();
     a.nsplit = s.nsplit.as<int32_t>();
+    a.nlane = s.nlane.as<int32_t>();
     a.split_min = (d.rng_mode == WAYNE_RNG_SPLIT) ? kSplitMin : 0;
     a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sub = s.sub.as<SubInfo>();
@@ -1013,11 +1043,14 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
         const double unit = (d.rng_mode == WAYNE_RNG_REPLAY) ? 1. : (double)kThrowBlock;
         const double lanes = 1.08 * s.est_thrown / unit;
         splits = (int)std::min(4096., std::ceil(lanes / kThrowThreads));
+        // split mode with no bin expected beyond a lane's cap: k_throw finds nothing to do (any stray bin is
+        // handled by the one workgroup per sub-sample launched here)
+        if (d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0.) splits = -1;
         // a lane takes several units when the launch would exceed ~24 workgroups per CU: then ~12 per CU
         // (each lane a handful of units) is the measured optimum (scripts/sweep_throw.py)
         const int cap = std::max(1, (3072 + K - 1) / K);
         if (splits > 2 * cap) splits = cap;
-        splits = std::max(splits, (min_wgs + K - 1) / K);
+        splits = splits < 0 ? 1 : std::max(splits, (min_wgs + K - 1) / K);
       }
     }
     a.min_wgs = min_wgs;
@@ -1037,6 +1070,8 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.flat_inv_range = 1.0 / (c->g.flat_wmax - c->g.flat_wmin);
     a.sub = s.sub.as<SubInfo>(); a.prefix = s.prefix.as<uint32_t>(); a.nwide = s.nwide.as<int32_t>();
     a.nsplit = s.nsplit.as<int32_t>();
+    a.nlane = s.nlane.as<int32_t>();
+    std::memcpy(a.chunk_order, s.chunk_order, sizeof a.chunk_order);
     a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sigl = s.sigl.as<double>(); a.sigh = s.sigh.as<double>();
     for (int i = 0; i < 4; ++i) a.flat[i] = c->has_flat ? c->flat[i].as<float>() : nullptr;
@@ -1047,7 +1082,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     const bool fork = d.rng_mode == WAYNE_RNG_SPLIT && c->fork_narrow;
     hipStream_t main_stream = c->stream;
     {
-      // (with the fork, the PK_THROW interval spans both thrower kernels; PK_NARROW is k_narrow's own)
+      // (with the fork, the PK_THROW interval spans all thrower kernels; PK_NARROW / PK_LANE are those kernels' own)
       ProfScope ps_throw(c, PK_THROW);
       if (fork) {
         HIP_TRY(c, hipEventRecord(c->ev_fork[si_], main_stream));
@@ -1066,6 +1101,10 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       }
       int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
       if (rc) return rc;
+      if (d.rng_mode == WAYNE_RNG_SPLIT) {
+        ProfScope ps(c, PK_LANE);
+        if ((rc = launch_lane<1>(c, a))) return rc;
+      }
       if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join[si_], 0));
     }
     if (!fork && d.rng_mode == WAYNE_RNG_SPLIT) {
