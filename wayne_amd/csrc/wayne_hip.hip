@@ -140,6 +140,11 @@ struct wayne_ctx {
   hipStream_t side[kStreams] = {nullptr, nullptr};
   hipEvent_t ev_fork[kStreams] = {nullptr, nullptr}, ev_join[kStreams] = {nullptr, nullptr};
   bool fork_narrow = true;
+  // Delivered pipeline (fetch_async): the kernels of the exposure that follows on the other stream wait for the
+  // KERNELS of the fetched one (not for its copy).  Left alone, the two streams drift into phase -- both compute,
+  // then both copy and share the PCIe link: 640 exposures/s -- instead of one copying while the other computes (810).
+  hipEvent_t ev_kdone[kStreams] = {nullptr, nullptr};
+  bool kdone_valid[kStreams] = {false, false};
   int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
   std::string err;
   // grism
@@ -550,6 +555,7 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
     }
   c->stream = c->streams[0];
   for (int i = 0; i < kStreams; ++i) {
+    if (hipEventCreateWithFlags(&c->ev_kdone[i], hipEventDisableTiming) != hipSuccess) c->ev_kdone[i] = nullptr;
     if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
@@ -584,6 +590,7 @@ void wayne_ctx_destroy(wayne_ctx* c) {
     if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    if (c->ev_kdone[i]) (void)hipEventDestroy(c->ev_kdone[i]);
   }
   delete c;
 }
@@ -944,6 +951,13 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   const wayne_exposure_desc& d = s.d;
   const int W = s.W, K = s.K, R = s.R, N = c->N, S = c->S;
   const size_t SS = (size_t)S * S;
+  if (c->n_streams == 2) {
+    const int other = 1 - slot % 2;
+    if (c->kdone_valid[other]) {     // see wayne_ctx::ev_kdone
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_kdone[other], 0));
+      c->kdone_valid[other] = false;
+    }
+  }
   if (s.acc_dirty) {
     HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
     s.acc_dirty = false;
@@ -1221,6 +1235,10 @@ int wayne_exposure_fetch_async(wayne_ctx* c, int slot) {
   // The copy follows the slot's kernels on the slot's own stream: while it runs (1.2 ms at 55 GB/s for a full
   // frame) the kernels of the exposure in the next slot run on the other stream.  (A separate copy stream fed by
   // events was measured: 660-700 exposures/s instead of 810-826 -- scripts/probe_pipeline.py.)
+  if (c->n_streams == 2 && c->ev_kdone[slot % 2]) {
+    HIP_TRY(c, hipEventRecord(c->ev_kdone[slot % 2], c->stream));
+    c->kdone_valid[slot % 2] = true;
+  }
   HIP_TRY(c, hipMemcpyAsync(s.pinned, s.out.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(s.pinned_misc, s.misc.p, sizeof(Slot::Misc), hipMemcpyDeviceToHost, c->stream));
   return WAYNE_OK;
