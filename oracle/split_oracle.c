@@ -154,10 +154,9 @@ static int so_trunc(float v) {
  * `split_min` narrow electrons (and 0.05 < sigma_l <= 6/6.5) hand them to the
  * multinomial.  What is left to throw one by one -- the wide electrons of such a
  * bin, or the whole of a bin that does not qualify -- is thrown from the bin's
- * OWN streams when it is at most `lane_max` electrons (the device gives each bin a
- * lane, k_lane): the j-th wide electron takes pair j of the xoshiro128+ stream
- * seeded by Philox block (bin, 0, sub-sample, exposure), stage LANE, the j-th
- * narrow one pair j of the stream seeded by block (bin, 1, ...).  Beyond `lane_max`
+ * OWN stream when it is at most `lane_max` electrons (the device gives each bin a
+ * lane, k_lane): electron j takes pair j of the xoshiro128+ stream seeded by
+ * Philox block (bin, 0, sub-sample, exposure), stage LANE.  Beyond `lane_max`
  * the electrons are numbered bin-major over the bins thrown that way and drawn
  * from the STAGE_THROW block streams exactly as wayne_oracle_psf_philox does.
  * Either way: the first n_wide electrons of a bin take sigma_h
@@ -201,14 +200,10 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
     /* one by one */
     const int64_t thrown = split ? n_wide : counts[b];
     if (split_min > 0 && thrown <= lane_max) {
-      const int64_t n_w = n_wide < thrown ? n_wide : thrown;
-      for (uint32_t part = 0; part < 2; ++part) {
-        const uint32_t ctr[4] = {(uint32_t)b, part, subsample, exposure};
-        uint32_t gl[4];
-        wayne_oracle_philox4x32(ctr, key_l, gl);
-        const int64_t cnt = part ? thrown - n_w : n_w;
-        for (int64_t j = 0; j < cnt; ++j) so_throw_one(gl, x, y, part ? sl : sh, n, out);
-      }
+      const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
+      uint32_t gl[4];
+      wayne_oracle_philox4x32(ctr, key_l, gl);
+      for (int64_t j = 0; j < thrown; ++j) so_throw_one(gl, x, y, (j < n_wide) ? sh : sl, n, out);
     } else {
       for (int64_t j = 0; j < thrown; ++j, ++e) {
         if ((e & 127u) == 0) {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Exposures/s of every BASELINE.json configuration on one MI355X:
-device-complete (reads left in HBM) and delivered (reads copied to host memory)."""
+"""Exposures/s of every BASELINE.json configuration on one MI355X: device-complete (reads left in HBM; one
+stream, and alternating over two) and end to end (host descriptor -> upload -> kernels -> reads in pinned host
+memory, light curves on the device: VisitRunner)."""
 import json
 import os
 import sys
@@ -41,14 +42,27 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
         ctx.run(2 * j)
     p = ctx.profile_get()
     ctx.profile_enable(False)
-    # delivered: the visit runner (host prep + upload + kernels + download), exposures returned as numpy arrays
-    runner = visit.VisitRunner(v, 0, frame_overrides={})
+    # the same exposures alternating over the context's two streams
+    for j in range(n + 2):
+        eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
+        ctx.upload(j, eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(j)))
+    for j in range(2):
+        ctx.run(j)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for j in range(2, n + 2):
+        ctx.run(j)
+    ctx.synchronize()
+    dt_two = time.perf_counter() - t0
+    # end to end: the visit runner (host prep + upload + kernels + copy to pinned host memory), device light curves
+    runner = visit.VisitRunner(v, 0, frame_overrides={}, device_lc=True)
     runner.rng_mode = mode
-    runner.run([0, 1])
+    runner.run(list(range(4)))
     t1 = time.perf_counter()
-    runner.run(range(2, n + 2))
-    dt2 = time.perf_counter() - t1
-    out[name] = {"device_complete_exp_s": n / dt, "delivered_exp_s": n / dt2, "electrons_per_exposure": p["electrons"] / n,
+    runner.run([j % (n + 2) for j in range(3 * n)])
+    dt2 = (time.perf_counter() - t1) / 3
+    out[name] = {"device_complete_exp_s": n / dt, "two_streams_exp_s": n / dt_two, "end_to_end_exp_s": n / dt2,
+                 "electrons_per_exposure": p["electrons"] / n,
                  "ms": {k: p[k]["ms"] / n for k in p if k != "electrons"}, "K": v.K, "W": int(np.sum((v.wl >= gr.wl_limits[0]) & (v.wl <= gr.wl_limits[1]))),
                  "frame": eng.N, "NSAMP": v.NSAMP}
     print(name, json.dumps(out[name]), flush=True)

@@ -203,11 +203,12 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   for (int i = tid; i < tarea; i += kLaneThreads) tile[i] = 0;
   __syncthreads();
 
-  // Two parts, each from a stream of its own, so that sigma is a loop constant: the wide electrons, then the
-  // narrow ones (none for a bin whose narrow electrons went to k_narrow).  Inside a part the wave first runs
-  // the iterations EVERY lane has (no per-lane test at all: neighbouring bins hold nearly the same number of
-  // electrons), then the tail, where the stream still advances in every lane and only the deposit is
-  // suppressed (position far off the frame) for the lanes that are done.
+  // Electron j of the bin takes pair j of the bin's stream; the first nw take sigma_h.  A wave whose bins all
+  // had their narrow electrons taken by k_narrow (nw = n everywhere: the usual case) runs with sigma as a loop
+  // constant: first the iterations EVERY lane has, with no per-lane test at all (neighbouring bins hold nearly the
+  // same number of electrons), then the tail, where the stream still advances in every lane and only the deposit
+  // is suppressed (position far off the frame) for the lanes that are done.  A wave with thin, unsplit bins
+  // selects sigma per electron.
   const int tw4 = tw * 4;
   auto throw_one = [&](SeededStream& rng, float c, float px, float py) {
     uint32_t wa, wb;
@@ -222,23 +223,26 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)               // (:93)
       deposit_global<FLUSH>(a, si, xi, yi, 1);
   };
-#pragma unroll 1
-  for (int part = 0; part < 2; ++part) {
-    const int cnt = part ? n - nw : nw;
-    int cmin = cnt, cmax = cnt;
-    for (int off = 32; off > 0; off >>= 1) {
-      cmin = min(cmin, __shfl_xor(cmin, off));
-      cmax = max(cmax, __shfl_xor(cmax, off));
-    }
-    cmin = __builtin_amdgcn_readfirstlane(cmin);
-    cmax = __builtin_amdgcn_readfirstlane(cmax);
-    if (cmax <= 0) continue;
-    const float c = part ? cl : ch;
-    SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure, (uint32_t)part);
-    for (int j = 0; j < cmin; ++j) throw_one(rng, c, x, y);
-    for (int j = cmin; j < cmax; ++j) {
-      const bool live = j < cnt;
-      throw_one(rng, c, live ? x : -1e30f, live ? y : -1e30f);
+  int cmin = n, cmax = n;
+  for (int off = 32; off > 0; off >>= 1) {
+    cmin = min(cmin, __shfl_xor(cmin, off));
+    cmax = max(cmax, __shfl_xor(cmax, off));
+  }
+  cmin = __builtin_amdgcn_readfirstlane(cmin);
+  cmax = __builtin_amdgcn_readfirstlane(cmax);
+  if (cmax > 0) {
+    SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
+    if (!__any(n > nw)) {
+      for (int j = 0; j < cmin; ++j) throw_one(rng, ch, x, y);
+      for (int j = cmin; j < cmax; ++j) {
+        const bool live = j < n;
+        throw_one(rng, ch, live ? x : -1e30f, live ? y : -1e30f);
+      }
+    } else {
+      for (int j = 0; j < cmax; ++j) {
+        const bool live = j < n;
+        throw_one(rng, (j < nw) ? ch : cl, live ? x : -1e30f, live ? y : -1e30f);
+      }
     }
   }
   __syncthreads();

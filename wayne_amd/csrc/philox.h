@@ -36,9 +36,9 @@ enum Stage : uint32_t {
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
   STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's
                       //   narrow-PSF electrons over pixels (k_narrow, rng_mode WAYNE_RNG_SPLIT)
-  STAGE_LANE = 10,    // seeded stream (bin w, part, sub-sample k, exposure): pair j -> j-th electron of the part, of the
-                      //   electrons a bin's own lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT).  part 0: the
-                      //   bin's wide-PSF electrons; part 1: the narrow ones of a bin that was not split
+  STAGE_LANE = 10,    // seeded stream (bin w, 0, sub-sample k, exposure): pair j -> electron j of the electrons a bin's own
+                      //   lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT): the wide-PSF electrons of a bin whose
+                      //   narrow ones went to the multinomial, or every electron of a thinly populated bin (wide ones first)
 };
 constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 

@@ -199,8 +199,10 @@ class Visit(object):
         if self.ssv:
             from .trend_generators.scan_speed_varations import SSVSine
             ssv = SSVSine(*self.ssv)
+        # (the K x W depth matrix is only built when the caller does not bring its own planet_signal)
+        signal = override["planet_signal"] if "planet_signal" in override else self.planet_signal(i)
         kw = dict(x_ref=self.x_refs[i], y_ref=self.y_refs[i], x_jitter=self.x_jitter, y_jitter=self.y_jitter,
-                  wl=self.wl, stellar_flux=self.stellar_flux, planet_signal=self.planet_signal(i),
+                  wl=self.wl, stellar_flux=self.stellar_flux, planet_signal=signal,
                   scan_speed=self.scan_speed, sample_rate=10.0, sample_mid_points=self.sample_mid_points,
                   sample_durations=self.sample_durations, read_index=self.read_index, ssv_generator=ssv,
                   noise_mean=False, noise_std=False, add_dark=True, add_flat=True, cosmic_rate=self.cosmic_rate,
