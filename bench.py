@@ -6,7 +6,7 @@
 One "step" = one whole exposure (1014x1014 frame, NSAMP = 16, 128-sub-sample
 spatial scan, 1e9 electrons: BASELINE.json configs[3], the configuration the
 metric is quoted on) synthesised by the HIP path: k_prep_wl, k_prep_sub,
-k_throw || k_narrow, k_cosmic, k_ramp.  All inputs and calibration planes are
+k_lane || k_narrow (+ k_throw for oversized bins), k_cosmic, k_ramp.  All inputs and calibration planes are
 resident in HBM before the timed region; outputs stay in HBM (device-complete
 rate).  Exposures are independent: with N ranks each rank runs its own K
 exposures (round-robin exposure indices, no collective in the data path) ->
@@ -407,6 +407,7 @@ def main():
         # WAYNE_FORK_NARROW (default on): the library launches k_narrow on a side stream beside k_throw and
         # its k_throw profile interval then covers both kernels
         forked = args.thrower == "split" and os.environ.get("WAYNE_FORK_NARROW", "1") != "0"
+        # (the k_throw interval always includes k_lane, which follows it on the slot's stream)
         thrower_ms = throw_ms if forked else throw_ms + narrow_ms
         electrons = prof["electrons"] / max(n_break, 1)
         rates = sorted(args.steps * n_gpus / e for e in reps)
@@ -440,8 +441,9 @@ def main():
             "kernels_ms_per_exposure": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items() if k != "electrons"},
             "thrower": {"mode": args.thrower, "electrons_per_exposure": electrons, "ms": thrower_ms,
                         "electrons_per_s": electrons / (thrower_ms * 1e-3) if thrower_ms > 0 else None,
-                        "note": "k_narrow runs beside k_throw on a side stream: the k_throw interval spans both"
-                        if forked else "k_throw then k_narrow on one stream"},
+                        "note": "split mode: the k_throw interval spans k_throw (bins beyond a lane's cap: normally none) + "
+                                "k_lane on the slot's stream with k_narrow + k_cosmic beside them on a side stream"
+                        if forked else "k_throw + k_lane (one interval), then k_narrow, on one stream"},
         }
         line.update(extras)
         # numbers that only a rocprofv3 --pmc run can give come from profiles/*.json, which

@@ -54,8 +54,9 @@ def main():
     issue = dict(stamp)
     issue["source"] = "%s/pmc_sq.json (rocprofv3 --pmc SQ counters, scripts/collect_profiles.sh), commit %s" % (
         os.path.basename(prof_dir.rstrip("/")), commit[:10])
-    issue["note"] = ("a wave64 VALU instruction holds a SIMD for 4 cycles, a transcendental for up to 16: "
-                     "issue_cycles_per_simd = (4 SQ_INSTS_VALU + 12 SQ_INSTS_VALU_TRANS_F32) / 1024 SIMDs; busy = "
+    issue["note"] = ("a wave64 VALU instruction holds a SIMD for 4 cycles, a transcendental for 11.5 (measured: "
+                     "scripts/ubench/issue_cost.hip, profiles/r02/issue_cost_ubench.txt): "
+                     "issue_cycles_per_simd = (4 SQ_INSTS_VALU + 7.5 SQ_INSTS_VALU_TRANS_F32) / 1024 SIMDs; busy = "
                      "SQ_BUSY_CYCLES / 32 shader engines; valu_issue_frac = min(1, issue / busy); lane_utilisation = "
                      "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)")
     issue["kernels"] = {}
@@ -67,7 +68,7 @@ def main():
         busy = c["SQ_BUSY_CYCLES"]["mean"] / 32.0
         if busy < 20000:          # tiny kernels say nothing
             continue
-        cyc = (4 * valu + 12 * trans) / 1024.0
+        cyc = (4 * valu + 7.5 * trans) / 1024.0
         issue["kernels"][k.replace("wayne::", "")] = {
             "valu_wave_instructions": round(valu), "transcendental_wave_instructions": round(trans),
             "issue_cycles_per_simd": round(cyc), "busy_cycles": round(busy),
