@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
   roofline      the fused up-the-ramp kernel k_ramp against the HBM roof
   cpu_baseline  the reference's C thrower + the numpy restatement of the host
                 loop, timed on this box's host cores on a bounded sample
-  per_electron / out_f64 / two_streams / delivered / end_to_end
+  per_electron / replay_bit_exact / out_f64 / two_streams / delivered / end_to_end
                 the same workload measured like-for-like with the reference
                 (every electron thrown; float64 reads) and through the host
                 pipeline (PCIe-inclusive) -- never `value`
@@ -362,6 +362,13 @@ def main():
             extras["per_electron_f64"] = {"value": rate(slot_of), "unit": "exposures/s",
                                           "note": "every electron thrown AND float64 reads: the reference's arithmetic "
                                                   "shape, one stream"}
+            # (3b) the bit-exact mode: glibc rand_r streams + the reference's OpenMP partition replayed on the device,
+            # fp64 Box-Muller and positions -- the thrower whose frames equal the reference C's bit for bit
+            # (tests/test_psf_gpu.py, tests/golden/psf_*.npz) -- with float64 reads
+            upload_all(2, np.float64, _lib.RNG_REPLAY)
+            extras["replay_bit_exact"] = {"value": rate(slot_of, min(n_x, 10)), "unit": "exposures/s",
+                                          "note": "rng_mode REPLAY (threads_compat 2): the thrower that reproduces the "
+                                                  "reference's frames bit for bit, float64 reads, one stream"}
         # (4) delivered: reads of resident exposures copied to pinned host memory through the VisitRunner pipeline
         # (4 slots in rotation over both streams, device-to-host copies on the copy stream)
         runner = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32)

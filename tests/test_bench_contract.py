@@ -33,9 +33,10 @@ def test_bench_line_has_the_contract_keys():
     # the like-for-like and host-pipeline numbers ride in the same line, and never replace `value`
     rep = d["repetitions"]
     assert rep["n"] >= 5 and len(rep["values"]) == rep["n"] and rep["min"] <= d["value"] <= rep["max"]
-    for key in ("per_electron", "per_electron_f64", "out_f64", "two_streams", "delivered", "end_to_end"):
+    for key in ("per_electron", "per_electron_f64", "replay_bit_exact", "out_f64", "two_streams", "delivered", "end_to_end"):
         assert d[key]["unit"] == "exposures/s" and d[key]["value"] > 10, key
-    assert d["per_electron"]["value"] < d["value"] and d["delivered"]["value"] < d["two_streams"]["value"]
+    assert d["replay_bit_exact"]["value"] < d["per_electron"]["value"] < d["value"]
+    assert d["delivered"]["value"] < d["two_streams"]["value"]
     assert 0 < d["end_to_end"]["frac_of_pcie"] < 1
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 1e8
     assert "traffic_source" in d["roofline"]
