@@ -94,6 +94,32 @@ def crop_central_box(array, size):
     return array[index:-index, index:-index]
 
 
+def rebin_spec(wavelength, spectrum, new_wavelength):
+    """tools.py:131-149 hands this to pysynphot (an un-vendored dependency, version unpinned in setup.py:32-33, not
+    installed here): `Observation(spec, flat filter, binset=new_wavelength, force='taper').binflux`.  pysynphot's
+    published binning (observation.py, `initbinflux`): bin edges half-way between the binset wavelengths, the end
+    bins as wide as their neighbours' half-spacing allows; the spectrum, piecewise linear between its samples, is
+    integrated over each bin and divided by the bin's width.  Restated here bin by bin with an explicit merged
+    grid and the trapezoid rule -- deliberately not the product's cumulative-integral interpolation.  PARITY
+    UNPINNED against pysynphot itself."""
+    wl = np.asarray(wavelength, dtype=float)
+    sp = np.asarray(spectrum, dtype=float)
+    new = np.asarray(new_wavelength, dtype=float)
+    edges = bin_centers_to_edges(new)
+    out = np.empty(new.size)
+    for i in range(new.size):
+        lo, hi = edges[i], edges[i + 1]
+        inside = wl[(wl > lo) & (wl < hi)]
+        grid = np.concatenate([[lo], inside, [hi]])
+        # outside the sampled range the spectrum continues at its end values (np.interp's clamp)
+        flux = np.interp(grid, wl, sp)
+        area = 0.0
+        for j in range(grid.size - 1):
+            area += 0.5 * (flux[j] + flux[j + 1]) * (grid[j + 1] - grid[j])
+        out[i] = area / (hi - lo)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # grism.py
 # ---------------------------------------------------------------------------

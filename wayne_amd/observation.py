@@ -54,6 +54,8 @@ class Observation(object):
         self._visit_trend = False
         self.ssv_gen = None
         self.noise_mean = self.noise_std = False
+        # extra keywords for scanning_frame / staring_frame (rng_mode, out_dtype, exact_samplers, reference_quirks)
+        self.frame_options = {}
 
     # -- setup_* (observation.py:46-291) ----------------------------------------
     def setup_observation(self, x_ref, y_ref, spatial_scan=False, scan_speed=False):
@@ -247,6 +249,7 @@ class Observation(object):
                       add_non_linear=self.add_non_linear, clip_values_det_limits=self.clip_values_det_limits,
                       add_read_noise=self.add_read_noise, add_stellar_noise=self.add_stellar_noise,
                       add_initial_bias=self.add_initial_bias, threads=self.threads)
+        common.update(self.frame_options)
         if self.spatial_scan:
             args = (x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux, planet_depths,
                     self.scan_speed, sample_rate, sample_mid_points, sample_durations, read_index)

@@ -145,15 +145,23 @@ def rebin_spec(wavelength, spectrum, new_wavelength):
     """Flux-conserving rebin onto the bins centred on `new_wavelength`.
 
     The reference delegates this to pysynphot (tools.py:131-149), which is not
-    available: here the input spectrum is integrated (trapezoid rule on the
-    cumulative integral) over each output bin, the bin edges lying half-way
-    between output centres.  Parity with pysynphot is unpinned."""
+    available: here the input spectrum, piecewise linear between its samples, is
+    integrated exactly over each output bin (through its cumulative integral),
+    the bin edges lying half-way between output centres.  Parity with pysynphot
+    is unpinned; checked against oracle/wayne_oracle.py::rebin_spec."""
     wl = np.asarray(wavelength, dtype=float)
     sp = np.asarray(spectrum, dtype=float)
     new = np.asarray(new_wavelength, dtype=float)
     edges = bin_centers_to_edges(new)
+    # integral of the piecewise-linear spectrum from wl[0] to each edge: the whole intervals below the edge plus
+    # the trapezoid from the last sample to the edge (quadratic inside an interval); beyond the sampled range the
+    # spectrum continues at its end values
     cum = np.concatenate([[0.0], np.cumsum(0.5 * (sp[1:] + sp[:-1]) * np.diff(wl))])
-    at_edges = np.interp(edges, wl, cum)
+    j = np.clip(np.searchsorted(wl, edges, side="right") - 1, 0, wl.size - 1)
+    f_edge = np.interp(edges, wl, sp)
+    at_edges = cum[j] + 0.5 * (sp[j] + f_edge) * (edges - wl[j])
+    below = edges < wl[0]
+    at_edges[below] = sp[0] * (edges[below] - wl[0])
     return np.diff(at_edges) / np.diff(edges)
 
 
