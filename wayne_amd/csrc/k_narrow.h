@@ -154,14 +154,13 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
 // electrons (the spectrum is smooth), and the per-electron work is the draw and the deposit alone.
 // Electron j of the bin takes pair j of the bin's STAGE_LANE stream; the first n_wide electrons take
 // sigma_h (pyparallel_menu.c:89-107).  Same arithmetic as k_throw's Philox mode.
-constexpr int kLaneThreads = 256;
-static_assert(kLaneThreads == kNarrowThreads, "k_lane and k_narrow share ThrowArgs::chunk_order");
+constexpr int kLaneThreads = 512;
 // The tile must hold practically every electron: one that falls outside takes the global-atomic path INSIDE the
 // loop (four flat-plane loads, the fp64 flat polynomial, a 64-bit atomic: microseconds of latency with the other
 // 63 lanes of the wave idle).  At a margin of 22 px (3.7 sigma_h) 3 % of the wave-iterations had such a lane and
 // the kernel ran at 220 cycles per iteration instead of ~135; 30 px is 5 sigma_h.
 constexpr int kLaneMargin = 30;
-constexpr int kLaneTile = 4608;         // ints of LDS (18 KB): 256 bins span ~10 px of the trace, + 2 x margin, by 2 x margin + a few rows
+constexpr int kLaneTile = 5376;         // ints of LDS (21 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
 
 template <int FLUSH>
 __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   __shared__ int s_box[4];
   const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
-  const int w = (int)a.chunk_order[blockIdx.y] * kLaneThreads + tid;
+  const int w = (int)a.lane_order[blockIdx.y] * kLaneThreads + tid;
   const size_t kw = (size_t)k * a.W + (w < a.W ? w : 0);
   const int n = (w < a.W) ? a.nlane[kw] : 0;
   if (!__syncthreads_or(n > 0)) return;

@@ -59,6 +59,7 @@ struct ThrowArgs {
   // k_narrow / k_lane: chunk (of 256 bins) handled by the workgroups with blockIdx.y = rank -- heaviest chunks
   // first, so that the last workgroups of the launch, which run on a nearly empty chip, are the light ones
   unsigned char chunk_order[kMaxChunks];
+  unsigned char lane_order[kMaxChunks];    // the same for k_lane's chunks (kLaneThreads bins each)
   const double* xpos;      // [K*W]
   const double* ypos;      // [K*W]
   const double* sigl;      // [W]

@@ -87,6 +87,7 @@ struct Slot {
   double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   unsigned char chunk_order[kMaxChunks] = {0};   // chunks of 256 bins, most electrons first (ThrowArgs::chunk_order)
+  unsigned char lane_order[kMaxChunks] = {0};    // chunks of kLaneThreads bins, most electrons first
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
   char* stage = nullptr;
@@ -328,10 +329,12 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
 // in the longest sub-sample of an exposure
 // (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
 // the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
-double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order) {
+double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
+                       unsigned char* lane_order) {
   const int W = d->n_wl, K = d->n_samples;
   const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
-  std::vector<double> chunk_e((size_t)n_chunks, 0.);
+  const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
+  std::vector<double> chunk_e((size_t)n_chunks, 0.), lane_e((size_t)n_lane_chunks, 0.);
   double dur_max = 0.;
   for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
   const GrismDev& g = c->g;
@@ -355,6 +358,7 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
     double cnt = d->flux[i] * sens * (left + right) * 1e4 * dur_max * 1e-3 * d->scale_factor;
     if (!(cnt > 0.)) continue;
     chunk_e[(size_t)(i / kNarrowThreads)] += cnt;
+    lane_e[(size_t)(i / kLaneThreads)] += cnt;
     if (d->rng_mode == WAYNE_RNG_SPLIT) {
       const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
       const double sl = poly3(g.p_sigl, x);
@@ -369,6 +373,10 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
   for (int i = 0; i < n_chunks; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return chunk_e[a_] > chunk_e[b_]; });
   for (int i = 0; i < n_chunks && i < kMaxChunks; ++i) chunk_order[i] = (unsigned char)order[i];
+  order.resize((size_t)n_lane_chunks);
+  for (int i = 0; i < n_lane_chunks; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return lane_e[a_] > lane_e[b_]; });
+  for (int i = 0; i < n_lane_chunks && i < kMaxChunks; ++i) lane_order[i] = (unsigned char)order[i];
   return total;
 }
 
@@ -720,7 +728,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.frame = c->pa_frame.as<int32_t>();
     if ((size + kNarrowThreads - 1) / kNarrowThreads > kMaxChunks && (any_lane || any_split))
       return fail(c, WAYNE_E_INVALID, "psf_apply: more than 32768 bins in split mode");
-    for (int i = 0; i < kMaxChunks; ++i) a.chunk_order[i] = (unsigned char)i;
+    for (int i = 0; i < kMaxChunks; ++i) a.chunk_order[i] = a.lane_order[i] = (unsigned char)i;
     if (run > 0) {
       ProfScope ps(c, PK_THROW);
       rc = (rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 0>(c, a, lds_ints) : launch_throw<1, 0>(c, a, lds_ints);
@@ -934,7 +942,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
-  s.est_thrown = estimate_thrown(c, d, s.chunk_order);
+  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order);
   if ((rc = prepare_sky_tables(c, s))) return rc;
   s.uploaded = true;
   s.front_done = false;
@@ -1086,6 +1094,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.nsplit = s.nsplit.as<int32_t>();
     a.nlane = s.nlane.as<int32_t>();
     std::memcpy(a.chunk_order, s.chunk_order, sizeof a.chunk_order);
+    std::memcpy(a.lane_order, s.lane_order, sizeof a.lane_order);
     a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sigl = s.sigl.as<double>(); a.sigh = s.sigh.as<double>();
     for (int i = 0; i < 4; ++i) a.flat[i] = c->has_flat ? c->flat[i].as<float>() : nullptr;
