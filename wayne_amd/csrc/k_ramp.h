@@ -156,26 +156,6 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   // <= kSkyPiece (additivity again), so that exp(-mean) stays far from underflow whatever the plane holds
   float ld = lam - lam_level;
   if (ld > 0.f) {
-    if (M::fast && !PIECES) {
-      // One piece of mean <= kSkyPiece, in practice a fraction of an electron: count how many of the first
-      // cumulative probabilities e^-m (1, 1 + m, 1 + m + m^2/2, ...) lie below u -- four compares, no loop,
-      // no division -- and only when u lies beyond them all (for m = 1: 4e-3 of the draws) continue the search.
-      const float u = M::u01(wr);
-      float t = M::exp_(-ld), cdf = t, j = 0.f;
-      j += (u > cdf) ? 1.f : 0.f;  t = t * ld;               cdf += t;
-      j += (u > cdf) ? 1.f : 0.f;  t = t * (ld * 0.5f);       cdf += t;
-      j += (u > cdf) ? 1.f : 0.f;  t = t * (ld * 0.33333334f); cdf += t;
-      j += (u > cdf) ? 1.f : 0.f;
-      if (u > cdf) {
-        for (int it = 4; it < 512; ++it) {
-          t = t * M::div_(ld, (float)it);
-          cdf += t;
-          if (!(u > cdf)) break;
-          j = j + 1.f;
-        }
-      }
-      return k + j;
-    }
     for (;;) {
       const float piece = PIECES ? fminf(ld, kSkyPiece) : ld;
       float u = M::u01(wr);
@@ -195,6 +175,35 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
     }
   }
   return k;
+}
+
+// sky_draw in production math with the pixel's remainder mean m and e^-m handed in: both change only when the read
+// interval does (SPARS sequences repeat theirs), so the read loop keeps them from one read to the next.
+template <class RNG>
+__device__ __forceinline__ float sky_draw_cached(const uint32_t* tab, float m, float em, RNG& rng) {
+  uint32_t w, wr;
+  rng.next2(w, wr);
+  const uint32_t idx = w >> 24;
+  const uint32_t e = tab[idx];
+  const float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
+  // count how many of the first cumulative probabilities e^-m (1, 1 + m, 1 + m + m^2/2, ...) lie below u -- four
+  // compares, no loop, no division -- and only when u lies beyond them all (for m = 1: 4e-3 of the draws) continue
+  // the search (m = 0: e^-m = 1 >= u, nothing drawn)
+  const float u = u01f(wr);
+  float t = em, cdf = t, j = 0.f;
+  j += (u > cdf) ? 1.f : 0.f;  t = t * m;                 cdf += t;
+  j += (u > cdf) ? 1.f : 0.f;  t = t * (m * 0.5f);         cdf += t;
+  j += (u > cdf) ? 1.f : 0.f;  t = t * (m * 0.33333334f);  cdf += t;
+  j += (u > cdf) ? 1.f : 0.f;
+  if (u > cdf) {
+    for (int it = 4; it < 512; ++it) {
+      t = t * FastMath::div_(m, (float)it);
+      cdf += t;
+      if (!(u > cdf)) break;
+      j = j + 1.f;
+    }
+  }
+  return k + j;
 }
 
 // Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
@@ -252,7 +261,9 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
 
 // SKY: 0 = Poisson(lam) per pixel (sky_counts), 1 = alias tables + one-piece remainder, 2 = alias tables +
 // remainder in pieces (a master sky with hot pixels)
-template <class OutT, bool FAST, int SKY>
+// NOISE: the optional gaussian noise stage (noise_mean / noise_std; off in every shipped configuration) is
+// compiled in or out: its stream would otherwise hold four registers of a kernel that lives at the 64-VGPR limit
+template <class OutT, bool FAST, int SKY, bool NOISE>
 __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ramp(RampArgs a) {
   // (8 waves per SIMD = 64 VGPRs: the kernel hides its plane loads behind other waves' arithmetic; at 66 VGPRs
   // and 7 waves it measured 0.116 ms instead of 0.108)
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   const bool do_dark = (a.flags & (1u << 6)) != 0 && a.dark_sci && a.dark_err;
   const bool do_lin = (a.flags & (1u << 2)) != 0 && a.lin[0];
   const bool gainvar = (a.flags & (1u << 1)) != 0 && a.pfl;
-  const bool do_noise = (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
+  const bool do_noise = NOISE && (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
   const bool do_sky = a.sky_ct_s > 0. && a.sky;
 
   if (tid < a.R) {
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   float ds_next = ld_dark ? dsp[0] : 0.f, de_next = ld_dark ? dep[0] : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
+  float sky_c = -1.f, sky_m = 0.f, sky_em = 1.f;
   for (int r = 0; r < a.R; ++r) {
     const long long q = q_next;
     const float ds = ds_next, de = de_next;
@@ -359,7 +371,14 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
       if (skyv > 0.f) {                                  // += np.random.poisson(master_sky) (:495)
         // master_sky *= bg_count is an in-place float32 multiply (:493)
         const float lam = skyv * s_c[r];
-        if (ALIAS) {
+        if (ALIAS && FAST && SKY == 1) {
+          if (s_c[r] != sky_c) {                         // a new read interval: the pixel's remainder mean and its e^-m
+            sky_c = s_c[r];
+            sky_m = fmaxf(lam - sky_base * sky_c, 0.f);
+            sky_em = FastMath::exp_(-sky_m);
+          }
+          if (lam > 0.f) px = px + (double)sky_draw_cached(s_tab[s_tab0[r] + sky_lvl], sky_m, sky_em, rs);
+        } else if (ALIAS) {
           if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[s_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
         } else {
           px = px + (double)s_tab[r][tid];

@@ -502,6 +502,18 @@ int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
   return WAYNE_OK;
 }
 
+template <class OutT, bool FAST, int SKY>
+void (*ramp_noise(bool noise))(RampArgs) { return noise ? k_ramp<OutT, FAST, SKY, true> : k_ramp<OutT, FAST, SKY, false>; }
+template <class OutT, bool FAST>
+void (*ramp_sky(int sky, bool noise))(RampArgs) {
+  return sky == 1 ? ramp_noise<OutT, FAST, 1>(noise) : sky == 2 ? ramp_noise<OutT, FAST, 2>(noise) : ramp_noise<OutT, FAST, 0>(noise);
+}
+// k_ramp<reads' type, production / exact math, sky sampler, gaussian-noise stage>
+void (*pick_ramp(bool f64, bool exact, int sky, bool noise))(RampArgs) {
+  return f64 ? (exact ? ramp_sky<double, false>(sky, noise) : ramp_sky<double, true>(sky, noise))
+             : (exact ? ramp_sky<float, false>(sky, noise) : ramp_sky<float, true>(sky, noise));
+}
+
 template <int FLUSH>
 int launch_lane(wayne_ctx* c, const ThrowArgs& a) {
   const dim3 grid((unsigned)a.K, (unsigned)((a.W + kLaneThreads - 1) / kLaneThreads));
@@ -1179,13 +1191,8 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
     ProfScope ps(c, PK_RAMP, true);
     const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
     const int sky_mode = a.sky_alias == nullptr ? 0 : (sky_pieces ? 2 : 1);
-    void (*kern)(RampArgs) =
-        sky_mode == 1 ? (f64 ? (exact ? k_ramp<double, false, 1> : k_ramp<double, true, 1>)
-                             : (exact ? k_ramp<float, false, 1> : k_ramp<float, true, 1>))
-        : sky_mode == 2 ? (f64 ? (exact ? k_ramp<double, false, 2> : k_ramp<double, true, 2>)
-                               : (exact ? k_ramp<float, false, 2> : k_ramp<float, true, 2>))
-                        : (f64 ? (exact ? k_ramp<double, false, 0> : k_ramp<double, true, 0>)
-                               : (exact ? k_ramp<float, false, 0> : k_ramp<float, true, 0>));
+    const bool noise = d.noise_mean != 0. && d.noise_std != 0.;
+    void (*kern)(RampArgs) = pick_ramp(f64, exact, sky_mode, noise);
     if (ps.on) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, ps.rec.a, ps.rec.b, 0, a);
     else hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
