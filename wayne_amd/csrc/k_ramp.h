@@ -70,7 +70,7 @@ struct RampArgs {
 constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
 constexpr float kSkyPiece = 16.f; // largest mean drawn by one sequential search
 
-constexpr int kRampThreads = 256;
+constexpr int kRampThreads = 1024;
 constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
 
 // Box-Muller pair from two words.  EXACT mirrors the oracle's libm formula;
@@ -269,8 +269,9 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   // and 7 waves it measured 0.116 ms instead of 0.108)
   constexpr bool ALIAS = SKY != 0;
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
-  static_assert(kSkyAlias == kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
-  __shared__ uint32_t s_tab[kMaxReads][kSkyAlias];   // ALIAS: alias tables; else: sky counts [read][thread]
+  static_assert(kSkyAlias <= kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
+  // ALIAS: alias tables [table][entry]; else: sky counts [read][thread]
+  __shared__ uint32_t s_tab[kMaxReads][ALIAS ? kSkyAlias : kRampThreads];
   __shared__ float s_c[kMaxReads + 1];
   __shared__ int s_tab0[kMaxReads + 1];   // first alias table of read r (a per-read index into the kernel arguments would be a global load)
   const int S = a.S;
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   if (interior && do_sky) skyv = a.sky[p];
   __syncthreads();
   if (!ALIAS) {
-    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c, s_tab);
+    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c,
+                                 (uint32_t (*)[kRampThreads])&s_tab[0][0]);
     __syncthreads();
   }
   if (!valid) return;
