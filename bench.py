@@ -411,9 +411,9 @@ def main():
         sb = survey_bytes(N, S, R, K, W, ob, 1.64e5)
         throw_ms = prof["k_throw"]["ms"] / max(prof["k_throw"]["launches"], 1)
         narrow_ms = prof["k_narrow"]["ms"] / max(prof["k_narrow"]["launches"], 1)
-        # WAYNE_FORK_NARROW (default on): the library launches k_narrow on a side stream beside k_throw and
-        # its k_throw profile interval then covers both kernels
-        forked = args.thrower == "split" and os.environ.get("WAYNE_FORK_NARROW", "1") != "0"
+        # WAYNE_FORK_NARROW=1 (default off): the library launches k_narrow on a side stream beside k_lane and
+        # the k_throw profile interval then covers both kernels
+        forked = args.thrower == "split" and os.environ.get("WAYNE_FORK_NARROW", "0") not in ("", "0")
         # (the k_throw interval always includes k_lane, which follows it on the slot's stream)
         thrower_ms = throw_ms if forked else throw_ms + narrow_ms
         electrons = prof["electrons"] / max(n_break, 1)

@@ -22,7 +22,7 @@ namespace wayne {
 // One lane per bin, 256 consecutive bins per workgroup, cells visited in
 // lockstep with wave-level skipping (a cell is processed only while some lane
 // still holds electrons).  Random words: the bin's STAGE_NARROW stream.
-constexpr int kNarrowThreads = 256;
+constexpr int kNarrowThreads = 512;
 constexpr int kNarrowCells = 2 * kNarrowR + 1;
 constexpr int kNarrowTile = 1536;       // ints of LDS for the workgroup's tile (its bins span ~15 x 1 px + the 13 x 13 windows)
 
