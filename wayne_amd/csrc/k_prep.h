@@ -62,6 +62,8 @@ struct PrepArgs {
   uint32_t seed, exposure;
   uint32_t flags;
   int split_min;             // > 0: WAYNE_RNG_SPLIT -- bins with >= split_min narrow electrons go to k_narrow
+  int lane_max;              // WAYNE_RNG_SPLIT: most one-by-one electrons a bin's own lane takes (kLaneMax; unlimited
+                             // when the host launches no k_throw for the exposure because it expects no larger bin)
   double scale_factor;
   const double* wl;          // [W]
   const double* flux;        // [W]
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sl > 0.05 &&
                          sl * 6.5 <= (double)kNarrowR;
       const uint32_t ind = split ? wide : c;                 // electrons thrown one by one
-      const bool lane = a.split_min > 0 && ind <= (uint32_t)kLaneMax;
+      const bool lane = a.split_min > 0 && ind <= (uint32_t)a.lane_max;
       a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
       a.nlane[(size_t)k * W + w] = lane ? (int32_t)ind : 0;
       n_split_total += (split ? narrow : 0u) + (lane ? ind : 0u);
@@ -251,15 +253,56 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// cosmic rays : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
+// ---------------------------------------------------------------------------
+// One workgroup per read interval adds the interval's hits to the accumulators (in electrons, before the
+// gain: exposure_generator.py:497-505).  Fifteen small workgroups: they ride in k_prep_fix's launch instead of
+// one of their own (a launch of its own costs more than the work: ~8 us on the exposure's critical path).
+struct CosmicArgs {
+  int R, N, S;
+  uint32_t seed, exposure;
+  double rate;               // hits per second per 1024^2 pixels; < 0: no cosmic rays
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S]
+};
+
+__device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t* s_n) {
+  if (threadIdx.x == 0) {
+    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
+    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
+    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
+    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
+    if (!(n >= 0.)) n = 0.;
+    if (n > 1e7) n = 1e7;
+    *s_n = (uint32_t)n;
+  }
+  __syncthreads();
+  const uint32_t n = *s_n;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
+    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
+    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
+    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
+    const long long q = (long long)energy << kQBits;
+    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
+              (unsigned long long)q);
+  }
+}
+
 // One workgroup per sub-sample: chunk offsets -> global exclusive prefix, E_k,
 // bounding box -> LDS tile rectangle, SubInfo.
-__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks) {
+// (launched with max(K, R) workgroups: workgroup r < R also adds the cosmic-ray hits of read interval r)
+__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks, CosmicArgs ca) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int W = a.W;
   __shared__ uint32_t s_off[64];
   __shared__ uint32_t s_E;
   __shared__ int s_over;
+  __shared__ uint32_t s_hits;
+  if (k < ca.R && ca.rate >= 0.) cosmic_hits(ca, k, &s_hits);
+  if (k >= a.K) return;
   if (tid == 0) {
     uint64_t run = 0;
     int over = 0;

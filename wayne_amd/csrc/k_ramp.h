@@ -1,45 +1,8 @@
-// k_cosmic and k_ramp: cosmic rays, per-read and post-ramp stages (A13-A15)
+// k_ramp: per-read and post-ramp stages (A13-A15); the cosmic-ray hits of A13 are added by k_prep_fix (k_prep.h)
 #pragma once
 #include "common.h"
 
 namespace wayne {
-
-// ---------------------------------------------------------------------------
-// k_cosmic : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
-// ---------------------------------------------------------------------------
-struct CosmicArgs {
-  int R, N, S;
-  uint32_t seed, exposure;
-  double rate;               // hits per second per 1024^2 pixels
-  const double* read_dt;     // [R]
-  long long* acc;            // [R*S*S]
-};
-
-__global__ __launch_bounds__(256) void k_cosmic(CosmicArgs a) {
-  const int r = blockIdx.x;
-  if (r >= a.R) return;
-  __shared__ uint32_t s_n;
-  if (threadIdx.x == 0) {
-    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
-    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
-    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
-    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
-    if (!(n >= 0.)) n = 0.;
-    if (n > 1e7) n = 1e7;
-    s_n = (uint32_t)n;
-  }
-  __syncthreads();
-  const uint32_t n = s_n;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
-    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
-    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
-    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
-    const long long q = (long long)energy << kQBits;
-    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
-              (unsigned long long)q);
-  }
-}
 
 // ---------------------------------------------------------------------------
 // k_ramp : fused up-the-ramp kernel, one thread per bordered pixel

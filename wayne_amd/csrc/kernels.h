@@ -4,12 +4,13 @@
 //   k_prep.h        k_prep_wl      per-wavelength arrays: PSF polynomials, sensitivity LUT, bin widths   (A8, A9)
 //                   k_prep_sub     per sub-sample: trace, bin positions, expected counts, Poisson/round,
 //                                  sigma split, routing of the bins, chunk-local prefix                  (A6, A7, A9, A10)
-//                   k_prep_fix     global prefix, electron count and clip rectangle per sub-sample
+//                   k_prep_fix     global prefix, electron count and clip rectangle per sub-sample; cosmic-ray hits
+//                                  per read interval                                                      (A13, cosmic_rays.py)
 //   k_throw.h       k_throw        the electron thrower: LDS int32 tile per workgroup slice,
 //                                  flushed x flat into the read-interval accumulator                     (A1-A4, A11, A12)
-//   k_narrow.h      k_narrow       narrow PSF component as one multinomial per bin; sparse bins lane per bin
-//   k_ramp.h        k_cosmic       cosmic-ray hits per read interval                                      (A13, cosmic_rays.py)
-//                   k_ramp         fused up-the-ramp kernel: sky, gain, cumulative, dark, non-linearity,
+//   k_narrow.h      k_narrow       narrow PSF component as one multinomial per bin
+//                   k_lane         a bin's one-by-one electrons (wide component, thin bins) thrown by its own lane
+//   k_ramp.h        k_ramp         fused up-the-ramp kernel: sky, gain, cumulative, dark, non-linearity,
 //                                  clip, reference pixels, zero read, read noise                          (A13-A15)
 //
 // "A<n>" are the row ids of SURVEY.md section 8(a); reference file:line

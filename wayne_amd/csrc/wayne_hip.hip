@@ -1022,6 +1022,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   }
   // margin of a thrower workgroup's tile around its slice of the trace: 5 sigma_h, so that practically no electron
   // takes the in-loop global-atomic path (see k_lane)
+  bool lane_unlimited = false;
   const int margin = d.thrower_margin > 0 ? d.thrower_margin : 30;
   {
     PrepArgs a{};
@@ -1042,6 +1043,12 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.nsplit = s.nsplit.as<int32_t>();
     a.nlane = s.nlane.as<int32_t>();
     a.split_min = (d.rng_mode == WAYNE_RNG_SPLIT) ? kSplitMin : 0;
+    // no bin expected beyond a lane's cap (the rule on every BASELINE configuration): k_throw is not launched at
+    // all -- an empty launch still costs ~8 us of the exposure's critical path -- and the lanes take whatever
+    // they find (a bin that defies the estimate is thrown by its lane, slowly but completely)
+    a.lane_max = (d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0. && d.thrower_splits <= 0 &&
+                  !std::getenv("WAYNE_THROW_WGS")) ? 0x7FFFFFFF : kLaneMax;
+    lane_unlimited = a.lane_max == 0x7FFFFFFF;
     a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sub = s.sub.as<SubInfo>();
     a.total_electrons = c->counters.as<unsigned long long>();
@@ -1052,22 +1059,13 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     ProfScope ps(c, PK_PREP_SUB);
     hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
-    HIP_TRY(c, hipGetLastError());
-  }
-  // cosmic rays only add into the accumulators too: in split mode they ride on the side stream
-  bool cosmic_done = false;
-  auto launch_cosmic = [&]() -> int {
-    cosmic_done = true;
-    if (!(d.cosmic_rate >= 0.)) return WAYNE_OK;
     CosmicArgs ca{};
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
-    ca.rate = d.cosmic_rate; ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
-    ProfScope ps(c, PK_COSMIC);
-    hipLaunchKernelGGL(k_cosmic, dim3(R), dim3(256), 0, c->stream, ca);
+    ca.rate = (d.cosmic_rate >= 0.) ? d.cosmic_rate : -1.;
+    ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
+    hipLaunchKernelGGL(k_prep_fix, dim3(std::max(K, R)), dim3(kPrepThreads), 0, c->stream, a, n_chunks, ca);
     HIP_TRY(c, hipGetLastError());
-    return WAYNE_OK;
-  };
+  }
   {
     ThrowArgs a{};
     a.W = W; a.K = K; a.N = N; a.S = S;
@@ -1134,13 +1132,13 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
           ProfScope ps(c, PK_NARROW);
           rc = launch_narrow<1>(c, a, (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0);
         }
-        if (rc == WAYNE_OK) rc = launch_cosmic();
         if (rc == WAYNE_OK && hipEventRecord(c->ev_join[si_], c->side[si_]) != hipSuccess)
           rc = fail(c, WAYNE_E_HIP, "run: event record on the side stream");
         c->stream = main_stream;
         if (rc) return rc;
       }
-      int rc = (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
+      int rc = lane_unlimited ? (int)WAYNE_OK
+               : (d.rng_mode == WAYNE_RNG_REPLAY) ? launch_throw<0, 1>(c, a, lds_ints) : launch_throw<1, 1>(c, a, lds_ints);
       if (rc) return rc;
       if (d.rng_mode == WAYNE_RNG_SPLIT) {
         ProfScope ps(c, PK_LANE);
@@ -1155,7 +1153,6 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     }
   }
   s.acc_dirty = true;
-  if (!cosmic_done) { int rc = launch_cosmic(); if (rc) return rc; }
   s.front_done = true;
   return WAYNE_OK;
 }
