@@ -6,7 +6,7 @@
 One "step" = one whole exposure (1014x1014 frame, NSAMP = 16, 128-sub-sample
 spatial scan, 1e9 electrons: BASELINE.json configs[3], the configuration the
 metric is quoted on) synthesised by the HIP path: k_prep_wl, k_prep_sub,
-k_lane || k_narrow (+ k_throw for oversized bins), k_cosmic, k_ramp.  All inputs and calibration planes are
+k_prep_fix (+ cosmic-ray hits), k_lane, k_narrow (+ k_throw for oversized bins), k_ramp.  All inputs and calibration planes are
 resident in HBM before the timed region; outputs stay in HBM (device-complete
 rate).  Exposures are independent: with N ranks each rank runs its own K
 exposures (round-robin exposure indices, no collective in the data path) ->
@@ -449,7 +449,7 @@ def main():
             "thrower": {"mode": args.thrower, "electrons_per_exposure": electrons, "ms": thrower_ms,
                         "electrons_per_s": electrons / (thrower_ms * 1e-3) if thrower_ms > 0 else None,
                         "note": "split mode: the k_throw interval spans k_throw (bins beyond a lane's cap: normally none) + "
-                                "k_lane on the slot's stream with k_narrow + k_cosmic beside them on a side stream"
+                                "k_lane on the slot's stream with k_narrow beside them on a side stream"
                         if forked else "k_throw + k_lane (one interval), then k_narrow, on one stream"},
         }
         line.update(extras)

@@ -108,7 +108,7 @@ def test_cfg5_every_switch_on_same_counters():
 def test_cfg5_default_split_thrower_same_counters():
     # the production default (split thrower + alias-table sky) against oracle/split_oracle.c on the same counters;
     # a moved electron shows as +-1 e- in two pixels of every later read.  First without cosmic rays, so that the
-    # accumulators hold the thrower's electrons only (k_cosmic adds its hits to the same accumulators) ...
+    # accumulators hold the thrower's electrons only (the cosmic-ray hits go into the same accumulators) ...
     v, got, want, rec, orec = both("cfg5", K=16, thrower="split", rng_mode=_lib.RNG_SPLIT, scale_factor=40.0,
                                    cosmic_rate=None)
     acc_o = np.stack(orec["acc"])

@@ -149,7 +149,7 @@ def test_spectrum_both_modes_agree_statistically(gpu_ctx):
     assert abs(prof_a[far].sum() - prof_b[far].sum()) < 5 * np.sqrt(prof_a[far].sum() + prof_b[far].sum())
 
 
-def test_split_mode_deterministic_sparse_and_edges(gpu_ctx):
+def test_split_mode_deterministic_and_edges(gpu_ctx):
     from conftest import load_golden_psf
     k = load_golden_psf("edge_low")                                      # spectrum running off the frame
     counts = (k["counts"].astype(np.int64) * 20).astype(np.int32)

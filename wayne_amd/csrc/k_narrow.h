@@ -19,7 +19,7 @@ namespace wayne {
 // floor() wherever a pixel is kept, :91-93).  ~30-40 binomial draws replace
 // ~1400 electron throws per bin; the distribution of the frame is the same.
 //
-// One lane per bin, 256 consecutive bins per workgroup, cells visited in
+// One lane per bin, 512 consecutive bins per workgroup, cells visited in
 // lockstep with wave-level skipping (a cell is processed only while some lane
 // still holds electrons).  Random words: the bin's STAGE_NARROW stream.
 constexpr int kNarrowThreads = 512;

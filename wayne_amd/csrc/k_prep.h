@@ -90,6 +90,7 @@ struct PrepArgs {
 };
 
 constexpr int kPrepThreads = 512;
+constexpr int kMaxPrepChunks = 128;     // chunks of kPrepThreads bins per sub-sample (32768 bins)
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
 constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int W = a.W;
-  __shared__ uint32_t s_off[64];
+  __shared__ uint32_t s_off[kMaxPrepChunks];
   __shared__ uint32_t s_E;
   __shared__ int s_over;
   __shared__ uint32_t s_hits;

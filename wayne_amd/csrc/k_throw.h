@@ -38,7 +38,7 @@ namespace wayne {
 //   (detector.py:146-147).  Integer atomics commute, so the result is
 //   bit-reproducible for any launch geometry.
 constexpr int kThrowThreads = 512;
-constexpr int kMaxChunks = 128;         // 32768 bins / 256
+constexpr int kMaxChunks = 128;         // >= 32768 bins / bins per k_narrow / k_lane workgroup
 constexpr int kThrowPCache = 256;       // bins of a workgroup's slice whose prefix / parameters are kept in LDS
 
 struct ThrowArgs {
@@ -56,7 +56,7 @@ struct ThrowArgs {
   const int32_t* nwide;    // [K*W]
   const int32_t* nsplit;   // [K*W] (k_narrow)
   const int32_t* nlane;    // [K*W] (k_lane)
-  // k_narrow / k_lane: chunk (of 256 bins) handled by the workgroups with blockIdx.y = rank -- heaviest chunks
+  // k_narrow / k_lane: chunk (of one workgroup's bins) handled by the workgroups with blockIdx.y = rank -- heaviest chunks
   // first, so that the last workgroups of the launch, which run on a nearly empty chip, are the light ones
   unsigned char chunk_order[kMaxChunks];
   unsigned char lane_order[kMaxChunks];    // the same for k_lane's chunks (kLaneThreads bins each)

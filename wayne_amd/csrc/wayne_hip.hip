@@ -22,7 +22,7 @@ using namespace wayne;
 namespace {
 
 enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE, PK_NARROW, PK_LANE };
-const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub",   "k_throw",  "k_cosmic",
+const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub",   "k_throw",  "k_cosmic",   /* (cosmic rays ride in k_prep_fix: slot kept for the ABI) */
                                                     "k_ramp",    "k_lightcurve", "k_narrow", "k_lane"};
 
 struct DevBuf {
@@ -581,7 +581,7 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
       c->fork_narrow = false;     // not fatal: k_narrow then follows k_throw on the main stream
   }
-  // k_narrow (+ k_cosmic) beside k_lane on a side stream: worth 10 % when the thrower still had idle issue slots
+  // k_narrow beside k_lane on a side stream: worth 10 % when the thrower still had idle issue slots
   // (round 1); now each of the two fills the VALU by itself and running them one after the other is as fast
   // (1860 vs 1846 exposures/s on one stream, 2212 vs 2224 on two) -- off unless WAYNE_FORK_NARROW=1
   {
@@ -937,7 +937,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   HIP_TRY(c, s.sub.reserve((size_t)K * sizeof(SubInfo)));
   {
     const size_t n_chunks = (size_t)(W + kPrepThreads - 1) / kPrepThreads;
-    if (n_chunks > 64) return fail(c, WAYNE_E_INVALID, "upload: more than 32768 wavelength bins");
+    if (n_chunks > (size_t)kMaxPrepChunks || W > 32768) return fail(c, WAYNE_E_INVALID, "upload: more than 32768 wavelength bins");
     HIP_TRY(c, s.chunk_total.reserve((size_t)K * n_chunks * sizeof(uint32_t)));
     HIP_TRY(c, s.chunk_box.reserve((size_t)K * n_chunks * 4 * sizeof(double)));
   }
