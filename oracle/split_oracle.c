@@ -115,7 +115,8 @@ void wayne_oracle_binomial_vec(const float *n, const float *p, int64_t count, ui
   }
 }
 
-static float so_tail(float t) { return 0.5f * erfcf(t * 0.70710678118654752f); }
+/* P(Z > t), t >= 0; nothing beyond 6.5 sigma (k_narrow.h kTailCut) */
+static float so_tail(float t) { return t > 6.5f ? 0.0f : 0.5f * erfcf(t * 0.70710678118654752f); }
 
 /* Masses of N(frac, sigma^2) on the 13 unit cells of the window, in visiting
  * order: centre, +1, -1, +2, -2, ...  `before[c]` = mass not yet visited when
@@ -173,6 +174,172 @@ static void so_throw_one(uint32_t g[4], float x, float y, float sig, int n, int3
   if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
 }
 
+/*
+ * Pooled rows (k_narrow.h, "row pooling").  16 consecutive bins of a sub-sample sit at nearly the same height
+ * y and have nearly the same sigma_l, so their row distributions q_b(t) over a common window of SO_PROWS absolute
+ * rows are nearly equal.  Any electron's row can be drawn from the mixture
+ *     q_b = Z * (qbar / Z) + (1 - Z) * r_b,     qbar(t) = min_b q_b(t),  Z = sum_t qbar(t),
+ *     r_b = (q_b - qbar) / (1 - Z)
+ * -- with probability Z from the distribution the whole group shares, otherwise from the bin's own residual --
+ * which is exact for every Z in (0, 1].  Columns and rows are independent, so: each bin splits its electrons into
+ * "common" (Binomial(n, Z)) and "residual" ones; the common ones go through the bin's column chain and are POOLED
+ * per absolute column over the group; each column then needs ONE row chain for the whole group (its own stream,
+ * stage POOL); the residual electrons (a fraction of a per cent) are thrown one by one, column from the gaussian
+ * itself and row by inverse CDF on r_b.  A group is pooled when it has at least two split bins that are close
+ * enough (so_group_pools); otherwise every bin runs its own column and row chains as before.
+ */
+enum { SO_GROUP = 16, SO_PROWS = 2 * SO_WINDOW + 2, SO_STAGE_POOL = 11 };
+
+/* masses of N(y, sigma^2) on the rows [J0 + t, J0 + t + 1), t = 0..SO_PROWS-1, normalised to sum 1; every mass is
+ * a difference of two tails on the same side of y (no cancellation), the row that holds y is 1 - both tails */
+static void so_rows_abs(float y, float inv_s, int J0, float q[SO_PROWS]) {
+  float A[SO_PROWS + 1], E[SO_PROWS + 1];
+  for (int t = 0; t <= SO_PROWS; ++t) {
+    E[t] = (float)(J0 + t) - y;
+    A[t] = so_tail(fabsf(E[t]) * inv_s);
+  }
+  float S = 0.0f;
+  for (int t = 0; t < SO_PROWS; ++t) {
+    float m;
+    if (E[t] >= 0.0f) m = A[t] - A[t + 1];
+    else if (E[t + 1] <= 0.0f) m = A[t + 1] - A[t];
+    else m = 1.0f - A[t] - A[t + 1];
+    q[t] = m > 0.0f ? m : 0.0f;
+    S += q[t];
+  }
+  for (int t = 0; t < SO_PROWS; ++t) q[t] = q[t] / S;
+}
+
+typedef struct { int split; float n, x, y, sl; int ic, jc; } so_bin;
+
+static int so_group_pools(const so_bin *B, int nb) {
+  int act = 0, ic0 = INT32_MAX, ic1 = INT32_MIN;
+  float y0 = 3e38f, y1 = -3e38f, s0 = 3e38f, s1 = 0.0f;
+  int64_t tot = 0;
+  for (int i = 0; i < nb; ++i) {
+    if (!B[i].split) continue;
+    if (!(fabsf(B[i].x) < 1e6f && fabsf(B[i].y) < 1e6f)) return 0;
+    ++act;
+    if (B[i].ic < ic0) ic0 = B[i].ic;
+    if (B[i].ic > ic1) ic1 = B[i].ic;
+    y0 = fminf(y0, B[i].y); y1 = fmaxf(y1, B[i].y);
+    s0 = fminf(s0, B[i].sl); s1 = fmaxf(s1, B[i].sl);
+    tot += (int64_t)B[i].n;
+  }
+  return act >= 2 && ic1 - ic0 <= 2 && (y1 - y0) <= 0.25f * s0 && s1 <= 1.1f * s0 && tot <= 16777216;
+}
+
+static void so_put(int32_t *out, int n, int col, int row, float m) {
+  if (m > 0.0f && col > 0 && col < n && row > 0 && row < n) out[(size_t)row * n + col] += (int32_t)m;
+}
+
+static void so_narrow_own(const so_bin *b, int bin, const uint32_t key_n[2], uint32_t subsample, uint32_t exposure,
+                          int n, int32_t *out) {
+  const float inv_s = 1.0f / b->sl;
+  float P[SO_CELLS], Pb[SO_CELLS], Q[SO_CELLS], Qb[SO_CELLS];
+  so_cell_masses(b->x - (float)b->ic, inv_s, P, Pb);
+  so_cell_masses(b->y - (float)b->jc, inv_s, Q, Qb);
+  const uint32_t ctr[4] = {(uint32_t)bin, 0u, subsample, exposure};
+  uint32_t st[4];
+  wayne_oracle_philox4x32(ctr, key_n, st);
+  float left = b->n;
+  for (int c = 0; c < SO_CELLS && left > 0.0f; ++c) {
+    const float in_col = wayne_oracle_binomial_f(left, so_clamp01(P[c] / Pb[c]), st);
+    left -= in_col;
+    const int col = b->ic + so_cell_offset(c);
+    float col_left = in_col;
+    for (int r = 0; r < SO_CELLS && col_left > 0.0f; ++r) {
+      /* row r given that none of the rows before it was hit: its mass over the two tails still unvisited */
+      const float m = wayne_oracle_binomial_f(col_left, so_clamp01(Q[r] / Qb[r]), st);
+      col_left -= m;
+      so_put(out, n, col, b->jc + so_cell_offset(r), m);
+    }
+  }
+}
+
+static void so_narrow_pooled(const so_bin *B, int nb, int bin0, uint32_t seed, uint32_t subsample,
+                             uint32_t exposure, int n, int32_t *out) {
+  const uint32_t key_n[2] = {seed, SO_STAGE_NARROW};
+  const uint32_t key_p[2] = {seed, SO_STAGE_POOL};
+  int ic0 = INT32_MAX, jc0 = INT32_MAX;
+  for (int i = 0; i < nb; ++i)
+    if (B[i].split) { if (B[i].ic < ic0) ic0 = B[i].ic; if (B[i].jc < jc0) jc0 = B[i].jc; }
+  const int X0 = ic0 - SO_WINDOW, J0 = jc0 - SO_WINDOW;
+  float q[SO_GROUP][SO_PROWS], qbar[SO_PROWS];
+  for (int t = 0; t < SO_PROWS; ++t) qbar[t] = 3e38f;
+  for (int i = 0; i < nb; ++i) {
+    if (!B[i].split) continue;
+    so_rows_abs(B[i].y, 1.0f / B[i].sl, J0, q[i]);
+    for (int t = 0; t < SO_PROWS; ++t) qbar[t] = fminf(qbar[t], q[i][t]);
+  }
+  /* tails of qbar about the centre row SO_WINDOW, summed from the far ends inwards */
+  float PL[SO_PROWS], SU[SO_PROWS + 1];
+  PL[0] = qbar[0];
+  for (int t = 1; t <= SO_WINDOW; ++t) PL[t] = PL[t - 1] + qbar[t];
+  SU[SO_PROWS] = 0.0f;
+  for (int t = SO_PROWS - 1; t > SO_WINDOW; --t) SU[t] = SU[t + 1] + qbar[t];
+  const float Z = fminf(PL[SO_WINDOW] + SU[SO_WINDOW + 1], 1.0f);
+
+  float pooled[SO_GROUP];
+  for (int j = 0; j < SO_GROUP; ++j) pooled[j] = 0.0f;
+  for (int i = 0; i < nb; ++i) {
+    if (!B[i].split) continue;
+    const so_bin *b = &B[i];
+    const uint32_t ctr[4] = {(uint32_t)(bin0 + i), 0u, subsample, exposure};
+    uint32_t st[4];
+    wayne_oracle_philox4x32(ctr, key_n, st);
+    const float common = wayne_oracle_binomial_f(b->n, Z, st);
+    const int residual = (int)(b->n - common);
+    /* the common electrons' columns */
+    const float inv_s = 1.0f / b->sl;
+    float P[SO_CELLS], Pb[SO_CELLS];
+    so_cell_masses(b->x - (float)b->ic, inv_s, P, Pb);
+    float left = common;
+    for (int c = 0; c < SO_CELLS && left > 0.0f; ++c) {
+      const float in_col = wayne_oracle_binomial_f(left, so_clamp01(P[c] / Pb[c]), st);
+      left -= in_col;
+      pooled[b->ic + so_cell_offset(c) - X0] += in_col;
+    }
+    /* the residual electrons, one by one: two pairs each (column from the gaussian, row by inverse CDF on q - qbar) */
+    float D[SO_PROWS], R = 0.0f;                /* running sums of the residual row masses */
+    for (int t = 0; t < SO_PROWS; ++t) { R += q[i][t] - qbar[t]; D[t] = R; }
+    const float cs = (-1.3862943611198906f * b->sl) * b->sl;
+    for (int e = 0; e < residual; ++e) {
+      uint32_t w[2], v[2];
+      wayne_oracle_xo_next2(st, w);
+      wayne_oracle_xo_next2(st, v);
+      const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
+      const float Rs = sqrtf(cs * log2f(so_u01(w[1])));
+      int col = (int)floorf(fmaf(cosf(ang), Rs, b->x));
+      if (col < b->ic - SO_WINDOW) col = b->ic - SO_WINDOW;
+      if (col > b->ic + SO_WINDOW) col = b->ic + SO_WINDOW;
+      const float u = so_u01(v[0]) * R;
+      int row = 0;
+      for (int t = 0; t < SO_PROWS - 1; ++t) row += (u >= D[t]);
+      so_put(out, n, col, J0 + row, 1.0f);
+    }
+  }
+  /* one row chain per pooled column: centre row first, then alternately above and below */
+  for (int j = 0; j < SO_GROUP; ++j) {
+    if (!(pooled[j] > 0.0f)) continue;
+    const uint32_t ctr[4] = {(uint32_t)(bin0 / SO_GROUP), (uint32_t)j, subsample, exposure};
+    uint32_t st[4];
+    wayne_oracle_philox4x32(ctr, key_p, st);
+    float left = pooled[j];
+    int up = SO_WINDOW + 1, lo = SO_WINDOW - 1;
+    for (int i = 0; i < SO_PROWS && left > 0.0f; ++i) {
+      int t;
+      float rem;
+      if (i == 0) { t = SO_WINDOW; rem = PL[SO_WINDOW] + SU[SO_WINDOW + 1]; }
+      else if (i & 1) { t = up; rem = SU[up] + (lo >= 0 ? PL[lo] : 0.0f); ++up; }
+      else { t = lo; rem = SU[up] + PL[lo]; --lo; }
+      const float m = wayne_oracle_binomial_f(left, so_clamp01(qbar[t] / rem), st);
+      left -= m;
+      so_put(out, n, X0 + j, J0 + t, m);
+    }
+  }
+}
+
 int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos, const double *y_pos,
                            const double *psf_ratio, const double *psf_sigmal, const double *psf_sigmah,
                            int n, int split_min, int lane_max, uint32_t seed, uint32_t exposure,
@@ -184,59 +351,48 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
   const uint32_t key_l[2] = {seed, SO_STAGE_LANE};
   uint64_t e = 0;
   uint32_t g[4] = {0, 0, 0, 0};
-  for (int b = 0; b < size; ++b) {
-    if (counts[b] < 0) return -2;
-    const double nwd = (double)counts[b] * psf_ratio[b];
-    int64_t n_wide = (nwd >= 2147483647.0) ? 2147483647 : (nwd > -2147483648.0 ? (int64_t)(int32_t)nwd : -2147483648LL);
-    if (n_wide < 0) n_wide = 0;
-    if (n_wide > counts[b]) n_wide = counts[b];
-    const int64_t n_narrow = counts[b] - n_wide;
-    /* (the chain counts in float32: bins beyond 2^24 narrow electrons stay with the per-electron thrower) */
-    const int split = split_min > 0 && n_narrow >= split_min && n_narrow <= 16777216 && psf_sigmal[b] > 0.05 &&
-                      psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
-    const float x = (float)x_pos[b], y = (float)y_pos[b];
-    const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
+  for (int b0 = 0; b0 < size; b0 += SO_GROUP) {
+    const int nb = size - b0 < SO_GROUP ? size - b0 : SO_GROUP;
+    so_bin B[SO_GROUP];
+    for (int i = 0; i < nb; ++i) {
+      const int b = b0 + i;
+      if (counts[b] < 0) return -2;
+      const double nwd = (double)counts[b] * psf_ratio[b];
+      int64_t n_wide = (nwd >= 2147483647.0) ? 2147483647 : (nwd > -2147483648.0 ? (int64_t)(int32_t)nwd : -2147483648LL);
+      if (n_wide < 0) n_wide = 0;
+      if (n_wide > counts[b]) n_wide = counts[b];
+      const int64_t n_narrow = counts[b] - n_wide;
+      /* (the chain counts in float32: bins beyond 2^24 narrow electrons stay with the per-electron thrower) */
+      const int split = split_min > 0 && n_narrow >= split_min && n_narrow <= 16777216 && psf_sigmal[b] > 0.05 &&
+                        psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
+      const float x = (float)x_pos[b], y = (float)y_pos[b];
+      const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
+      B[i].split = split; B[i].n = (float)n_narrow; B[i].x = x; B[i].y = y; B[i].sl = sl;
+      B[i].ic = (int)floorf(x); B[i].jc = (int)floorf(y);
 
-    /* one by one */
-    const int64_t thrown = split ? n_wide : counts[b];
-    if (split_min > 0 && thrown <= lane_max) {
-      const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
-      uint32_t gl[4];
-      wayne_oracle_philox4x32(ctr, key_l, gl);
-      for (int64_t j = 0; j < thrown; ++j) so_throw_one(gl, x, y, (j < n_wide) ? sh : sl, n, out);
-    } else {
-      for (int64_t j = 0; j < thrown; ++j, ++e) {
-        if ((e & 127u) == 0) {
-          const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
-          wayne_oracle_philox4x32(ctr, key_t, g);
+      /* one by one */
+      const int64_t thrown = split ? n_wide : counts[b];
+      if (split_min > 0 && thrown <= lane_max) {
+        const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
+        uint32_t gl[4];
+        wayne_oracle_philox4x32(ctr, key_l, gl);
+        for (int64_t j = 0; j < thrown; ++j) so_throw_one(gl, x, y, (j < n_wide) ? sh : sl, n, out);
+      } else {
+        for (int64_t j = 0; j < thrown; ++j, ++e) {
+          if ((e & 127u) == 0) {
+            const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
+            wayne_oracle_philox4x32(ctr, key_t, g);
+          }
+          so_throw_one(g, x, y, (j < n_wide) ? sh : sl, n, out);
         }
-        so_throw_one(g, x, y, (j < n_wide) ? sh : sl, n, out);
       }
     }
-    if (!split) continue;
-
-    /* the narrow component as one multinomial */
-    const int ic = (int)floorf(x), jc = (int)floorf(y);
-    const float inv_s = 1.0f / sl;
-    float P[SO_CELLS], Pb[SO_CELLS], Q[SO_CELLS], Qb[SO_CELLS];
-    so_cell_masses(x - (float)ic, inv_s, P, Pb);
-    so_cell_masses(y - (float)jc, inv_s, Q, Qb);
-    const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
-    uint32_t st[4];
-    wayne_oracle_philox4x32(ctr, key_n, st);
-    float left = (float)n_narrow;
-    for (int c = 0; c < SO_CELLS && left > 0.0f; ++c) {
-      const float in_col = wayne_oracle_binomial_f(left, so_clamp01(P[c] / Pb[c]), st);
-      left -= in_col;
-      const int col = ic + so_cell_offset(c);
-      float col_left = in_col;
-      for (int r = 0; r < SO_CELLS && col_left > 0.0f; ++r) {
-        /* row r given that none of the rows before it was hit: its mass over the two tails still unvisited */
-        const float m = wayne_oracle_binomial_f(col_left, so_clamp01(Q[r] / Qb[r]), st);
-        col_left -= m;
-        const int row = jc + so_cell_offset(r);
-        if (m > 0.0f && col > 0 && col < n && row > 0 && row < n) out[(size_t)row * n + col] += (int32_t)m;
-      }
+    /* the narrow component of the group's split bins as multinomials */
+    if (so_group_pools(B, nb)) {
+      so_narrow_pooled(B, nb, b0, seed, subsample, exposure, n, out);
+    } else {
+      for (int i = 0; i < nb; ++i)
+        if (B[i].split) so_narrow_own(&B[i], b0 + i, key_n, subsample, exposure, n, out);
     }
   }
   return 0;

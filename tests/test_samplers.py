@@ -145,6 +145,50 @@ def test_split_oracle_lone_bin_is_the_multinomial_of_the_narrow_gaussian(sigma, 
         assert np.abs(z[n * pm > 50]).max() < 5
 
 
+@pytest.mark.parametrize("dy,dsig", [(0.001, 0.0005), (0.01, 0.004), (0.0, 0.0)])
+def test_split_oracle_pooled_rows_keep_every_pixel_marginal(dy, dsig):
+    # 64 neighbouring bins, all narrow: groups of 16 pool their row chains (oracle/split_oracle.c so_narrow_pooled).
+    # Each pixel stays a sum over the bins of Binomial(n_b, p_b): mean AND variance against the closed form, the
+    # column sums likewise (dy, dsig set how much of a bin is "residual": ~0.3 % / ~15 % / nothing).
+    N, nb, reps = 96, 64, 1500
+    b = np.arange(nb)
+    x = 40.3 + 0.04 * b
+    y = 40.3 + dy * b
+    sl = 0.7 + dsig * (b % 16)
+    counts = np.full(nb, 2000, dtype=np.int32)
+    acc = np.zeros((N, N))
+    acc2 = np.zeros((N, N))
+    col = np.zeros(N)
+    col2 = np.zeros(N)
+    for r in range(reps):
+        f = clib.psf_split_oracle(counts, x, y, np.zeros(nb), sl, np.full(nb, 5.0), N, seed=7, exposure=r, subsample=3)
+        f = f.reshape(N, N).astype(float)
+        assert f.sum() == counts.sum()
+        acc += f
+        acc2 += f * f
+        c = f.sum(axis=0)
+        col += c
+        col2 += c * c
+    mean, var = acc / reps, acc2 / reps - (acc / reps) ** 2
+    e, ev, ec, ecv = np.zeros((N, N)), np.zeros((N, N)), np.zeros(N), np.zeros(N)
+    for i in range(nb):
+        P, Q = _cell_probs(x[i], sl[i], N), _cell_probs(y[i], sl[i], N)
+        p = np.outer(Q, P)
+        e += counts[i] * p
+        ev += counts[i] * p * (1 - p)
+        ec += counts[i] * P
+        ecv += counts[i] * P * (1 - P)
+    m = e > 5
+    z = (mean - e)[m] / np.sqrt(ev[m] / reps)
+    assert m.sum() > 30
+    assert abs(z.mean()) < 4 / np.sqrt(m.sum()) and np.abs(z).max() < 4.5
+    ratio = (var / np.where(m, ev, 1))[m]
+    assert abs(ratio.mean() - 1) < 4 * np.sqrt(2.0 / reps / m.sum()) + 0.01
+    cm = ec > 50
+    cr = ((col2 / reps - (col / reps) ** 2) / np.where(cm, ecv, 1))[cm]
+    assert np.abs(cr - 1).max() < 5 * np.sqrt(2.0 / reps)
+
+
 def test_split_oracle_matches_per_electron_oracle_in_distribution():
     # the same spectrum thrown both ways, many seeds: equal pixel means within the Poisson error
     rng = np.random.default_rng(3)

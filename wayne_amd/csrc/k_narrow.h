@@ -22,17 +22,78 @@ namespace wayne {
 // One lane per bin, 512 consecutive bins per workgroup, cells visited in
 // lockstep with wave-level skipping (a cell is processed only while some lane
 // still holds electrons).  Random words: the bin's STAGE_NARROW stream.
+//
+// POOLED ROWS.  The row chains are two thirds of the draws, and the 16 bins of a
+// DPP row (w >> 4: "group") sit at practically the same height with practically
+// the same sigma_l, so their row distributions q_b(t) over a common window of 14
+// absolute rows nearly coincide.  Write
+//     q_b = Z (qbar / Z) + (1 - Z) r_b,   qbar(t) = min_b q_b(t),  Z = sum_t qbar(t),
+//     r_b = (q_b - qbar) / (1 - Z):
+// an electron takes its row from the distribution the whole group shares with
+// probability Z and from its bin's own residual otherwise -- exact for every
+// Z in (0, 1], Z = 0.99+ on a spectrum.  Rows and columns are independent, so a
+// bin (1) thins its n electrons into Binomial(n, Z) "common" and the rest
+// "residual", (2) runs its column chain on the common ones and adds the column
+// counts into the group's 16 per-column totals (LDS), (3) throws the residual
+// handful one by one (column from the gaussian itself, row by inverse CDF on
+// q_b - qbar).  Then (4) lane j of the group draws the rows of column j's total
+// in ONE chain (stream STAGE_POOL): 16 row chains per group instead of ~6 per
+// bin.  A group pools when it has >= 2 multinomial bins within 2 columns,
+// 0.25 sigma in y and 10 % in sigma of one another (Z >~ 0.8) and <= 2^24
+// electrons; any other group runs a column and a row chain per bin as above.
+// oracle/split_oracle.c (so_group_pools, so_narrow_pooled) is the same procedure.
 constexpr int kNarrowThreads = 512;
 constexpr int kNarrowCells = 2 * kNarrowR + 1;
+constexpr int kPoolRows = 2 * kNarrowR + 2;   // rows of a group's common window: jc_min - R .. jc_min + R + 1
 constexpr int kNarrowTile = 1536;       // ints of LDS for the workgroup's tile (its bins span ~15 x 1 px + the 13 x 13 windows)
 
-__device__ __forceinline__ float upper_tail(float t) { return 0.5f * erfcf(t * 0.70710678118654752f); }
+// P(Z > t) of the standard normal for t >= 0, taken as 0 beyond 6.5 sigma (4e-11: a 2^24-electron bin would put
+// 7e-4 electrons there); the erfc is skipped when the whole wave is out there, as the outer cells of the window are
+constexpr float kTailCut = 6.5f;
+__device__ __forceinline__ float upper_tail(float t) {
+  if (__all(t > kTailCut)) return 0.f;
+  return (t > kTailCut) ? 0.f : 0.5f * erfcf(t * 0.70710678118654752f);
+}
+
+// Reductions over the 16 lanes of a DPP row (butterfly of row rotations): every lane of the row gets the result.
+// All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ int dpp_row(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+#define WAYNE_ROW16(name, T, cast_in, cast_out, op)                                   \
+  __device__ __forceinline__ T name(T v) {                                            \
+    v = op(v, cast_out(dpp_row<0x128>(cast_in(v))));  /* row_ror:8 */                 \
+    v = op(v, cast_out(dpp_row<0x124>(cast_in(v))));  /* row_ror:4 */                 \
+    v = op(v, cast_out(dpp_row<0x122>(cast_in(v))));  /* row_ror:2 */                 \
+    v = op(v, cast_out(dpp_row<0x121>(cast_in(v))));  /* row_ror:1 */                 \
+    return v;                                                                         \
+  }
+__device__ __forceinline__ int wayne_addi(int a, int b) { return a + b; }
+WAYNE_ROW16(row16_min, float, __float_as_int, __int_as_float, fminf)
+WAYNE_ROW16(row16_max, float, __float_as_int, __int_as_float, fmaxf)
+WAYNE_ROW16(row16_mini, int, , , min)
+WAYNE_ROW16(row16_maxi, int, , , max)
+WAYNE_ROW16(row16_sum, int, , , wayne_addi)
+#undef WAYNE_ROW16
+// ... and over the whole wave (wave-uniform result)
+__device__ __forceinline__ int wave_mini(int v) {
+  v = row16_mini(v);
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_maxi(int v) {
+  v = row16_maxi(v);
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 
 template <int FLUSH, bool FAST>
 __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   __shared__ int tile[kNarrowTile];
-  __shared__ float s_q[kNarrowCells][kNarrowThreads];   // CONDITIONAL row probabilities of each lane's bin (see below)
+  // per lane: the running sums of a pooling bin's residual row masses q_b(t) - qbar(t), t = 0..13; any other bin's CONDITIONAL row
+  // probabilities in visiting order (see below)
+  __shared__ float s_q[kPoolRows][kNarrowThreads];
+  __shared__ int s_pool[kNarrowThreads];                // [group][column of the group's window]: pooled column counts
+  __shared__ float s_cond[kNarrowThreads];              // [group][i]: conditional probability of the i-th row visited by a pooled chain
   __shared__ int s_box[4];
   __shared__ float s_fc[10];                            // stirling_tail(0..9), indexed per lane in the rejection sampler
   if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
@@ -42,22 +103,29 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const SubInfo si = a.sub[k];
   const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // narrow electrons of the bin's multinomial
   if (!__syncthreads_or(n0 > 0)) return;
+  const bool act = n0 > 0;
 
   float x = 0.f, y = 0.f, sg = 1.f;
   int ic0 = 0, jc0 = 0;
-  if (n0 > 0) {
+  if (act) {
     x = (float)a.xpos[(size_t)k * a.W + w];
     y = (float)a.ypos[(size_t)k * a.W + w];
     sg = (float)a.sigl[w];
     ic0 = (int)floorf(x);
     jc0 = (int)floorf(y);
   }
+  s_pool[tid] = 0;
   // workgroup tile = bounding box of its bins' windows, clipped to [1, N)
   if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
   __syncthreads();
-  if (n0 > 0) {
-    atomicMin(&s_box[0], ic0 - kNarrowR); atomicMax(&s_box[1], ic0 + kNarrowR + 1);
-    atomicMin(&s_box[2], jc0 - kNarrowR); atomicMax(&s_box[3], jc0 + kNarrowR + 1);
+  {
+    // (reduced over the wave first: 512 lanes hammering four LDS words with atomics serialise for microseconds)
+    const int x_lo = wave_mini(act ? ic0 - kNarrowR : 0x7FFFFFFF), x_hi = wave_maxi(act ? ic0 + kNarrowR + 1 : -0x7FFFFFFF);
+    const int y_lo = wave_mini(act ? jc0 - kNarrowR : 0x7FFFFFFF), y_hi = wave_maxi(act ? jc0 + kNarrowR + 1 : -0x7FFFFFFF);
+    if ((tid & 63) == 0) {
+      atomicMin(&s_box[0], x_lo); atomicMax(&s_box[1], x_hi);
+      atomicMin(&s_box[2], y_lo); atomicMax(&s_box[3], y_hi);
+    }
   }
   __syncthreads();
   int tx0 = max(s_box[0], 1), tx1 = min(s_box[1], a.N), ty0 = max(s_box[2], 1), ty1 = min(s_box[3], a.N);
@@ -66,16 +134,56 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const int tarea = tw * th;
   for (int i = tid; i < tarea; i += kNarrowThreads) tile[i] = 0;
 
+  auto deposit = [&](int ci, int rj, int m) {
+    const int lx = ci - tx0, ly = rj - ty0;
+    if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+      atomicAdd(&tile[ly * tw + lx], m);
+    else if (ci > 0 && ci < a.N && rj > 0 && rj < a.N)       // (:93)
+      deposit_global<FLUSH>(a, si, ci, rj, m);
+  };
+
   // (waves without a multinomial bin skip the work altogether)
-  const bool any_multi = __any(n0 > 0);
+  const bool any_multi = __any(act);
   const float inv_s = 1.f / sg;
+  const int grp = tid & ~15, gl = tid & 15;
+  bool pool = false;
+  int X0 = 0, J0 = 0, res = 0;
+  float Z = 1.f, Rb = 0.f;
   if (any_multi) {
-    // rows, centre-out (c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)): what the chain needs of row c is the
-    // probability of landing in it GIVEN that none of the rows before it was hit, mass_c / (mass not yet visited) --
-    // the same for every column of the bin (x and y are independent), so it is computed once, here, with the
-    // not-yet-visited mass taken as the sum of the two remaining tails (a running 1 - sum would lose the far rows
-    // to cancellation)
-    {
+    // does the lane's group pool its rows?  (so_group_pools)
+    const bool sane = act && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+    const int cnt = row16_sum(act ? 1 : 0), cnt_sane = row16_sum(sane ? 1 : 0), tot = row16_sum(act ? n0 : 0);
+    const int icmin = row16_mini(sane ? ic0 : 0x7FFFFFFF), icmax = row16_maxi(sane ? ic0 : -0x7FFFFFFF);
+    const int jcmin = row16_mini(sane ? jc0 : 0x7FFFFFFF);
+    const float ymin = row16_min(sane ? y : 3e38f), ymax = row16_max(sane ? y : -3e38f);
+    const float smin = row16_min(act ? sg : 3e38f), smax = row16_max(act ? sg : 0.f);
+    pool = cnt >= 2 && cnt_sane == cnt && icmax - icmin <= 2 && (ymax - ymin) <= 0.25f * smin && smax <= 1.1f * smin &&
+           tot <= 16777216;
+    X0 = icmin - kNarrowR;
+    J0 = jcmin - kNarrowR;
+
+    float qh[kPoolRows];
+#pragma unroll
+    for (int t = 0; t < kPoolRows; ++t) qh[t] = 3e38f;
+    if (act && pool) {
+      // the bin's masses on the rows [J0 + t, J0 + t + 1): differences of two tails on the same side of y
+      float Ep = (float)J0 - y, Ap = upper_tail(fabsf(Ep) * inv_s), S = 0.f;
+#pragma unroll
+      for (int t = 0; t < kPoolRows; ++t) {
+        const float E = (float)(J0 + t + 1) - y, A = upper_tail(fabsf(E) * inv_s);
+        const float m = (Ep >= 0.f) ? Ap - A : ((E <= 0.f) ? A - Ap : 1.f - Ap - A);
+        qh[t] = fmaxf(m, 0.f);
+        S += qh[t];
+        Ep = E; Ap = A;
+      }
+#pragma unroll
+      for (int t = 0; t < kPoolRows; ++t) qh[t] = M::div_(qh[t], S);
+    } else if (act) {
+      // rows, centre-out (c = 0 centre, odd c -> +((c+1)/2), even c -> -(c/2)): what the chain needs of row c is the
+      // probability of landing in it GIVEN that none of the rows before it was hit, mass_c / (mass not yet visited) --
+      // the same for every column of the bin (x and y are independent), so it is computed once, here, with the
+      // not-yet-visited mass taken as the sum of the two remaining tails (a running 1 - sum would lose the far rows
+      // to cancellation)
       const float f = y - (float)jc0;
       float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
       s_q[0][tid] = 1.f - up - lo;
@@ -88,6 +196,39 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
         s_q[c][tid] = fminf(fmaxf(M::div_(Q, rem), 0.f), 1.f);
       }
     }
+    if (__any(pool)) {
+      // what the group's bins share: qbar(t) = min over the bins; its tails about the centre row, summed inwards
+      float qb[kPoolRows];
+#pragma unroll
+      for (int t = 0; t < kPoolRows; ++t) qb[t] = row16_min(qh[t]);
+      float PL[kNarrowR + 1], SU[kPoolRows + 1];
+      PL[0] = qb[0];
+#pragma unroll
+      for (int t = 1; t <= kNarrowR; ++t) PL[t] = PL[t - 1] + qb[t];
+      SU[kPoolRows] = 0.f;
+#pragma unroll
+      for (int t = kPoolRows - 1; t > kNarrowR; --t) SU[t] = SU[t + 1] + qb[t];
+      Z = fminf(PL[kNarrowR] + SU[kNarrowR + 1], 1.f);
+      if (act && pool) {
+#pragma unroll
+        for (int t = 0; t < kPoolRows; ++t) {
+          Rb += qh[t] - qb[t];
+          s_q[t][tid] = Rb;                     // running sum: the residual rows' inverse CDF is a count of thresholds
+        }
+      }
+      if (pool && gl == 0) {
+        // rows in visiting order: centre (6), then 7, 5, 8, 4, ...: mass over the two tails not yet visited
+        s_cond[grp] = fminf(fmaxf(M::div_(qb[kNarrowR], PL[kNarrowR] + SU[kNarrowR + 1]), 0.f), 1.f);
+#pragma unroll
+        for (int i = 1; i < kPoolRows; ++i) {
+          const int u = (i + 1) >> 1;
+          float rem, q;
+          if (i & 1) { q = qb[kNarrowR + u]; rem = SU[kNarrowR + u] + (u <= kNarrowR ? PL[u <= kNarrowR ? kNarrowR - u : 0] : 0.f); }
+          else       { q = qb[kNarrowR - u]; rem = SU[kNarrowR + 1 + u] + PL[kNarrowR - u]; }
+          s_cond[grp + i] = fminf(fmaxf(M::div_(q, rem), 0.f), 1.f);
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -96,20 +237,27 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
     const float fx = x - (float)ic0;
     float up = upper_tail((1.f - fx) * inv_s), lo = upper_tail(fx * inv_s);
     float n_rem = (float)max(n0, 0);
-    for (int c = 0; c < kNarrowCells; ++c) {
+    // c = -1: a pooling bin thins its electrons (common ~ Binomial(n, Z)); c >= 0: the column chain
+    for (int c = __any(pool) ? -1 : 0; c < kNarrowCells; ++c) {
       if (!__any(n_rem > 0.f)) break;
       // this column's mass and the mass of everything not yet visited (before it)
       const int d = (c + 1) >> 1;
-      const int ci = (c == 0) ? ic0 : ((c & 1) ? ic0 + d : ic0 - d);
+      const int ci = (c <= 0) ? ic0 : ((c & 1) ? ic0 + d : ic0 - d);
       float P, rem;
-      if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
+      if (c < 0) { P = Z; rem = 1.f; }
+      else if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
       else if (c & 1) { const float nx = upper_tail(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
       else            { const float nx = upper_tail(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
       float n_col = 0.f;
-      if (n_rem > 0.f) {
-        const float pc = fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
+      if (n_rem > 0.f && (c >= 0 || pool)) {
+        const float pc = (c < 0) ? P : fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
         n_col = binomial<M>(n_rem, pc, rng, s_fc);
-        n_rem -= n_col;
+        if (c < 0) { res = (int)(n_rem - n_col); n_rem = n_col; n_col = 0.f; }
+        else n_rem -= n_col;
+      }
+      if (pool) {
+        if (n_col > 0.f) atomicAdd(&s_pool[grp + (ci - X0)], (int)n_col);
+        n_col = 0.f;
       }
       if (!__any(n_col > 0.f)) continue;
       // rows of this column
@@ -123,12 +271,47 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
         }
         if (m > 0.f) {
           const int e = (r + 1) >> 1;
-          const int rj = (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e);
-          const int lx = ci - tx0, ly = rj - ty0;
-          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-            atomicAdd(&tile[ly * tw + lx], (int)m);
-          else if (ci > 0 && ci < a.N && rj > 0 && rj < a.N)       // (:93)
-            deposit_global<FLUSH>(a, si, ci, rj, (int)m);
+          deposit(ci, (r == 0) ? jc0 : ((r & 1) ? jc0 + e : jc0 - e), (int)m);
+        }
+      }
+    }
+    // the residual electrons of the pooling bins, one by one: two pairs each
+    if (__any(res > 0)) {
+      const float cs = (-1.3862943611198906f * sg) * sg;
+      for (int e = 0; __any(e < res); ++e) {
+        if (e < res) {
+          uint32_t wa, wb, va, vb;
+          rng.next2(wa, wb);
+          rng.next2(va, vb);
+          const float Rs = __builtin_amdgcn_sqrtf(cs * __builtin_amdgcn_logf(u01f(wb)));
+          const int col = min(max((int)floorf(fmaf(__builtin_amdgcn_cosf(rev12(wa)), Rs, x)), ic0 - kNarrowR), ic0 + kNarrowR);
+          const float u = u01f(va) * Rb;
+          int row = 0;
+#pragma unroll
+          for (int t = 0; t < kPoolRows - 1; ++t) row += (u >= s_q[t][tid]) ? 1 : 0;
+          deposit(col, J0 + row, 1);
+        }
+      }
+    }
+    // the pooled columns' rows: lane j of a group takes column X0 + j
+    if (__any(pool)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float left = pool ? (float)s_pool[tid] : 0.f;
+      if (__any(left > 0.f)) {
+        SeededStream rp(a.seed, STAGE_POOL, (uint32_t)w >> 4, (uint32_t)k + a.subsample0, a.exposure, (uint32_t)gl);
+        for (int i = 0; i < kPoolRows; ++i) {
+          if (!__any(left > 0.f)) break;
+          float m = 0.f;
+          if (left > 0.f) {
+            m = binomial<M>(left, s_cond[grp + i], rp, s_fc);
+            left -= m;
+          }
+          if (m > 0.f) {
+            const int u = (i + 1) >> 1;
+            deposit(X0 + gl, J0 + ((i & 1) ? kNarrowR + u : kNarrowR - u), (int)m);
+          }
         }
       }
     }
@@ -187,10 +370,15 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   // workgroup tile: bounding box of its bins' positions +- margin, clipped to [1, N) and to the LDS budget
   if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
   __syncthreads();
-  if (n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f) {
+  {
+    const bool in = n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
     const int ic = (int)floorf(x), jc = (int)floorf(y);
-    atomicMin(&s_box[0], ic - kLaneMargin); atomicMax(&s_box[1], ic + kLaneMargin + 1);
-    atomicMin(&s_box[2], jc - kLaneMargin); atomicMax(&s_box[3], jc + kLaneMargin + 1);
+    const int x_lo = wave_mini(in ? ic - kLaneMargin : 0x7FFFFFFF), x_hi = wave_maxi(in ? ic + kLaneMargin + 1 : -0x7FFFFFFF);
+    const int y_lo = wave_mini(in ? jc - kLaneMargin : 0x7FFFFFFF), y_hi = wave_maxi(in ? jc + kLaneMargin + 1 : -0x7FFFFFFF);
+    if ((tid & 63) == 0) {                     // (one atomic per wave: see k_narrow)
+      atomicMin(&s_box[0], x_lo); atomicMax(&s_box[1], x_hi);
+      atomicMin(&s_box[2], y_lo); atomicMax(&s_box[3], y_hi);
+    }
   }
   __syncthreads();
   int tx0 = max(s_box[0], 1), tx1 = min(s_box[1], a.N), ty0 = max(s_box[2], 1), ty1 = min(s_box[3], a.N);

@@ -39,6 +39,8 @@ enum Stage : uint32_t {
   STAGE_LANE = 10,    // seeded stream (bin w, 0, sub-sample k, exposure): pair j -> electron j of the electrons a bin's own
                       //   lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT): the wide-PSF electrons of a bin whose
                       //   narrow ones went to the multinomial, or every electron of a thinly populated bin (wide ones first)
+  STAGE_POOL = 11,    // seeded stream (bin group w >> 4, column j of the group's window, sub-sample k, exposure): the row chain
+                      //   of the electrons the 16 bins of a group put into that column (k_narrow, pooled rows)
 };
 constexpr uint32_t kThrowBlock = 128;   // electrons per STAGE_THROW stream
 
