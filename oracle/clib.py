@@ -75,6 +75,8 @@ def lib():
         L.wayne_oracle_psf_split.restype = C.c_int
         L.wayne_oracle_psf_split.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int,
                                              C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
+        L.wayne_oracle_upper_tail.restype = C.c_float
+        L.wayne_oracle_upper_tail.argtypes = [C.c_float]
         L.wayne_oracle_binomial_vec.restype = None
         L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
         L.wayne_oracle_xo_pairs.restype = None
@@ -171,6 +173,11 @@ def binomial_vec(n, p, seed, subsample=0, exposure=0):
     out = np.empty(n.size, dtype=np.float32)
     lib().wayne_oracle_binomial_vec(n, p, n.size, int(seed), int(subsample), int(exposure), out)
     return out
+
+
+def upper_tail(t):
+    """P(Z > t) of the standard normal as the split thrower computes it (float32 Chebyshev fit of erfc)."""
+    return np.array([lib().wayne_oracle_upper_tail(float(v)) for v in np.atleast_1d(t)], dtype=np.float64)
 
 
 def philox4x32(ctr, key):

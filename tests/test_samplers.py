@@ -145,6 +145,18 @@ def test_split_oracle_lone_bin_is_the_multinomial_of_the_narrow_gaussian(sigma, 
         assert np.abs(z[n * pm > 50]).max() < 5
 
 
+def test_upper_tail_fit_against_erfc():
+    # the cell masses of the multinomial are differences of this tail: 2e-7 absolute, 5e-6 relative out to the cut
+    from scipy.special import erfc
+    t = np.linspace(0.0, 6.5, 6501)
+    got = clib.upper_tail(t)
+    ref = 0.5 * erfc(t / np.sqrt(2.0))
+    assert np.abs(got - ref).max() < 2.5e-7
+    assert np.abs(got / ref - 1).max() < 6e-6
+    assert np.all(np.diff(got) <= 0)                   # monotone: no negative cell mass
+    assert np.all(clib.upper_tail([6.5001, 7.0, 30.0]) == 0.0)
+
+
 @pytest.mark.parametrize("dy,dsig", [(0.001, 0.0005), (0.01, 0.004), (0.0, 0.0)])
 def test_split_oracle_pooled_rows_keep_every_pixel_marginal(dy, dsig):
     # 64 neighbouring bins, all narrow: groups of 16 pool their row chains (oracle/split_oracle.c so_narrow_pooled).

@@ -47,12 +47,29 @@ constexpr int kNarrowCells = 2 * kNarrowR + 1;
 constexpr int kPoolRows = 2 * kNarrowR + 2;   // rows of a group's common window: jc_min - R .. jc_min + R + 1
 constexpr int kNarrowTile = 1536;       // ints of LDS for the workgroup's tile (its bins span ~15 x 1 px + the 13 x 13 windows)
 
-// P(Z > t) of the standard normal for t >= 0, taken as 0 beyond 6.5 sigma (4e-11: a 2^24-electron bin would put
-// 7e-4 electrons there); the erfc is skipped when the whole wave is out there, as the outer cells of the window are
+// P(Z > t) of the standard normal for t >= 0 = erfc(t / sqrt 2) / 2, by the Chebyshev fit of Numerical Recipes
+// (erfcc: t' exp(-z^2 + poly(t')), t' = 1 / (1 + z/2); fractional error < 1.2e-7 in exact arithmetic, < 5e-6 here
+// out to 6.5 sigma, absolute error < 2e-7): a third of the instructions of the library erfcf, which is what a bin's
+// ~25 cell edges cost.  Taken as 0 beyond 6.5 sigma (4e-11: a 2^24-electron bin would put 7e-4 electrons there);
+// skipped altogether when the whole wave is out there, as the outer cells of the window are.
 constexpr float kTailCut = 6.5f;
+template <class M>
 __device__ __forceinline__ float upper_tail(float t) {
   if (__all(t > kTailCut)) return 0.f;
-  return (t > kTailCut) ? 0.f : 0.5f * erfcf(t * 0.70710678118654752f);
+  const float z = t * 0.70710678118654752f;
+  const float u = M::div_(1.f, 1.f + 0.5f * z);
+  float p = 0.17087277f;
+  p = fmaf(p, u, -0.82215223f);
+  p = fmaf(p, u, 1.48851587f);
+  p = fmaf(p, u, -1.13520398f);
+  p = fmaf(p, u, 0.27886807f);
+  p = fmaf(p, u, -0.18628806f);
+  p = fmaf(p, u, 0.09678418f);
+  p = fmaf(p, u, 0.37409196f);
+  p = fmaf(p, u, 1.00002368f);
+  p = fmaf(p, u, -1.26551223f);
+  p = fmaf(-z, z, p);
+  return (t > kTailCut) ? 0.f : (0.5f * u) * M::exp_(p);
 }
 
 // Reductions over the 16 lanes of a DPP row (butterfly of row rotations): every lane of the row gets the result.
@@ -167,10 +184,10 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
     for (int t = 0; t < kPoolRows; ++t) qh[t] = 3e38f;
     if (act && pool) {
       // the bin's masses on the rows [J0 + t, J0 + t + 1): differences of two tails on the same side of y
-      float Ep = (float)J0 - y, Ap = upper_tail(fabsf(Ep) * inv_s), S = 0.f;
+      float Ep = (float)J0 - y, Ap = upper_tail<M>(fabsf(Ep) * inv_s), S = 0.f;
 #pragma unroll
       for (int t = 0; t < kPoolRows; ++t) {
-        const float E = (float)(J0 + t + 1) - y, A = upper_tail(fabsf(E) * inv_s);
+        const float E = (float)(J0 + t + 1) - y, A = upper_tail<M>(fabsf(E) * inv_s);
         const float m = (Ep >= 0.f) ? Ap - A : ((E <= 0.f) ? A - Ap : 1.f - Ap - A);
         qh[t] = fmaxf(m, 0.f);
         S += qh[t];
@@ -185,14 +202,14 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       // not-yet-visited mass taken as the sum of the two remaining tails (a running 1 - sum would lose the far rows
       // to cancellation)
       const float f = y - (float)jc0;
-      float up = upper_tail((1.f - f) * inv_s), lo = upper_tail(f * inv_s);   // mass above / below the centre row
+      float up = upper_tail<M>((1.f - f) * inv_s), lo = upper_tail<M>(f * inv_s);   // mass above / below the centre row
       s_q[0][tid] = 1.f - up - lo;
       for (int c = 1; c < kNarrowCells; ++c) {
         const int d = (c + 1) >> 1;
         const float rem = up + lo;
         float Q;
-        if (c & 1) { const float nx = upper_tail(((float)(d + 1) - f) * inv_s); Q = up - nx; up = nx; }
-        else       { const float nx = upper_tail(((float)d + f) * inv_s);       Q = lo - nx; lo = nx; }
+        if (c & 1) { const float nx = upper_tail<M>(((float)(d + 1) - f) * inv_s); Q = up - nx; up = nx; }
+        else       { const float nx = upper_tail<M>(((float)d + f) * inv_s);       Q = lo - nx; lo = nx; }
         s_q[c][tid] = fminf(fmaxf(M::div_(Q, rem), 0.f), 1.f);
       }
     }
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   if (any_multi) {
     SeededStream rng(a.seed, STAGE_NARROW, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
     const float fx = x - (float)ic0;
-    float up = upper_tail((1.f - fx) * inv_s), lo = upper_tail(fx * inv_s);
+    float up = upper_tail<M>((1.f - fx) * inv_s), lo = upper_tail<M>(fx * inv_s);
     float n_rem = (float)max(n0, 0);
     // c = -1: a pooling bin thins its electrons (common ~ Binomial(n, Z)); c >= 0: the column chain
     for (int c = __any(pool) ? -1 : 0; c < kNarrowCells; ++c) {
@@ -246,8 +263,8 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       float P, rem;
       if (c < 0) { P = Z; rem = 1.f; }
       else if (c == 0) { P = 1.f - up - lo; rem = 1.f; }
-      else if (c & 1) { const float nx = upper_tail(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
-      else            { const float nx = upper_tail(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
+      else if (c & 1) { const float nx = upper_tail<M>(((float)(d + 1) - fx) * inv_s); P = up - nx; rem = up + lo; up = nx; }
+      else            { const float nx = upper_tail<M>(((float)d + fx) * inv_s);       P = lo - nx; rem = up + lo; lo = nx; }
       float n_col = 0.f;
       if (n_rem > 0.f && (c >= 0 || pool)) {
         const float pc = (c < 0) ? P : fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
