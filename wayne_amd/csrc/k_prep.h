@@ -1,4 +1,4 @@
-// k_prep_wl, k_prep_sub, k_prep_fix: per-wavelength arrays, per-bin positions and counts (A6-A10)
+// k_prep_wl, k_prep_sub, k_prep_fix: per-wavelength arrays, per-bin positions and counts (A6-A10); cosmic-ray hits (A13)
 #pragma once
 #include "common.h"
 
@@ -87,6 +87,7 @@ struct PrepArgs {
   int* status;               // set non-zero on overflow
   uint32_t* chunk_total;     // [K * n_chunks] electrons (for k_throw) per chunk of kPrepThreads bins
   double* chunk_box;         // [K * n_chunks * 4] xmin, xmax, ymin, ymax of the chunk's populated bins
+  int fix_inline;            // split mode without a k_throw launch: chunk 0 writes SubInfo, k_prep_fix is not launched
 };
 
 constexpr int kPrepThreads = 512;
@@ -120,10 +121,82 @@ __device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, do
     o[0] = m_t; o[1] = c_t; o[2] = m_w; o[3] = c_w; o[4] = m_wl; o[5] = c_wl;
 }
 
+// ---------------------------------------------------------------------------
+// cosmic rays : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
+// ---------------------------------------------------------------------------
+// One workgroup per read interval adds the interval's hits to the accumulators (in electrons, before the
+// gain: exposure_generator.py:497-505).  Fifteen small workgroups' worth of work: the first R workgroups of
+// k_prep_sub do it on their way in instead of a launch of its own (which costs more than the work: ~8 us on the
+// exposure's critical path).
+struct CosmicArgs {
+  int R, N, S;
+  uint32_t seed, exposure;
+  double rate;               // hits per second per 1024^2 pixels; < 0: no cosmic rays
+  const double* read_dt;     // [R]
+  long long* acc;            // [R*S*S]
+};
+
+__device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t* s_n) {
+  if (threadIdx.x == 0) {
+    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
+    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
+    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
+    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
+    if (!(n >= 0.)) n = 0.;
+    if (n > 1e7) n = 1e7;
+    *s_n = (uint32_t)n;
+  }
+  __syncthreads();
+  const uint32_t n = *s_n;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
+    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
+    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
+    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
+    const long long q = (long long)energy << kQBits;
+    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
+              (unsigned long long)q);
+  }
+}
+
+// SubInfo of sub-sample k: what the throwers need of it (read interval, replay seed, the trace coefficients of the
+// flat field), the electrons k_throw shares out and the LDS tile rectangle of its workgroups
+__device__ __forceinline__ SubInfo make_sub_info(const PrepArgs& a, int k, double x_ref, double y_ref, const double* tr,
+                                                 uint32_t E, double xmin, double xmax, double ymin, double ymax) {
+  SubInfo si;
+  si.electrons = E;
+  si.read = a.sample_read[k];
+  si.replay_seed = a.replay_seed ? a.replay_seed[k] : 0;
+  si.pad_ = 0;
+  si.x_ref = x_ref; si.y_ref = y_ref;
+  si.a_t_i = 1. / tr[0];            // grism.py:367
+  si.a_w = tr[2]; si.b_w = tr[3];
+  si.inv_norm = 1. / sqrt(si.a_t_i * si.a_t_i + 1.);
+  // LDS tile: bounding box of the populated trace + margin, clipped to the
+  // frame's populated range [1, N) (pixel row / column 0 is never hit,
+  // pyparallel_menu.c:93), shrunk symmetrically if it exceeds the LDS budget
+  // (electrons outside the tile take the global-atomic path: speed only).
+  int tx0 = 0, ty0 = 0, tw = 0, th = 0;
+  if (E > 0 && xmax >= xmin) {
+    int x0 = (int)floor(xmin) - a.margin, x1 = (int)floor(xmax) + a.margin + 1;
+    int y0 = (int)floor(ymin) - a.margin, y1 = (int)floor(ymax) + a.margin + 1;
+    x0 = max(x0, 1); y0 = max(y0, 1); x1 = min(x1, a.N); y1 = min(y1, a.N);
+    if (x1 > x0 && y1 > y0) {
+      tw = x1 - x0; th = y1 - y0;
+      while ((long long)tw * th > a.max_tile && th > 1) { y0 += 1; th -= 2; if (th < 1) th = 1; }
+      while ((long long)tw * th > a.max_tile && tw > 1) { x0 += 1; tw -= 2; if (tw < 1) tw = 1; }
+      tx0 = x0; ty0 = y0;
+    }
+  }
+  si.tx0 = tx0; si.ty0 = ty0; si.tw = tw; si.th = th;
+  return si;
+}
+
 // One workgroup per (sub-sample, chunk of kPrepThreads bins): positions, counts,
-// sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the
-// chunk offsets.  K * ceil(W / 512) workgroups instead of K: the whole chip works.
-__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
+// sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the chunk
+// offsets (when anything is left for k_throw: see the end of the kernel).
+// K * ceil(W / 512) workgroups instead of K: the whole chip works.
+__global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArgs ca) {
   const int k = blockIdx.x;
   const int ch = blockIdx.y;
   const int tid = threadIdx.x;
@@ -133,7 +206,12 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
   __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
   __shared__ uint32_t s_wsum[NW];   // per-wave totals
   __shared__ double s_red[4][NW];
+  __shared__ uint32_t s_hits;
 
+  if (ca.rate >= 0.) {   // cosmic rays: read interval r is the business of workgroup r (mod the grid)
+    const int n_wg = gridDim.x * gridDim.y;
+    for (int r = blockIdx.y * gridDim.x + blockIdx.x; r < ca.R; r += n_wg) { cosmic_hits(ca, r, &s_hits); __syncthreads(); }
+  }
   const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
   if (tid == 0) trace_coeffs(a.g, x_ref, y_ref, s_tr);
   __syncthreads();
@@ -204,106 +282,77 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a) {
       c = lane ? 0u : ind;                                   // c: electrons left for k_throw
     }
   }
-  // exclusive scan of c inside the chunk: shuffle scan per wave, wave totals through LDS
-  uint32_t incl = c;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) s_wsum[wave] = incl;
-  // bounding box of populated bins
-  for (int off = 32; off > 0; off >>= 1) {
-    xmin = fmin(xmin, __shfl_down(xmin, off));
-    xmax = fmax(xmax, __shfl_down(xmax, off));
-    ymin = fmin(ymin, __shfl_down(ymin, off));
-    ymax = fmax(ymax, __shfl_down(ymax, off));
-  }
-  if (lane == 0) {
-    s_red[0][wave] = xmin; s_red[1][wave] = xmax;
-    s_red[2][wave] = ymin; s_red[3][wave] = ymax;
-  }
-  __syncthreads();
-  uint64_t wave_off = 0, chunk_total = 0;
-#pragma unroll
-  for (int i = 0; i < NW; ++i) {
-    const uint32_t t = s_wsum[i];
-    if (i < wave) wave_off += t;
-    chunk_total += t;
-  }
-  if (chunk_total > 0xFFFFFFFFull) overflow = true;
-  if (w < W) a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)(wave_off + incl - c);   // chunk-local for now
   if (overflow) atomicExch(a.status, 1);
-  // electrons handed to k_narrow: one atomic per workgroup (wave shuffle, then LDS)
+  // electrons handed to k_lane / k_narrow: one atomic per workgroup (wave shuffle, then LDS)
   for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
   __shared__ unsigned long long s_split[NW];
   if (lane == 0) s_split[wave] = n_split_total;
+
+  if (!a.fix_inline) {
+    // what k_throw needs: exclusive scan of c inside the chunk (shuffle scan per wave, wave totals through LDS) ...
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    // ... and the bounding box of the populated bins
+    for (int off = 32; off > 0; off >>= 1) {
+      xmin = fmin(xmin, __shfl_down(xmin, off));
+      xmax = fmax(xmax, __shfl_down(xmax, off));
+      ymin = fmin(ymin, __shfl_down(ymin, off));
+      ymax = fmax(ymax, __shfl_down(ymax, off));
+    }
+    if (lane == 0) {
+      s_red[0][wave] = xmin; s_red[1][wave] = xmax;
+      s_red[2][wave] = ymin; s_red[3][wave] = ymax;
+    }
+    __syncthreads();
+    uint64_t wave_off = 0, chunk_total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const uint32_t t = s_wsum[i];
+      if (i < wave) wave_off += t;
+      chunk_total += t;
+    }
+    if (chunk_total > 0xFFFFFFFFull) atomicExch(a.status, 1);
+    if (w < W) a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)(wave_off + incl - c);   // chunk-local for now
+    if (tid == 0) {
+      for (int i = 1; i < NW; ++i) {
+        xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
+        ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
+      }
+      const size_t ci = (size_t)k * gridDim.y + ch;
+      a.chunk_total[ci] = (uint32_t)chunk_total;
+      a.chunk_box[4 * ci + 0] = xmin; a.chunk_box[4 * ci + 1] = xmax;
+      a.chunk_box[4 * ci + 2] = ymin; a.chunk_box[4 * ci + 3] = ymax;
+    }
+  }
   __syncthreads();
   if (tid == 0) {
     unsigned long long tot = 0;
     for (int i = 0; i < NW; ++i) tot += s_split[i];
     if (tot) atomicAdd(a.total_electrons, tot);
-    for (int i = 1; i < NW; ++i) {
-      xmin = fmin(xmin, s_red[0][i]); xmax = fmax(xmax, s_red[1][i]);
-      ymin = fmin(ymin, s_red[2][i]); ymax = fmax(ymax, s_red[3][i]);
-    }
-    const size_t ci = (size_t)k * gridDim.y + ch;
-    a.chunk_total[ci] = (uint32_t)chunk_total;
-    a.chunk_box[4 * ci + 0] = xmin; a.chunk_box[4 * ci + 1] = xmax;
-    a.chunk_box[4 * ci + 2] = ymin; a.chunk_box[4 * ci + 3] = ymax;
   }
+
+  // Split mode with no k_throw launch (the default: every bin's one-by-one electrons fit its lane): nothing of the
+  // sub-sample's SubInfo depends on the other workgroups -- no electrons for k_throw, no tile -- so chunk 0 writes it
+  // here and k_prep_fix is not launched (~12 us of the exposure's critical path for ~1 us of work).  (A ticket
+  // counter electing the last workgroup would serve every mode, but what the others wrote is only visible across
+  // XCDs after an L2 write-back per workgroup: measured 0.17 ms per launch.)
+  if (a.fix_inline && ch == 0 && tid == 0) a.sub[k] = make_sub_info(a, k, x_ref, y_ref, s_tr, 0u, 1e300, -1e300, 1e300, -1e300);
 }
 
-// ---------------------------------------------------------------------------
-// cosmic rays : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)
-// ---------------------------------------------------------------------------
-// One workgroup per read interval adds the interval's hits to the accumulators (in electrons, before the
-// gain: exposure_generator.py:497-505).  Fifteen small workgroups: they ride in k_prep_fix's launch instead of
-// one of their own (a launch of its own costs more than the work: ~8 us on the exposure's critical path).
-struct CosmicArgs {
-  int R, N, S;
-  uint32_t seed, exposure;
-  double rate;               // hits per second per 1024^2 pixels; < 0: no cosmic rays
-  const double* read_dt;     // [R]
-  long long* acc;            // [R*S*S]
-};
-
-__device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t* s_n) {
-  if (threadIdx.x == 0) {
-    // rate_size = rate / (1024*1024) * N*N ; Poisson(rate_size * time)  (:33-44, :121-127)
-    const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);
-    PhiloxStream rng(a.seed, STAGE_CR_COUNT, 0u, (uint32_t)r, a.exposure);
-    double n = poisson<ExactMath<double> >(rate_size * a.read_dt[r], rng);
-    if (!(n >= 0.)) n = 0.;
-    if (n > 1e7) n = 1e7;
-    *s_n = (uint32_t)n;
-  }
-  __syncthreads();
-  const uint32_t n = *s_n;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const u32x4 w = philox4x32_10(i, 0u, (uint32_t)r, a.exposure, a.seed, STAGE_CR_HIT);
-    const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);  // randint(10000, 35000)  (:134)
-    const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
-    const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
-    const long long q = (long long)energy << kQBits;
-    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
-              (unsigned long long)q);
-  }
-}
-
-// One workgroup per sub-sample: chunk offsets -> global exclusive prefix, E_k,
+// One workgroup per sub-sample (modes that launch k_throw): chunk offsets -> global exclusive prefix, E_k,
 // bounding box -> LDS tile rectangle, SubInfo.
-// (launched with max(K, R) workgroups: workgroup r < R also adds the cosmic-ray hits of read interval r)
-__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks, CosmicArgs ca) {
+__global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chunks) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int W = a.W;
   __shared__ uint32_t s_off[kMaxPrepChunks];
   __shared__ uint32_t s_E;
   __shared__ int s_over;
-  __shared__ uint32_t s_hits;
-  if (k < ca.R && ca.rate >= 0.) cosmic_hits(ca, k, &s_hits);
-  if (k >= a.K) return;
   if (tid == 0) {
     uint64_t run = 0;
     int over = 0;
@@ -330,33 +379,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
     trace_coeffs(a.g, x_ref, y_ref, tr);
     const uint32_t E = s_E;
     a.prefix[(size_t)k * (W + 1) + W] = E;
-    SubInfo si;
-    si.electrons = E;
-    si.read = a.sample_read[k];
-    si.replay_seed = a.replay_seed ? a.replay_seed[k] : 0;
-    si.pad_ = 0;
-    si.x_ref = x_ref; si.y_ref = y_ref;
-    si.a_t_i = 1. / tr[0];            // grism.py:367
-    si.a_w = tr[2]; si.b_w = tr[3];
-    si.inv_norm = 1. / sqrt(si.a_t_i * si.a_t_i + 1.);
-    // LDS tile: bounding box of the populated trace + margin, clipped to the
-    // frame's populated range [1, N) (pixel row / column 0 is never hit,
-    // pyparallel_menu.c:93), shrunk symmetrically if it exceeds the LDS budget
-    // (electrons outside the tile take the global-atomic path: speed only).
-    int tx0 = 0, ty0 = 0, tw = 0, th = 0;
-    if (E > 0 && xmax >= xmin) {
-      int x0 = (int)floor(xmin) - a.margin, x1 = (int)floor(xmax) + a.margin + 1;
-      int y0 = (int)floor(ymin) - a.margin, y1 = (int)floor(ymax) + a.margin + 1;
-      x0 = max(x0, 1); y0 = max(y0, 1); x1 = min(x1, a.N); y1 = min(y1, a.N);
-      if (x1 > x0 && y1 > y0) {
-        tw = x1 - x0; th = y1 - y0;
-        while ((long long)tw * th > a.max_tile && th > 1) { y0 += 1; th -= 2; if (th < 1) th = 1; }
-        while ((long long)tw * th > a.max_tile && tw > 1) { x0 += 1; tw -= 2; if (tw < 1) tw = 1; }
-        tx0 = x0; ty0 = y0;
-      }
-    }
-    si.tx0 = tx0; si.ty0 = ty0; si.tw = tw; si.th = th;
-    a.sub[k] = si;
+    a.sub[k] = make_sub_info(a, k, x_ref, y_ref, tr, E, xmin, xmax, ymin, ymax);
     atomicAdd(a.total_electrons, (unsigned long long)E);
   }
 }

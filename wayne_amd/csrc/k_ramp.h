@@ -1,4 +1,4 @@
-// k_ramp: per-read and post-ramp stages (A13-A15); the cosmic-ray hits of A13 are added by k_prep_fix (k_prep.h)
+// k_ramp: per-read and post-ramp stages (A13-A15); the cosmic-ray hits of A13 are added by k_prep_sub (k_prep.h)
 #pragma once
 #include "common.h"
 

@@ -3,9 +3,8 @@
 //   k_lightcurve.h  k_lightcurve   transit depths depth[K][W] from z[K], rp[W], limb darkening
 //   k_prep.h        k_prep_wl      per-wavelength arrays: PSF polynomials, sensitivity LUT, bin widths   (A8, A9)
 //                   k_prep_sub     per sub-sample: trace, bin positions, expected counts, Poisson/round,
-//                                  sigma split, routing of the bins, chunk-local prefix                  (A6, A7, A9, A10)
-//                   k_prep_fix     global prefix, electron count and clip rectangle per sub-sample; cosmic-ray hits
-//                                  per read interval                                                      (A13, cosmic_rays.py)
+//                                  sigma split, routing of the bins, prefix, electron count and clip rectangle
+//                                  per sub-sample; cosmic-ray hits per read interval          (A6, A7, A9, A10, A13, cosmic_rays.py)
 //   k_throw.h       k_throw        the electron thrower: LDS int32 tile per workgroup slice,
 //                                  flushed x flat into the read-interval accumulator                     (A1-A4, A11, A12)
 //   k_narrow.h      k_narrow       narrow PSF component as one multinomial per bin

@@ -22,7 +22,7 @@ using namespace wayne;
 namespace {
 
 enum ProfKernel { PK_PREP_WL = 0, PK_PREP_SUB, PK_THROW, PK_COSMIC, PK_RAMP, PK_LIGHTCURVE, PK_NARROW, PK_LANE };
-const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub",   "k_throw",  "k_cosmic",   /* (cosmic rays ride in k_prep_fix: slot kept for the ABI) */
+const char* const kProfNames[WAYNE_PROF_KERNELS] = {"k_prep_wl", "k_prep_sub",   "k_throw",  "k_cosmic",   /* (cosmic rays ride in k_prep_sub: slot kept for the ABI) */
                                                     "k_ramp",    "k_lightcurve", "k_narrow", "k_lane"};
 
 struct DevBuf {
@@ -1056,15 +1056,18 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     const int n_chunks = (W + kPrepThreads - 1) / kPrepThreads;
     a.chunk_total = s.chunk_total.as<uint32_t>();
     a.chunk_box = s.chunk_box.as<double>();
-    ProfScope ps(c, PK_PREP_SUB);
-    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a);
-    HIP_TRY(c, hipGetLastError());
+    a.fix_inline = lane_unlimited ? 1 : 0;
     CosmicArgs ca{};
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
     ca.rate = (d.cosmic_rate >= 0.) ? d.cosmic_rate : -1.;
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
-    hipLaunchKernelGGL(k_prep_fix, dim3(std::max(K, R)), dim3(kPrepThreads), 0, c->stream, a, n_chunks, ca);
+    ProfScope ps(c, PK_PREP_SUB);
+    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
     HIP_TRY(c, hipGetLastError());
+    if (!a.fix_inline) {
+      hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
+      HIP_TRY(c, hipGetLastError());
+    }
   }
   {
     ThrowArgs a{};
