@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16
 REPS = 5
+RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th exposure (they cost the stream ~10 us a pair)
 
 
 def ramp_bytes(N, S, R, out_bytes):
@@ -272,14 +273,17 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed(slot_of, steps, warmup):
+    def timed(slot_of, steps, warmup, events_every=0):
         """Exactly `steps` exposures after `warmup` untimed ones, bracketed by barrier + synchronise;
-        returns the elapsed seconds (max over ranks)."""
+        returns the elapsed seconds (max over ranks).  events_every = n: the selected kernels' HIP events are
+        recorded on every n-th exposure only (an event pair costs the stream ~5 us either side of the kernel)."""
         for j in range(warmup):
             ctx.run(slot_of(j))
         sync_all()
         t0 = time.perf_counter()
         for j in range(warmup, warmup + steps):
+            if events_every:
+                ctx.profile_enable((j - warmup) % events_every == 0)
             ctx.run(slot_of(j))
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -306,7 +310,8 @@ def main():
     ctx.profile_select(["k_ramp"])
     ctx.profile_enable(True)
     ctx.profile_reset()
-    reps = [timed(slot_of, args.steps, 0) for _ in range(REPS)]
+    reps = [timed(slot_of, args.steps, 0, events_every=RAMP_EVENTS_EVERY) for _ in range(REPS)]
+    ctx.profile_enable(True)
     prof_ramp = ctx.profile_get()
     elapsed = float(np.median(reps))
 
@@ -443,6 +448,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_ramp", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": rb, "ms_per_launch": ramp_ms,
+                         "launches_timed": prof_ramp["k_ramp"]["launches"],
+                         "timing": "HIP events on the kernel's own stream, every %d-th launch of the timed region" % RAMP_EVENTS_EVERY,
                          "survey_formula_bytes_per_exposure": sb,
                          "achieved_survey_formula": sb / (ramp_ms * 1e-3) / 1e9},
             "kernels_ms_per_exposure": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items() if k != "electrons"},

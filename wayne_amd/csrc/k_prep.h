@@ -159,6 +159,74 @@ __device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t
   }
 }
 
+// ---------------------------------------------------------------------------
+// The stellar Poisson draw of a bin: PTRS in fp64, same trials and same outcomes as
+// poisson<ExactMath<double>> (samplers.h; the oracle's sampler), with a SQUEEZE in front
+// of the log-density comparison.  A quarter of the trials reach that comparison
+// (three fp64 logarithms and ln Gamma: ~400 fp64 instructions, and some lane of a
+// wave always does).  Its two sides are first evaluated in fp32, the right-hand side
+// in a form without cancellation,
+//     -lam + k ln lam - ln k!  =  -d^2/lam - k g(d/lam) - ln(2 pi k)/2 - 1/(12k) + 1/(360k^3),
+//     d = k - lam (exact in fp64),  g(x) = ln(1+x) - x  (series, |x| <= 1/4),
+// good to 1.4e-6 (1 + d^2/lam) against the fp64 value (measured over 1e6 undecided
+// trials, lam = 10 .. 4e6; scripts/check_ptrs_squeeze.py).  Only when the two sides
+// are closer than 2e-4 (1 + d^2/lam) -- a margin of 140 -- does the fp64 comparison
+// run: one trial in a few thousand.  The decision is the fp64 one either way.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// > 0: accept, < 0: reject, 0: too close to call in fp32
+__device__ __forceinline__ int ptrs_squeeze(double lam, double k, double lhs_arg) {
+  const double d = k - lam;
+  if (!(k >= 10. && lam <= 4194304. && fabs(d) <= 0.25 * lam)) return 0;
+  const float df = (float)d, kf = (float)k;
+  const float rl = __builtin_amdgcn_rcpf((float)lam), rk = __builtin_amdgcn_rcpf(kf);
+  const float x = df * rl;
+  // (ln(1+x) - x) / x^2 = -1/2 + x/3 - x^2/4 + ... - x^12/14 + x^13/15
+  float p = 1.f / 15.f;
+  p = fmaf(p, x, -1.f / 14.f); p = fmaf(p, x, 1.f / 13.f); p = fmaf(p, x, -1.f / 12.f);
+  p = fmaf(p, x, 1.f / 11.f);  p = fmaf(p, x, -1.f / 10.f); p = fmaf(p, x, 1.f / 9.f);
+  p = fmaf(p, x, -1.f / 8.f);  p = fmaf(p, x, 1.f / 7.f);   p = fmaf(p, x, -1.f / 6.f);
+  p = fmaf(p, x, 1.f / 5.f);   p = fmaf(p, x, -1.f / 4.f);  p = fmaf(p, x, 1.f / 3.f);
+  p = fmaf(p, x, -0.5f);
+  const float scale = fmaf(df * df, rl, 1.f);                  // 1 + d^2 / lam
+  const float ln2 = 0.6931471805599453f;
+  const float rhs = -(df * df) * rl - kf * (p * x * x) - 0.5f * ln2 * __builtin_amdgcn_logf(6.283185307179586f * kf) -
+                    rk * (1.f / 12.f - rk * rk * (1.f / 360.f));
+  const float D = ln2 * __builtin_amdgcn_logf((float)lhs_arg) - rhs;   // accept <=> D <= 0
+  const float eps = 2e-4f * scale;
+  return (D <= -eps) ? 1 : ((D >= eps) ? -1 : 0);
+}
+
+template <class RNG>
+__device__ double poisson_counts(double lam, RNG& rng) {
+  typedef ExactMath<double> M;
+  if (!(lam >= 10.)) return poisson<M>(lam, rng);              // (also lam <= 0 and NaN)
+  // PtrsSetup<M>::init without ln(lam), which only the fp64 comparison needs
+  const double slam = sqrt(lam);
+  const double b = 0.931 + 2.53 * slam;
+  const double a = -0.059 + 0.02483 * b;
+  const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+  const double vr = 0.9277 - 3.6224 / (b - 2.);
+  for (int it = 0; it < 256; ++it) {
+    uint32_t w1, w2;
+    rng.next2(w1, w2);
+    const double U = M::u01(w1) - 0.5;
+    const double V = M::u01(w2);
+    const double us = 0.5 - fabs(U);
+    const double k = floor((2. * a / us + b) * U + lam + 0.43);
+    if (us >= 0.07 && V <= vr) return k;
+    if (k < 0. || (us < 0.013 && V > us)) continue;
+    const double den = a / (us * us) + b;
+    int s = ptrs_squeeze(lam, k, V * invalpha / den);
+    if (s == 0) s = M::accept(V, invalpha, den, -lam + k * log(lam) - loggam<M>(k + 1.)) ? 1 : -1;
+    if (s > 0) return k;
+  }
+  return floor(lam + 0.5);
+}
+#else
+template <class RNG> __device__ double poisson_counts(double lam, RNG& rng) { return poisson<ExactMath<double> >(lam, rng); }   // host pass: never executed
+#endif
+
 // SubInfo of sub-sample k: what the throwers need of it (read interval, replay seed, the trace coefficients of the
 // flat field), the electrons k_throw shares out and the LDS tile rectangle of its workgroups
 __device__ __forceinline__ SubInfo make_sub_info(const PrepArgs& a, int k, double x_ref, double y_ref, const double* tr,
@@ -248,7 +316,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     double cnt;
     if (noisy) {
       PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
-      cnt = poisson<ExactMath<double> >(lam, rng);   // np.random.poisson (:626)
+      cnt = poisson_counts(lam, rng);       // np.random.poisson (:626)
     } else {
       cnt = rint(lam);                      // np.round, half to even (:628)
     }
