@@ -60,6 +60,23 @@ def test_prep_counts_with_stellar_poisson(name):
     assert abs(a.mean() - lam_mean) < 1e-3 * lam_mean
 
 
+def test_prep_counts_with_stellar_poisson_over_six_decades():
+    # the device decides most PTRS trials by an fp32 squeeze (k_prep.h ptrs_squeeze) and must still land on the
+    # fp64 sampler's draw: expected counts from ~1 to ~3e6 per bin in one exposure
+    v, _, _, rec0, _ = run_both("tiny", **dict(DET_OFF, add_flat=False))
+    base = np.maximum(rec0["counts"][min(1, len(rec0["counts"]) - 1)].astype(float), 1e-3)   # expected counts as they are
+    W = base.size
+    target = 10.0 ** np.random.default_rng(4).uniform(0.0, 3.5, W)
+    bright = np.linspace(0, W - 1, 40).astype(int)          # (kept few: the oracle throws every electron)
+    target[bright] = 10.0 ** np.linspace(4.0, 6.5, 40)
+    flux = v.stellar_flux * np.where(base > 0.5, target / base, 0.0)
+    v, got, want, rec, orec = run_both("tiny", **dict(DET_OFF, add_stellar_noise=True, add_flat=False, stellar_flux=flux))
+    a, b = rec["counts"], np.stack(orec["counts"])
+    for lo, hi in ((0, 10), (10, 100), (100, 1e3), (1e3, 1e4), (1e4, 1e5), (1e5, 1e6), (1e6, 1e7)):
+        assert ((b >= lo) & (b < hi)).sum() >= 5, (lo, hi)
+    assert (a != b).mean() < 1e-5
+
+
 @pytest.mark.parametrize("name,flat", [("tiny", True), ("tiny", False), ("small256", True)])
 def test_accumulated_electrons_replay_thrower_and_flat(name, flat):
     v, got, want, rec, orec = run_both(name, **dict(DET_OFF, add_flat=flat))

@@ -103,6 +103,48 @@ def test_split_mode_against_oracle_same_counters(gpu_ctx, name, scale):
         assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
 
 
+def test_pooled_row_groups_against_oracle_same_counters(gpu_ctx):
+    # k_narrow pools the row chains of the 16 bins of a group when they sit close enough; every case the rule
+    # distinguishes, side by side in one launch (so that pooling and non-pooling groups share waves):
+    #   groups 0-3 ordinary spectrum; 4 identical bins (no residual); 5 y spread just under / 6 just over the limit;
+    #   7 sigma spread over the limit; 8 x spread over three columns; 9 a single multinomial bin; 10 thin bins mixed in;
+    #   11 window clipped by the frame's lower-left corner; 12 by its upper edge; 13 sigma at both ends of the range;
+    #   14 a bin beyond 2^24 in a group (the group's total disqualifies pooling); 15 far-off positions
+    from oracle import clib
+    rng = np.random.default_rng(17)
+    G, N = 16, 192
+    W = 16 * G + 5                                            # (a ragged last group)
+    g = np.arange(W) // G
+    j = np.arange(W) % G
+    counts = rng.integers(900, 2600, W).astype(np.int64)
+    x = 30.3 + 0.04 * np.arange(W)
+    y = 90.7 + 0.0007 * np.arange(W)
+    sl = 0.66 + 0.0002 * np.arange(W)
+    sh = np.full(W, 4.0)
+    ratio = np.full(W, 0.2)
+    m = g == 4; x[m], y[m], sl[m] = 70.25, 91.5, 0.7
+    m = g == 5; y[m] = 60.1 + 0.24 * 0.7 * j[m] / 15.0; sl[m] = 0.7
+    m = g == 6; y[m] = 60.1 + 0.27 * 0.7 * j[m] / 15.0; sl[m] = 0.7
+    m = g == 7; sl[m] = 0.6 * (1 + 0.12 * j[m] / 15.0)
+    m = g == 8; x[m] = 100.2 + 0.21 * j[m]
+    m = g == 9; counts[m] = np.where(j[m] == 7, 5000, rng.integers(0, 20, m.sum()))
+    m = g == 10; counts[m] = np.where(j[m] % 3 == 0, rng.integers(0, 30, m.sum()), counts[m])
+    m = g == 11; x[m] = 1.4 + 0.04 * j[m]; y[m] = 2.2 + 0.001 * j[m]
+    m = g == 12; x[m] = 150.0 + 0.04 * j[m]; y[m] = N - 1.6 + 0.001 * j[m]
+    m = g == 13; sl[m] = np.where(j[m] < 8, 0.0505, 0.92)
+    m = g == 14; counts[m] = np.where(j[m] == 3, (1 << 24) + 77, counts[m]); ratio[m] = 0.0
+    m = g == 15; x[m] = np.where(j[m] % 2 == 0, 5e7, x[m]); y[m] = np.where(j[m] % 4 == 1, -3e8, y[m])
+    counts = counts.astype(np.int32)
+    for seed, exp, sub in [(41, 0, 0), (42, 5, 99)]:
+        want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed, exp, sub)
+        got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, seed, rng_mode=_lib.RNG_SPLIT, exposure=exp, subsample=sub)
+        total = int(want.sum())
+        assert total > 0.6 * counts.sum()
+        assert abs(int(got.sum()) - total) <= 2 + total // 100000
+        moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
+        assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
+
+
 def test_thin_bins_against_oracle_same_counters(gpu_ctx):
     # a finely sampled scan: 0-15 electrons per bin -> every bin is thrown whole by its own lane from its own
     # stream (stage LANE); mixed with a few dense bins whose narrow electrons take the multinomial
