@@ -55,11 +55,13 @@ RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th 
 
 def ramp_bytes(N, S, R, out_bytes):
     """Compulsory HBM bytes of ONE k_ramp launch as designed (DESIGN.md "k_ramp"):
-    per interior pixel and read: int64 accumulator read + cleared (8 + 8), dark SCI + ERR
-    (4 + 4), read written (out_bytes); once per pixel: pixel flat 4, sky 4, c1..c4 16,
-    zero read written (out_bytes).  Border pixels only write their reads."""
+    per interior pixel and read: int64 accumulator read (8), dark SCI + ERR (4 + 4), read written
+    (out_bytes); once per pixel: pixel flat 4, sky 4, c1..c4 16, zero read written (out_bytes).
+    Border pixels only write their reads.  The accumulators the thrower touched (~10 % of a frame)
+    are also written back as zeros: exposure dependent, left out here (the conservative choice for
+    `roofline.achieved`; the PMC figure `roofline.traffic` contains them)."""
     inner = N * N
-    per_read_inner = 8 + 8 + 4 + 4
+    per_read_inner = 8 + 4 + 4
     once_inner = 4 + 4 + 16
     return R * (inner * per_read_inner + S * S * out_bytes) + inner * once_inner + S * S * out_bytes
 

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     uint32_t g0 = 0u, g1 = 0u;
     if (do_noise) rg.next2(g0, g1);
     if (interior) {
-      accp[(size_t)r * SS] = 0;      // leave the accumulator clean for the next exposure
+      if (q != 0) accp[(size_t)r * SS] = 0;   // leave the accumulator clean for the next exposure (90 % of a frame never left zero:
+                                              // not re-zeroing those saves a quarter of the kernel's HBM traffic)
       px = (double)q * kInvQ;
       if (do_noise) {                // _gen_noise (:477-484, :712-727)
         const double dt = a.read_dt[r];
