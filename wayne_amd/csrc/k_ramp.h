@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     rn.next2(w0, w1);
     double v = z;
     if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }
-    out[p] = (OutT)v;
+    __builtin_nontemporal_store((OutT)v, &out[p]);
   }
 
   // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
@@ -304,13 +304,14 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
 
   // software-pipelined ramp: the planes of read r+1 are requested before the
-  // (VALU-heavy) work on read r so that HBM latency hides behind it
+  // (VALU-heavy) work on read r so that HBM latency hides behind it.  The dark planes and the reads are
+  // streamed once: non-temporal loads / stores (measured: 0.076 -> 0.070 ms)
   long long* __restrict__ accp = a.acc + p;
   const float* __restrict__ dsp = a.dark_sci ? a.dark_sci + p : nullptr;
   const float* __restrict__ dep = a.dark_err ? a.dark_err + p : nullptr;
   const bool ld_dark = do_dark && interior;
   long long q_next = interior ? accp[0] : 0;
-  float ds_next = ld_dark ? dsp[0] : 0.f, de_next = ld_dark ? dep[0] : 0.f;
+  float ds_next = ld_dark ? __builtin_nontemporal_load(&dsp[0]) : 0.f, de_next = ld_dark ? __builtin_nontemporal_load(&dep[0]) : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
   float sky_c = -1.f, sky_m = 0.f, sky_em = 1.f;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     const float ds = ds_next, de = de_next;
     if (r + 1 < a.R) {
       if (interior) q_next = accp[(size_t)(r + 1) * SS];
-      if (ld_dark) { ds_next = dsp[(size_t)(r + 1) * SS]; de_next = dep[(size_t)(r + 1) * SS]; }
+      if (ld_dark) { ds_next = __builtin_nontemporal_load(&dsp[(size_t)(r + 1) * SS]); de_next = __builtin_nontemporal_load(&dep[(size_t)(r + 1) * SS]); }
     }
     double px = 0.;
     uint32_t g0 = 0u, g1 = 0u;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
     v = v + z;                       // add_zero_read (exposure.py:94-104)
     if (rdn) v = v + kReadNoise * (double)zr;   // add_read_noise (detector.py:193-198)
-    out[(size_t)(r + 1) * SS + p] = (OutT)v;
+    __builtin_nontemporal_store((OutT)v, &out[(size_t)(r + 1) * SS + p]);
   }
 }
 
