@@ -281,6 +281,37 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   if (rdn || do_dark) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
   if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
 
+  // Buffer addressing: descriptor (scalar) + the lane's 32-bit byte offset (vector, loop constant) + the plane's
+  // byte offset (scalar, advances per read) -- no 64-bit vector address arithmetic per access, which the
+  // flat-pointer form spent five v_lshl_add_u64 a read on.  (Planes are < 2^31 bytes: R * S * S * 8 <= 142 MB.)
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const int n_acc = (int)((size_t)a.R * SS * sizeof(long long)), n_f32 = (int)((size_t)a.R * SS * sizeof(float));
+  const int n_out = (int)((size_t)(a.R + 1) * SS * sizeof(OutT));
+  const __amdgpu_buffer_rsrc_t rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)a.acc, 0, n_acc, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ds = __builtin_amdgcn_make_buffer_rsrc((void*)a.dark_sci, 0, a.dark_sci ? n_f32 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_de = __builtin_amdgcn_make_buffer_rsrc((void*)a.dark_err, 0, a.dark_err ? n_f32 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, n_out, 0x00020000);
+  const uint32_t off8 = (uint32_t)p * 8u, off4 = (uint32_t)p * 4u, offo = (uint32_t)p * (uint32_t)sizeof(OutT);
+  const uint32_t acc_plane = (uint32_t)(SS * sizeof(long long)), f32_plane = (uint32_t)(SS * sizeof(float));
+  const uint32_t out_plane = (uint32_t)(SS * sizeof(OutT));
+  constexpr int kNT = 2;                                   // cache policy: non-temporal (streamed once)
+  auto ld_acc = [&](int r) -> long long {
+    const v2u w = __builtin_amdgcn_raw_buffer_load_b64(rs_acc, off8, (uint32_t)r * acc_plane, 0);
+    return (long long)(((unsigned long long)w.y << 32) | w.x);
+  };
+  auto ld_f32 = [&](const __amdgpu_buffer_rsrc_t& rs, int r) -> float {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off4, (uint32_t)r * f32_plane, kNT));
+  };
+  auto st_out = [&](int plane, OutT v) {
+    if (sizeof(OutT) == 4) {
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)v), rs_out, offo, (uint32_t)plane * out_plane, kNT);
+    } else {
+      const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+      const v2u w = {(unsigned)b, (unsigned)(b >> 32)};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rs_out, offo, (uint32_t)plane * out_plane, kNT);
+    }
+  };
+
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
   double z = (a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     rn.next2(w0, w1);
     double v = z;
     if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }
-    __builtin_nontemporal_store((OutT)v, &out[p]);
+    st_out(0, (OutT)v);
   }
 
   // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
@@ -306,12 +337,9 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   // software-pipelined ramp: the planes of read r+1 are requested before the
   // (VALU-heavy) work on read r so that HBM latency hides behind it.  The dark planes and the reads are
   // streamed once: non-temporal loads / stores (measured: 0.076 -> 0.070 ms)
-  long long* __restrict__ accp = a.acc + p;
-  const float* __restrict__ dsp = a.dark_sci ? a.dark_sci + p : nullptr;
-  const float* __restrict__ dep = a.dark_err ? a.dark_err + p : nullptr;
   const bool ld_dark = do_dark && interior;
-  long long q_next = interior ? accp[0] : 0;
-  float ds_next = ld_dark ? __builtin_nontemporal_load(&dsp[0]) : 0.f, de_next = ld_dark ? __builtin_nontemporal_load(&dep[0]) : 0.f;
+  long long q_next = interior ? ld_acc(0) : 0;
+  float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
   float sky_c = -1.f, sky_m = 0.f, sky_em = 1.f;
@@ -319,14 +347,14 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     const long long q = q_next;
     const float ds = ds_next, de = de_next;
     if (r + 1 < a.R) {
-      if (interior) q_next = accp[(size_t)(r + 1) * SS];
-      if (ld_dark) { ds_next = __builtin_nontemporal_load(&dsp[(size_t)(r + 1) * SS]); de_next = __builtin_nontemporal_load(&dep[(size_t)(r + 1) * SS]); }
+      if (interior) q_next = ld_acc(r + 1);
+      if (ld_dark) { ds_next = ld_f32(rs_ds, r + 1); de_next = ld_f32(rs_de, r + 1); }
     }
     double px = 0.;
     uint32_t g0 = 0u, g1 = 0u;
     if (do_noise) rg.next2(g0, g1);
     if (interior) {
-      if (q != 0) accp[(size_t)r * SS] = 0;   // leave the accumulator clean for the next exposure (90 % of a frame never left zero:
+      if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);   // leave the accumulator clean for the next exposure (90 % of a frame never left zero:
                                               // not re-zeroing those saves a quarter of the kernel's HBM traffic)
       px = (double)q * kInvQ;
       if (do_noise) {                // _gen_noise (:477-484, :712-727)
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
     v = v + z;                       // add_zero_read (exposure.py:94-104)
     if (rdn) v = v + kReadNoise * (double)zr;   // add_read_noise (detector.py:193-198)
-    __builtin_nontemporal_store((OutT)v, &out[(size_t)(r + 1) * SS + p]);
+    st_out(r + 1, (OutT)v);
   }
 }
 
