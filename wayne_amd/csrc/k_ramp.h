@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
 
   // software-pipelined ramp: the planes of read r+1 are requested before the
   // (VALU-heavy) work on read r so that HBM latency hides behind it.  The dark planes and the reads are
-  // streamed once: non-temporal loads / stores (measured: 0.076 -> 0.070 ms)
+  // streamed once: non-temporal loads / stores (kNT; measured: 0.076 -> 0.070 ms)
   const bool ld_dark = do_dark && interior;
   long long q_next = interior ? ld_acc(0) : 0;
   float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
@@ -354,8 +354,9 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     uint32_t g0 = 0u, g1 = 0u;
     if (do_noise) rg.next2(g0, g1);
     if (interior) {
-      if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);   // leave the accumulator clean for the next exposure (90 % of a frame never left zero:
-                                              // not re-zeroing those saves a quarter of the kernel's HBM traffic)
+      // leave the accumulator clean for the next exposure -- 90 % of a frame never left zero, and not re-zeroing
+      // those saves a quarter of the kernel's HBM traffic
+      if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);
       px = (double)q * kInvQ;
       if (do_noise) {                // _gen_noise (:477-484, :712-727)
         const double dt = a.read_dt[r];
