@@ -359,13 +359,22 @@ constexpr int kLaneThreads = 512;
 // loop (four flat-plane loads, the fp64 flat polynomial, a 64-bit atomic: microseconds of latency with the other
 // 63 lanes of the wave idle).  At a margin of 22 px (3.7 sigma_h) 3 % of the wave-iterations had such a lane and
 // the kernel ran at 220 cycles per iteration instead of ~135; 30 px is 5 sigma_h.
+//
+// Better still, the tile can hold EVERY electron: u01f() >= 2^-33, so an electron lands within
+// sigma sqrt(2 ln 2^33) = 6.764 sigma of its bin.  A workgroup whose tile -- the bins' bounding box +- (6.8
+// sigma_max + 1) px -- fits the LDS budget and lies inside the frame needs no bounds test at all: the deposit is
+// cvt, cvt, lshl_add, mad, ds_add (the tile origin folded into one scalar), four vector instructions fewer per
+// electron and no branch in the loop.  Other workgroups (frame edge, huge sigma, wild positions) keep the test and
+// the fixed margin.
 constexpr int kLaneMargin = 30;
-constexpr int kLaneTile = 5376;         // ints of LDS (21 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
+constexpr int kLaneReachMax = 48;       // largest margin of a test-free tile (sigma_h up to 6.9 px)
+constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
 
 template <int FLUSH>
 __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   __shared__ int tile[kLaneTile];
   __shared__ int s_box[4];
+  __shared__ int s_reach;                 // max over the lanes of 6.8 sigma + 1 (float bits; 0x7F800000 if a lane is not sane)
   const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
   const int w = (int)a.lane_order[blockIdx.y] * kLaneThreads + tid;
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   if (!__syncthreads_or(n > 0)) return;
   const SubInfo si = a.sub[k];
 
-  float x = -1e30f, y = -1e30f, ch = 0.f, cl = 0.f;
+  float x = -1e30f, y = -1e30f, ch = 0.f, cl = 0.f, reach = 0.f;
   int nw = 0;
   if (n > 0) {
     x = (float)a.xpos[kw];
@@ -383,23 +392,34 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     ch = (-1.3862943611198906f * sh) * sh;
     cl = (-1.3862943611198906f * sl) * sl;
     nw = min(max(a.nwide[kw], 0), n);
+    const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
+    reach = (smax >= 0.f && smax < 1e6f) ? 6.8f * smax + 1.f : __int_as_float(0x7F800000);
   }
+  const bool in = n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+  if (n > 0 && !in) reach = __int_as_float(0x7F800000);
   // workgroup tile: bounding box of its bins' positions +- margin, clipped to [1, N) and to the LDS budget
-  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
+  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; s_reach = 0; }
   __syncthreads();
+  const int ic = (int)floorf(x), jc = (int)floorf(y);
   {
-    const bool in = n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
-    const int ic = (int)floorf(x), jc = (int)floorf(y);
-    const int x_lo = wave_mini(in ? ic - kLaneMargin : 0x7FFFFFFF), x_hi = wave_maxi(in ? ic + kLaneMargin + 1 : -0x7FFFFFFF);
-    const int y_lo = wave_mini(in ? jc - kLaneMargin : 0x7FFFFFFF), y_hi = wave_maxi(in ? jc + kLaneMargin + 1 : -0x7FFFFFFF);
-    if ((tid & 63) == 0) {                     // (one atomic per wave: see k_narrow)
+    // (reduced over the wave first: one atomic per wave, see k_narrow)
+    const int x_lo = wave_mini(in ? ic : 0x7FFFFFFF), x_hi = wave_maxi(in ? ic : -0x7FFFFFFF);
+    const int y_lo = wave_mini(in ? jc : 0x7FFFFFFF), y_hi = wave_maxi(in ? jc : -0x7FFFFFFF);
+    const int r_hi = wave_maxi(__float_as_int(reach));       // (non-negative floats order as their bit patterns)
+    if ((tid & 63) == 0) {
       atomicMin(&s_box[0], x_lo); atomicMax(&s_box[1], x_hi);
       atomicMin(&s_box[2], y_lo); atomicMax(&s_box[3], y_hi);
+      atomicMax(&s_reach, r_hi);
     }
   }
   __syncthreads();
-  int tx0 = max(s_box[0], 1), tx1 = min(s_box[1], a.N), ty0 = max(s_box[2], 1), ty1 = min(s_box[3], a.N);
+  const float reach_wg = __int_as_float(s_reach);
+  bool sure = reach_wg <= (float)kLaneReachMax;               // every electron within `margin` of its bin
+  const int margin = sure ? (int)ceilf(reach_wg) : kLaneMargin;
+  const int bx0 = s_box[0] - margin, bx1 = s_box[1] + margin + 1, by0 = s_box[2] - margin, by1 = s_box[3] + margin + 1;
+  int tx0 = max(bx0, 1), tx1 = min(bx1, a.N), ty0 = max(by0, 1), ty1 = min(by1, a.N);
   int tw = max(tx1 - tx0, 0), th = max(ty1 - ty0, 0);
+  sure = sure && s_box[0] <= s_box[1] && tx0 == bx0 && tx1 == bx1 && ty0 == by0 && ty1 == by1 && (long long)tw * th <= kLaneTile;
   while ((long long)tw * th > kLaneTile && th > 1) { ty0 += 1; th = max(th - 2, 1); }
   while ((long long)tw * th > kLaneTile && tw > 1) { tx0 += 1; tw = max(tw - 2, 1); }
   if ((long long)tw * th > kLaneTile) { tw = 0; th = 0; }
@@ -411,16 +431,30 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   // had their narrow electrons taken by k_narrow (nw = n everywhere: the usual case) runs with sigma as a loop
   // constant: first the iterations EVERY lane has, with no per-lane test at all (neighbouring bins hold nearly the
   // same number of electrons), then the tail, where the stream still advances in every lane and only the deposit
-  // is suppressed (position far off the frame) for the lanes that are done.  A wave with thin, unsplit bins
-  // selects sigma per electron.
+  // is suppressed for the lanes that are done.  A wave with thin, unsplit bins selects sigma per electron.
   const int tw4 = tw * 4;
-  auto throw_one = [&](SeededStream& rng, float c, float px, float py) {
+  const int origin = -(ty0 * tw4 + tx0 * 4);                 // tile[(yi - ty0) * tw + (xi - tx0)] as a byte offset from yi, xi
+  auto draw = [&](SeededStream& rng, float c, float px, float py, int& xi, int& yi) {
     uint32_t wa, wb;
     rng.next2(wa, wb);
     const float rev = rev12(wa);
     const float Rs = __builtin_amdgcn_sqrtf(c * __builtin_amdgcn_logf(u01f(wb)));
-    const int xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);   // C truncation toward zero (:91-92)
-    const int yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
+    xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);      // C truncation toward zero (:91-92)
+    yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
+  };
+  // (test-free tile) every live electron is inside the tile and on the frame
+  auto throw_sure = [&](SeededStream& rng, float c, bool live) {
+    int xi, yi;
+    draw(rng, c, x, y, xi, yi);
+    // byte address = yi * tw4 + (xi * 4 + origin): v_lshl_add_u32, v_mad_u32_u24 (the compiler's own choice is a multiply,
+    // a shift and a three-operand add)
+    int addr;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(tw4), "v"((xi << 2) + origin));
+    if (live) atomicAdd((int*)((char*)tile + addr), 1);
+  };
+  auto throw_one = [&](SeededStream& rng, float c, float px, float py) {
+    int xi, yi;
+    draw(rng, c, px, py, xi, yi);
     const int lx = xi - tx0, ly = yi - ty0;
     if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
       atomicAdd((int*)((char*)tile + (__umul24(ly, tw4) + (lx << 2))), 1);
@@ -436,7 +470,15 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   cmax = __builtin_amdgcn_readfirstlane(cmax);
   if (cmax > 0) {
     SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
-    if (!__any(n > nw)) {
+    const bool one_sigma = !__any(n > nw);
+    if (sure) {
+      if (one_sigma) {
+        for (int j = 0; j < cmin; ++j) throw_sure(rng, ch, true);
+        for (int j = cmin; j < cmax; ++j) throw_sure(rng, ch, j < n);
+      } else {
+        for (int j = 0; j < cmax; ++j) throw_sure(rng, (j < nw) ? ch : cl, j < n);
+      }
+    } else if (one_sigma) {
       for (int j = 0; j < cmin; ++j) throw_one(rng, ch, x, y);
       for (int j = cmin; j < cmax; ++j) {
         const bool live = j < n;
