@@ -140,6 +140,55 @@ def test_rebin_spec_against_the_oracle():
     assert abs((tools.rebin_spec(wl, sp, new) * np.diff(e)).sum() - total) < 1e-10 * total
 
 
+def _bintable_fits(path, columns):
+    """A minimal FITS file with an empty primary HDU and one BINTABLE extension, written byte by byte (FITS 4.0
+    section 7.3): columns = [(name, TFORM letter, values)] -- the layout of the PHOENIX grid files the reference
+    reads with astropy (tools.py:152-170)."""
+    def card(k, v, quote=False):
+        val = ("'%-8s'" % v) if quote else ("%20s" % (("T" if v else "F") if isinstance(v, bool) else v))
+        return ("%-8s= %s" % (k, val)).ljust(80).encode("ascii")
+
+    def block(cards):
+        raw = b"".join(cards) + "END".ljust(80).encode("ascii")
+        return raw + b" " * (-len(raw) % 2880)
+
+    sizes = {"D": (">f8", 8), "E": (">f4", 4), "J": (">i4", 4)}
+    nrows = len(columns[0][2])
+    rowlen = sum(sizes[f][1] for _, f, _ in columns)
+    rows = np.zeros(nrows, dtype=np.dtype([(n, sizes[f][0]) for n, f, _ in columns]))
+    for n, f, v in columns:
+        rows[n] = v
+    primary = block([card("SIMPLE", True), card("BITPIX", 8), card("NAXIS", 0), card("EXTEND", True)])
+    cards = [card("XTENSION", "BINTABLE", True), card("BITPIX", 8), card("NAXIS", 2), card("NAXIS1", rowlen),
+             card("NAXIS2", nrows), card("PCOUNT", 0), card("GCOUNT", 1), card("TFIELDS", len(columns))]
+    for i, (n, f, _) in enumerate(columns, 1):
+        cards += [card("TTYPE%d" % i, n, True), card("TFORM%d" % i, f, True)]
+    data = rows.tobytes()
+    with open(path, "wb") as fh:
+        fh.write(primary + block(cards) + data + b"\0" * (-len(data) % 2880))
+
+
+def test_phoenix_grid_loader_sorts_and_drops_duplicates(tmp_path):
+    # tools.py:152-170: order by wavelength, then keep idx = nonzero(diff(wl)) -- which drops the first of every run
+    # of equal wavelengths AND, as written in the reference, the last sample of the file
+    wl = np.array([1.30, 1.10, 1.20, 1.20, 1.70, 1.00, 1.50, 1.50, 1.50, 1.60])
+    fl = np.arange(10, dtype=float) * 1e5 + 3.0
+    p = str(tmp_path / "lte.fits")
+    _bintable_fits(p, [("Wavelength", "D", wl), ("Flux", "D", fl), ("Extra", "J", np.arange(10))])
+    got_wl, got_fl = tools.load_pheonix_stellar_grid_fits(p)
+    order = np.argsort(wl, kind="stable")
+    swl, sfl = wl[order], fl[order]
+    keep = np.nonzero(np.diff(swl))
+    np.testing.assert_array_equal(got_wl, swl[keep])
+    np.testing.assert_array_equal(got_fl, sfl[keep])
+    assert np.all(np.diff(got_wl) > 0) and got_wl[-1] == 1.60 and got_wl.size == 6
+    # float32 columns and other capitalisation of the names load the same way
+    _bintable_fits(p, [("WAVELENGTH", "E", wl), ("FLUX", "E", fl)])
+    w32, f32 = tools.load_pheonix_stellar_grid_fits(p)
+    np.testing.assert_allclose(w32, got_wl, rtol=1e-7)
+    np.testing.assert_allclose(f32, got_fl, rtol=1e-7)
+
+
 def test_visit_planner():
     det = detector.WFC3_IR()
     vp = visit_planner.VisitPlanner(det, 5, "SPARS10", 256, num_orbits=3)
