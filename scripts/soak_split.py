@@ -49,7 +49,10 @@ def main():
         moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
         frac = moved / max(total, 1)
         worst = max(worst, frac)
-        ok = np.array_equal(got, again) and abs(int(got.sum()) - total) <= 2 + total // 100000 and moved <= 2 + 5e-4 * total
+        # (one binomial draw that flips on a 1-ulp difference between libm and the device re-draws the rest of that
+        # bin's chain: ~3 sqrt(n) electrons of ONE bin, whatever the total)
+        ok = (np.array_equal(got, again) and abs(int(got.sum()) - total) <= 2 + total // 100000 and
+              moved <= 2 + 5e-4 * total + 3 * np.sqrt(counts.max()))
         print("case %2d W=%4d N=%3d electrons=%9d moved=%6d (%.1e) %s" % (i, counts.size, N, total, moved, frac,
                                                                           "ok" if ok else "FAIL"), flush=True)
         if not ok:
