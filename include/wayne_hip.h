@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 3
+#define WAYNE_ABI_VERSION 4
 
 /* status codes */
 #define WAYNE_OK 0
@@ -106,6 +106,15 @@ int wayne_psf_apply(wayne_ctx *ctx, const int32_t *counts, int size,
                     const double *psf_sigmah, int nr, int nc, uint32_t seed,
                     int threads_compat, int rng_mode, uint32_t exposure,
                     uint32_t subsample, int32_t *out);
+/* The same with `flags`: WAYNE_F_EXACT_SAMPLERS runs the split mode's binomial chains (k_narrow) with IEEE
+ * divide and libm-grade exp / log instead of the hardware approximations -- same algorithm, same streams; for
+ * parity runs against oracle/split_oracle.c.  wayne_psf_apply is this call with flags = 0 (production math). */
+int wayne_psf_apply_ex(wayne_ctx *ctx, const int32_t *counts, int size,
+                       const double *x_pos, const double *y_pos,
+                       const double *psf_ratio, const double *psf_sigmal,
+                       const double *psf_sigmah, int nr, int nc, uint32_t seed,
+                       int threads_compat, int rng_mode, uint32_t exposure,
+                       uint32_t subsample, uint32_t flags, int32_t *out);
 
 /* ---- grism and calibration (uploaded once per context) ----------------- */
 

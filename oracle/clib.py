@@ -79,6 +79,10 @@ def lib():
         L.wayne_oracle_upper_tail.argtypes = [C.c_float]
         L.wayne_oracle_binomial_vec.restype = None
         L.wayne_oracle_binomial_vec.argtypes = [_f32p, _f32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+        L.wayne_oracle_binomial_trace.restype = None
+        L.wayne_oracle_binomial_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.wayne_oracle_binomial_trace_len.restype = C.c_int
+        L.wayne_oracle_binomial_trace_len.argtypes = []
         L.wayne_oracle_xo_pairs.restype = None
         L.wayne_oracle_xo_pairs.argtypes = [_u32p, C.c_int64, _u32p]
         L.wayne_oracle_lc_deficit.restype = None
@@ -164,6 +168,21 @@ def psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, 
     if rc != 0:
         raise ValueError("wayne_oracle_psf_split: status %d" % rc)
     return out
+
+
+def psf_split_trace(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample, perturb_at=-1, perturb_rel=0.0,
+                    cap=1 << 20):
+    """psf_split_oracle with every binomial call of the run recorded: -> (frame, calls[:, (n, p, result)]).
+    Call number `perturb_at` has its probability multiplied by (1 + perturb_rel)."""
+    buf = np.zeros((cap, 3), dtype=np.float32)
+    L = lib()
+    L.wayne_oracle_binomial_trace(buf.ctypes.data_as(C.c_void_p), cap, int(perturb_at), float(perturb_rel))
+    try:
+        frame = psf_split_oracle(counts, x, y, ratio, sl, sh, n, seed, exposure, subsample)
+        used = L.wayne_oracle_binomial_trace_len()
+    finally:
+        L.wayne_oracle_binomial_trace(None, 0, -1, 0.0)
+    return frame, buf[:min(used, cap)].copy()
 
 
 def binomial_vec(n, p, seed, subsample=0, exposure=0):

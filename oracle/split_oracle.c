@@ -51,7 +51,31 @@ static float so_fc(float k) {
   return ((float)(1.0 / 12) - ((float)(1.0 / 360) - (float)(1.0 / 1260) / k1s) / k1s) / k1;
 }
 
+static float so_binomial(float n, float p, uint32_t state[4]);
+
+/* Diagnostic hook (scripts/diagnose_split_flip.py): while a trace buffer is set, every binomial call is recorded
+ * as (n, p, result), and call number `perturb_at` has its p multiplied by (1 + perturb_rel) -- to find the draw of
+ * a chain whose outcome hangs on the last bits of its probability. */
+typedef struct { float n, p, x; } so_call;
+static so_call *so_trace_buf = 0;
+static int so_trace_cap = 0, so_trace_len = 0, so_perturb_at = -1;
+static float so_perturb_rel = 0.0f;
+void wayne_oracle_binomial_trace(float *buf3, int cap, int perturb_at, float perturb_rel) {
+  so_trace_buf = (so_call *)buf3; so_trace_cap = cap; so_trace_len = 0;
+  so_perturb_at = perturb_at; so_perturb_rel = perturb_rel;
+}
+int wayne_oracle_binomial_trace_len(void) { return so_trace_len; }
+
 float wayne_oracle_binomial_f(float n, float p, uint32_t state[4]) {
+  if (!so_trace_buf) return so_binomial(n, p, state);
+  const int i = so_trace_len++;
+  if (i == so_perturb_at) p = p * (1.0f + so_perturb_rel);
+  const float x = so_binomial(n, p, state);
+  if (i < so_trace_cap) { so_trace_buf[i].n = n; so_trace_buf[i].p = p; so_trace_buf[i].x = x; }
+  return x;
+}
+
+static float so_binomial(float n, float p, uint32_t state[4]) {
   if (!(n > 0.0f) || !(p > 0.0f)) return 0.0f;
   if (p >= 1.0f) return n;
   const int mirrored = p > 0.5f;

@@ -1,6 +1,7 @@
 """GPU: the BASELINE.json configurations at FULL size (1014x1014 / 256x256 frames,
 NSAMP 15-16, 1e7-1e9 electrons), checked through size-independent properties --
-the oracle needs minutes per exposure at these sizes:
+the properties that need no oracle (whole exposures against the oracle at these
+sizes: tests/test_fullsize_oracle_gpu.py):
 
   * conservation: with flat / gain variations off and no noise, electrons that
     reach the accumulators = electrons thrown - those falling off the frame, and

@@ -87,6 +87,8 @@ SYMBOLS = {
     "wayne_ctx_stream": (_vp, [_vp]),
     "wayne_psf_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                   C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "wayne_psf_apply_ex": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                     C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "wayne_ctx_set_grism": (C.c_int, [_vp, C.POINTER(GrismDesc)]),
     "wayne_ctx_set_calibration": (C.c_int, [_vp, C.POINTER(Calibration)]),
     "wayne_ctx_slots": (C.c_int, [_vp]),
@@ -127,7 +129,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
-        if L.wayne_abi_version() != 3:
+        if L.wayne_abi_version() != 4:
             raise ImportError("libwayne_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -200,16 +202,17 @@ class Context(object):
 
     # -- inner boundary -----------------------------------------------------
     def psf_apply(self, counts, x, y, ratio, sl, sh, nr, nc, seed, threads=1, rng_mode=RNG_REPLAY,
-                  exposure=0, subsample=0):
+                  exposure=0, subsample=0, exact_samplers=False):
         counts = i32(counts)
         x, y, ratio, sl, sh = f64(x), f64(y), f64(ratio), f64(sl), f64(sh)
         n = counts.size
         if not all(a.size == n for a in (x, y, ratio, sl, sh)):
             raise ValueError("apply_psf: arrays differ in length")
         out = np.empty(max(int(nr) * int(nc), 0), dtype=np.int32)
-        self.check(self._L.wayne_psf_apply(self._h, ptr(counts), n, ptr(x), ptr(y), ptr(ratio), ptr(sl),
-                                           ptr(sh), int(nr), int(nc), int(seed) & 0xFFFFFFFF, int(threads),
-                                           int(rng_mode), int(exposure), int(subsample), ptr(out)))
+        self.check(self._L.wayne_psf_apply_ex(self._h, ptr(counts), n, ptr(x), ptr(y), ptr(ratio), ptr(sl),
+                                              ptr(sh), int(nr), int(nc), int(seed) & 0xFFFFFFFF, int(threads),
+                                              int(rng_mode), int(exposure), int(subsample),
+                                              F_EXACT_SAMPLERS if exact_samplers else 0, ptr(out)))
         return out
 
     # -- grism / calibration --------------------------------------------------

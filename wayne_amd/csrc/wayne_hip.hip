@@ -639,6 +639,14 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
                     const double* y_pos, const double* psf_ratio, const double* psf_sigmal,
                     const double* psf_sigmah, int nr, int nc, uint32_t seed, int threads_compat,
                     int rng_mode, uint32_t exposure, uint32_t subsample, int32_t* out) {
+  return wayne_psf_apply_ex(c, counts, size, x_pos, y_pos, psf_ratio, psf_sigmal, psf_sigmah, nr, nc, seed, threads_compat,
+                            rng_mode, exposure, subsample, 0u, out);
+}
+
+int wayne_psf_apply_ex(wayne_ctx* c, const int32_t* counts, int size, const double* x_pos,
+                       const double* y_pos, const double* psf_ratio, const double* psf_sigmal,
+                       const double* psf_sigmah, int nr, int nc, uint32_t seed, int threads_compat,
+                       int rng_mode, uint32_t exposure, uint32_t subsample, uint32_t flags, int32_t* out) {
   if (!c) return WAYNE_E_INVALID;
   if (size < 0 || nr <= 0 || nc <= 0 || !out) return fail(c, WAYNE_E_INVALID, "psf_apply: bad size / frame");
   if (nr != nc)
@@ -745,7 +753,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     a.acc = nullptr;
     a.frame = c->pa_frame.as<int32_t>();
     if ((size + kNarrowThreads - 1) / kNarrowThreads > kMaxChunks && (any_lane || any_split))
-      return fail(c, WAYNE_E_INVALID, "psf_apply: more than 32768 bins in split mode");
+      return fail(c, WAYNE_E_INVALID, "psf_apply: more than 65536 bins in split mode");
     for (int i = 0; i < kMaxChunks; ++i) a.chunk_order[i] = a.lane_order[i] = (unsigned char)i;
     if (run > 0) {
       ProfScope ps(c, PK_THROW);
@@ -758,7 +766,7 @@ int wayne_psf_apply(wayne_ctx* c, const int32_t* counts, int size, const double*
     }
     if (any_split) {
       ProfScope ps(c, PK_NARROW);
-      if ((rc = launch_narrow<0>(c, a, false))) return rc;
+      if ((rc = launch_narrow<0>(c, a, (flags & WAYNE_F_EXACT_SAMPLERS) != 0))) return rc;
     }
     c->electrons += (uint64_t)total;
   }
