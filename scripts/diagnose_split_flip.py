@@ -61,13 +61,18 @@ def main():
     ys, xs = np.nonzero(diff)
     print("differing pixels: %d, x %d..%d, y %d..%d" % (ys.size, xs.min(), xs.max(), ys.min(), ys.max()))
     hit = [b for b in range(W) if split[b] and np.abs(diff[max(jc[b] - R, 0):jc[b] + R + 1, max(ic[b] - R, 0):ic[b] + R + 1]).sum()]
-    print("split bins whose 13 x 13 window holds a difference:", hit)
+    print("split bins whose 13 x 13 window holds a difference: %d of %d %s" % (len(hit), int(split.sum()), hit[:12]))
+    # only a bin whose window no other bin's electrons reach can be read off the difference frame
+    def lonely(b):
+        reach = R + np.ceil(6.8 * np.where(nw > 0, sh, 0.0)).astype(int) + 1     # other bins' wide electrons too
+        o = np.arange(W) != b
+        return not np.any(o & (counts > 0) & (np.abs(ic - ic[b]) <= R + reach) & (np.abs(jc - jc[b]) <= R + reach))
+    hit = [b for b in hit if lonely(b)][:6]
+    print("of these, bins that stand alone (analysed below):", hit)
     for b in hit:
-        others = [o for o in range(W) if o != b and split[o] and abs(ic[o] - ic[b]) <= 2 * R and abs(jc[o] - jc[b]) <= 2 * R]
         win = diff[jc[b] - R:jc[b] + R + 1, ic[b] - R:ic[b] + R + 1]
-        print("\nbin %d: x=%.4f y=%.4f sigma_l=%.4f narrow=%d, |diff| in window = %d (net %d)%s" % (
-            b, x[b], y[b], sl[b], narrow[b], np.abs(win).sum(), win.sum(),
-            "" if not others else "  [windows of bins %s overlap it]" % others))
+        print("\nbin %d: x=%.4f y=%.4f sigma_l=%.4f narrow=%d, |diff| in window = %d (net %d)" % (
+            b, x[b], y[b], sl[b], narrow[b], np.abs(win).sum(), win.sum()))
         # 2. the bin's calls in the oracle's trace: groups of 16 bins run in order; inside a non-pooling group each
         # split bin's chain is a run of calls starting with n = narrow[b]
         starts = [i for i in range(len(calls)) if calls[i, 0] == np.float32(narrow[b])]
