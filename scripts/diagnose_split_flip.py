@@ -62,59 +62,53 @@ def main():
     print("differing pixels: %d, x %d..%d, y %d..%d" % (ys.size, xs.min(), xs.max(), ys.min(), ys.max()))
     hit = [b for b in range(W) if split[b] and np.abs(diff[max(jc[b] - R, 0):jc[b] + R + 1, max(ic[b] - R, 0):ic[b] + R + 1]).sum()]
     print("split bins whose 13 x 13 window holds a difference: %d of %d %s" % (len(hit), int(split.sum()), hit[:12]))
-    # only a bin whose window no other bin's electrons reach can be read off the difference frame
-    def lonely(b):
-        reach = R + np.ceil(6.8 * np.where(nw > 0, sh, 0.0)).astype(int) + 1     # other bins' wide electrons too
-        o = np.arange(W) != b
-        return not np.any(o & (counts > 0) & (np.abs(ic - ic[b]) <= R + reach) & (np.abs(jc - jc[b]) <= R + reach))
-    hit = [b for b in hit if lonely(b)][:6]
-    print("of these, bins that stand alone (analysed below):", hit)
+    # A bin of a group that does not pool its rows draws its chain from its own stream and its own numbers alone, so
+    # the bin can be re-run BY ITSELF (every other count zero: same bin index, same stream) on both sides, and the
+    # difference of the two frames is then this bin's alone even where windows overlap in the full case.
+    hit = hit[:6]
+    counts_all = counts
     for b in hit:
-        win = diff[jc[b] - R:jc[b] + R + 1, ic[b] - R:ic[b] + R + 1]
-        print("\nbin %d: x=%.4f y=%.4f sigma_l=%.4f narrow=%d, |diff| in window = %d (net %d)" % (
-            b, x[b], y[b], sl[b], narrow[b], np.abs(win).sum(), win.sum()))
-        # 2. the bin's calls in the oracle's trace: groups of 16 bins run in order; inside a non-pooling group each
-        # split bin's chain is a run of calls starting with n = narrow[b]
-        starts = [i for i in range(len(calls)) if calls[i, 0] == np.float32(narrow[b])]
-        cand = None
-        for s in starts:
-            # a column chain: consecutive column calls have n decreasing by the previous result, with row chains between
-            cand = s
-            break
-        if cand is None:
-            print("  (could not locate the bin's chain in the trace)")
+        counts = np.zeros_like(counts_all)
+        counts[b] = counts_all[b]
+        want_b, calls = clib.psf_split_trace(counts, x, y, ratio, sl, sh, N, seed, exp, sub)
+        got_b = ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, seed, rng_mode=_lib.RNG_SPLIT, exposure=exp,
+                              subsample=sub).reshape(N, N).astype(np.int64)
+        diff_b = got_b - want_b.reshape(N, N)
+        win = diff_b[jc[b] - R:jc[b] + R + 1, ic[b] - R:ic[b] + R + 1]
+        print("\nbin %d alone: x=%.4f y=%.4f sigma_l=%.4f narrow=%d wide=%d, moved %d (in its window: |diff| = %d, net %d)" % (
+            b, x[b], y[b], sl[b], narrow[b], nw[b], np.abs(diff_b).sum() // 2, np.abs(win).sum(), win.sum()))
+        if not win.any():
+            print("  alone, the bin agrees: in the full case its group pools its rows (the flip is in a pooled chain)")
             continue
-        # walk the chain: column call, then its row calls until the column is used up
-        i, left, cols = cand, float(narrow[b]), []
+        # 2. the bin's chain in the oracle's trace, in drawing order: column c (centre-out), then that column's rows
+        # (centre-out) until the column is used up; the device's count of a call = the oracle's + the difference frame
+        off = lambda c: 0 if c == 0 else ((c + 1) // 2 if c % 2 else -(c // 2))
+        i, left, first = 0, float(narrow[b]), None
+        col_diff = win.sum(axis=0)
         c = 0
         while left > 0 and c < 2 * R + 1 and i < len(calls):
-            n_c, p_c, k_c = calls[i]
-            assert n_c == np.float32(left), (i, n_c, left)
-            cols.append((i, c, n_c, p_c, k_c))
-            left -= float(k_c)
+            n_c, p_c, k_c = (float(v) for v in calls[i])
+            assert n_c == left, (i, n_c, left)
+            dk = int(col_diff[R + off(c)])
+            if dk != 0 and first is None:
+                first = (i, "column step %d (x = ic%+d)" % (c, off(c)), n_c, p_c, k_c, dk)
             i += 1
-            m = float(k_c)
-            r = 0
+            left -= k_c
+            m, r = k_c, 0
             while m > 0 and r < 2 * R + 1:
-                m -= float(calls[i, 2])
+                n_r, p_r, k_r = (float(v) for v in calls[i])
+                dk = int(win[R + off(r), R + off(c)])
+                if dk != 0 and first is None:
+                    first = (i, "row step %d (y = jc%+d) of column step %d (x = ic%+d)" % (r, off(r), c, off(c)), n_r, p_r, k_r, dk)
+                m -= k_r
                 i += 1
                 r += 1
             c += 1
-        offs = [0 if c == 0 else ((c + 1) // 2 if c % 2 else -(c // 2)) for _, c, _, _, _ in cols]
-        col_diff = win.sum(axis=0)       # per column of the window, x = ic - R + j
-        first = None
-        for (ci, c, n_c, p_c, k_c), off in zip(cols, offs):
-            dk = int(col_diff[R + off])
-            mark = ""
-            if dk != 0 and first is None:
-                first = (ci, c, n_c, p_c, k_c, dk)
-                mark = "   <-- first column count that differs"
-            print("  column step %2d (x = ic%+d): n=%8.0f p=%.9g  oracle k=%8.0f  device k=%8.0f%s" % (
-                c, off, n_c, p_c, k_c, k_c + dk, mark))
         if first is None:
-            print("  column counts agree: the difference is inside a row chain")
+            print("  (no differing call found in the bin's chain)")
             continue
-        ci, c, n_c, p_c, k_c, dk = first
+        ci, where, n_c, p_c, k_c, dk = first
+        print("  first call of the chain whose count differs: call %d, %s" % (ci, where))
         # 3. smallest relative change of that call's p that gives the device's count
         ulp = float(np.spacing(np.float32(p_c)) / p_c)
         found = None
