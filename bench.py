@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16
 REPS = 5
+SUSTAIN_S = 2.5       # length of the sustained-rate pass
 RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th exposure (they cost the stream ~10 us a pair)
 
 
@@ -336,6 +337,17 @@ def main():
     ctx.profile_enable(False)
     prof["k_ramp"] = {"launches": prof_ramp["k_ramp"]["launches"], "ms": prof_ramp["k_ramp"]["ms"]}   # timed region
 
+    # sustained rate (not `value`): the same exposures back to back on the same stream for >= 2.5 s, cycling through
+    # the resident slots -- seconds of VALU-saturated kernels under the power cap instead of a 10 ms burst
+    sustained = None
+    if not args.no_extra_pass:
+        n_sus = int(max(args.steps, np.ceil(SUSTAIN_S * args.steps / elapsed)))
+        e_sus = timed(slot_of, n_sus, 0)
+        sustained = {"value": n_sus * n_gpus / e_sus, "unit": "exposures/s", "steps": n_sus, "seconds": e_sus,
+                     "vs_value": (n_sus / e_sus) / (args.steps / elapsed),
+                     "note": "%d exposures per rank back to back on one stream (the timed region's workload and slots), "
+                             "barrier + synchronise either side, max over ranks" % n_sus}
+
     # sanity: the last exposure really produced a frame
     reads = ctx.download(slot_of(args.steps - 1))
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
@@ -461,6 +473,7 @@ def main():
                                 "k_lane on the slot's stream with k_narrow beside them on a side stream"
                         if forked else "k_throw + k_lane (one interval), then k_narrow, on one stream"},
         }
+        line["sustained"] = sustained
         line.update(extras)
         # numbers that only a rocprofv3 --pmc run can give come from profiles/*.json, which
         # scripts/collect_profiles.sh stamps with the hash of wayne_amd/csrc they were measured on: quoted only
@@ -480,7 +493,12 @@ def main():
         v = json.load(open(vf)) if os.path.exists(vf) else {}
         if args.config == "cfg4" and args.thrower == "split":
             if v.get("csrc_hash") == here:
-                line["thrower"]["valu_issue"] = {k: {"frac": x["valu_issue_frac"], "lane_utilisation": x["lane_utilisation"]}
+                # counted and un-clamped (scripts/make_profile_stamps.py): quad-cycles of vector execution over SIMD cycles
+                line["thrower"]["valu_issue"] = {k: {"valu_busy_frac": x["valu_busy_frac"],
+                                                     "valu_busy_frac_sq_busy": x.get("valu_busy_frac_sq_busy"),
+                                                     "cycles_source": x.get("cycles_source"),
+                                                     "eff_clock_ghz": x.get("eff_clock_ghz"),
+                                                     "lane_utilisation": x["lane_utilisation"]}
                                                  for k, x in v["kernels"].items()}
                 line["thrower"]["valu_issue_source"] = v.get("source", "profiles/valu_issue.json")
             else:

@@ -16,9 +16,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- $B --steps 4 --warmup 1 > /dev/null 2> $OUT/pmc_$c.log
 done
-for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU"; do
+for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVES SQ_BUSY_CU_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVE_CYCLES"; do
   n=$(echo $c | tr " " "_")
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/sq_$n -o p -- $B --steps 4 --warmup 1 > /dev/null 2> $OUT/sq_$n.log
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/sq_$n -o p -- $B --steps 4 --warmup 1 > /dev/null 2> $OUT/sq_$n.log || echo "pmc pass $n failed (see $OUT/sq_$n.log)"
 done
 python3 $R/scripts/summarize_pmc.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_hbm.json
 python3 $R/scripts/summarize_pmc.py $OUT/sq_* > $OUT/pmc_sq.json

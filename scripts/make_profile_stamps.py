@@ -54,27 +54,36 @@ def main():
     issue = dict(stamp)
     issue["source"] = "%s/pmc_sq.json (rocprofv3 --pmc SQ counters, scripts/collect_profiles.sh), commit %s" % (
         os.path.basename(prof_dir.rstrip("/")), commit[:10])
-    issue["note"] = ("a wave64 VALU instruction holds a SIMD for 4 cycles, a transcendental for 11.5 (measured: "
-                     "scripts/ubench/issue_cost.hip, profiles/r02/issue_cost_ubench.txt): "
-                     "issue_cycles_per_simd = (4 SQ_INSTS_VALU + 7.5 SQ_INSTS_VALU_TRANS_F32) / 1024 SIMDs; busy = "
-                     "SQ_BUSY_CYCLES / 32 shader engines; valu_issue_frac = min(1, issue / busy); lane_utilisation = "
-                     "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)")
+    issue["note"] = (
+        "valu_busy_frac = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): SQ_ACTIVE_INST_VALU counts the QUAD-cycles a "
+        "SIMD spends executing vector instructions (MI355X_MICROARCH.md: 'SQ_ACTIVE_INST_* count quad-cycles'; it equals "
+        "SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32 on these kernels: 4 cycles per wave64 instruction, 8 per transcendental); "
+        "cycles = GRBM_GUI_ACTIVE / 8 XCDs of the same dispatch (the shader clock really run, DVFS included) when that "
+        "counter was collected, else SQ_BUSY_CYCLES / 32 shader engines.  Counted, not modelled, and NOT clamped: a value "
+        "above 1 would say the normalisation is wrong.  valu_busy_frac_sq_busy is the same over SQ_BUSY_CYCLES / 32; "
+        "eff_clock_ghz = cycles / kernel_avg_ns; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)")
     issue["kernels"] = {}
     for k, c in sq.items():
         if "wayne::" not in k or not all(n in c for n in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_THREAD_CYCLES_VALU",
                                                            "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_TRANS_F32")):
             continue
         valu, trans = c["SQ_INSTS_VALU"]["mean"], c["SQ_INSTS_VALU_TRANS_F32"]["mean"]
-        busy = c["SQ_BUSY_CYCLES"]["mean"] / 32.0
-        if busy < 20000:          # tiny kernels say nothing
+        active = c["SQ_ACTIVE_INST_VALU"]["mean"]
+        busy_sq = c["SQ_BUSY_CYCLES"]["mean"] / 32.0
+        if busy_sq < 20000:          # tiny kernels say nothing
             continue
-        cyc = (4 * valu + 7.5 * trans) / 1024.0
+        gui = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0 if "GRBM_GUI_ACTIVE" in c else None
+        cycles = gui if gui else busy_sq
+        ns = avg.get(k, {}).get("avg_ns")
         issue["kernels"][k.replace("wayne::", "")] = {
             "valu_wave_instructions": round(valu), "transcendental_wave_instructions": round(trans),
-            "issue_cycles_per_simd": round(cyc), "busy_cycles": round(busy),
-            "valu_issue_frac": round(min(1.0, cyc / busy), 3), "model_ratio": round(cyc / busy, 3),
-            "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]), 3),
-            "kernel_avg_ns": avg.get(k, {}).get("avg_ns")}
+            "valu_active_quad_cycles": round(active),
+            "cycles": round(cycles), "cycles_source": "GRBM_GUI_ACTIVE/8" if gui else "SQ_BUSY_CYCLES/32",
+            "valu_busy_frac": round(4.0 * active / 1024.0 / cycles, 3),
+            "valu_busy_frac_sq_busy": round(4.0 * active / 1024.0 / busy_sq, 3),
+            "eff_clock_ghz": round(cycles / ns, 3) if ns else None,
+            "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / (64.0 * active), 3),
+            "kernel_avg_ns": ns}
     json.dump(issue, open(os.path.join(prof_dir, "valu_issue.json"), "w"), indent=1)
     print("stamped", prof_dir, stamp)
 

@@ -36,6 +36,10 @@ def test_bench_line_has_the_contract_keys():
     for key in ("per_electron", "per_electron_f64", "replay_bit_exact", "out_f64", "two_streams", "delivered", "end_to_end"):
         assert d[key]["unit"] == "exposures/s" and d[key]["value"] > 10, key
     assert d["replay_bit_exact"]["value"] < d["per_electron"]["value"] < d["value"]
+    # the sustained pass: seconds of back-to-back exposures, reported beside `value`
+    sus = d["sustained"]
+    assert sus["unit"] == "exposures/s" and sus["seconds"] >= 2.0 and sus["steps"] >= 1000
+    assert 0.7 * d["value"] < sus["value"] < 1.2 * d["value"]
     assert d["delivered"]["value"] < d["two_streams"]["value"]
     assert 0 < d["end_to_end"]["frac_of_pcie"] < 1
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 1e8

@@ -75,10 +75,32 @@ def test_float32_reads_are_rounded_float64_reads():
     v = helpers.make_visit("tiny128")
     pg = helpers.product_generator(v, 0)
     kw = v.frame_kwargs(0)
-    a = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, **kw).reads])
-    b = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float32, **kw).reads])
+    # exact samplers: one arithmetic, the float32 read is the float64 read rounded once
+    a = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, exact_samplers=True, **kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float32, exact_samplers=True, **kw).reads])
     assert a.dtype == np.float64 and b.dtype == np.float32
     np.testing.assert_array_equal(a.astype(np.float32), b)
+    # production math: the float32 variant of k_ramp does its per-read arithmetic in float32 where a float32 read
+    # cannot tell (k_ramp.h, "PRODUCTION VARIANT"): same draws, reads within the float32 tolerance
+    a = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, **kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float32, **kw).reads])
+    np.testing.assert_allclose(b, a, rtol=2e-7, atol=0.02)
+    assert np.abs(b - a).max() < 0.01 and np.median(np.abs(b - a)) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["small256", "cfg4"])
+def test_production_float32_ramp_against_float64_ramp(name):
+    # the same at sizes where pixels run up the non-linear part of the ramp (tens of thousands of DN), every
+    # detector switch on: the production float32 k_ramp against the float64 variant in the same (hardware) math
+    v = helpers.make_visit(name)
+    pg = helpers.product_generator(v, 0)
+    kw = v.frame_kwargs(0)
+    a = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float64, **kw).reads])
+    b = np.stack([r[0] for r in pg.scanning_frame(out_dtype=np.float32, **kw).reads])
+    assert a[-1].max() > 5000
+    d = np.abs(b - a)
+    np.testing.assert_allclose(b, a, rtol=2e-7, atol=0.02)
+    assert np.median(d) < 1e-3
 
 
 def test_reference_quirk_switch_at_1024():

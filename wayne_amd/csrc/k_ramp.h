@@ -28,6 +28,9 @@ struct RampArgs {
   int sky_levels;            // L
   float sky_level[16];       // ascending levels of the master sky (quantiles of its positive pixels; [0] = min)
   unsigned char sky_tab0[16];  // first table of read r (its level-0 table; level j is the j-th after it)
+  // the same per-read numbers laid out for wave-uniform (scalar) loads in the production variant's read loop
+  float bg[16];              // (float)(sky_ct_s * read_dt[r]): bg_count of read r (:489-491)
+  int tab0[16];              // sky_tab0[r]
 };
 
 constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
@@ -167,6 +170,60 @@ __device__ __forceinline__ float sky_draw_cached(const uint32_t* tab, float m, f
     }
   }
   return k + j;
+}
+
+// sky_draw_cached with the count kept in integers: the same words, the same compares, the same count (the
+// production read loop adds it to the accumulator's fixed-point value before that is converted).
+template <class RNG>
+__device__ __forceinline__ int sky_draw_count(const uint32_t* tab, float m, float em, RNG& rng) {
+  uint32_t w, wr;
+  rng.next2(w, wr);
+  const uint32_t idx = w >> 24;
+  const uint32_t e = tab[idx];
+  const int k = (int)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
+  const float u = u01f(wr);
+  float t = em, cdf = t;
+  int j = (u > cdf) ? 1 : 0;   t = t * m;                 cdf += t;
+  j += (u > cdf) ? 1 : 0;      t = t * (m * 0.5f);         cdf += t;
+  j += (u > cdf) ? 1 : 0;      t = t * (m * 0.33333334f);  cdf += t;
+  j += (u > cdf) ? 1 : 0;
+  if (u > cdf) {
+#pragma nounroll
+    for (int it = 4; it < 512; ++it) {
+      t = t * FastMath::div_(m, (float)it);
+      cdf += t;
+      if (!(u > cdf)) break;
+      j = j + 1;
+    }
+  }
+  return k + j;
+}
+
+// nonlinear_response for the production variant (float32 reads): Newton on the GAP g = px - u, which is what the
+// non-linearity takes off a pixel -- at most ~5 % of it -- so float32 carries it to ~1e-7 of ITS size, i.e. to
+// < 1e-3 DN at full well, where the float32 read itself rounds at 4e-3 DN:
+//     u (1 + c1 + c2 u + c3 u^2 + c4 u^3) = px   <=>   g = u h(u),  h(u) = c1' + c2 u + c3 u^2 + c4 u^3,  u = px - g
+// (c1' = fl(1 + c1) - 1: the reference adds 1 to the float32 plane in float32, detector.py:339).  Same warm start,
+// same stop (|step| < 1e-3), same derivative as nonlinear_response; one fp64 subtraction at the end instead of an
+// fp64 residual per iteration.
+__device__ __forceinline__ double nonlinear_gap(double px, float c1p, float c2, float c3, float c4, NlState& st) {
+  const float d1 = 1.0f + c1p, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
+  const float pxf = (float)px;
+  float g = fmaf(pxf - st.v_prev, st.bend, st.gap);
+  float rinv = 1.0f;
+  for (int it = 0; it < 64; ++it) {
+    const float u = pxf - g;
+    const float h = fmaf(u, fmaf(u, fmaf(u, c4, c3), c2), c1p);
+    const float fp_ = fmaf(u, fmaf(u, fmaf(u, d4, d3), d2), d1);
+    rinv = __builtin_amdgcn_rcpf(fp_);
+    const float step = fmaf(u, h, -g) * rinv;          // Newton on phi(g) = u h(u) - g,  phi' = -f'(u)
+    g = g + step;
+    if (fabsf(step) < 1e-3f) break;
+  }
+  st.v_prev = pxf;
+  st.gap = g;
+  st.bend = 1.0f - rinv;
+  return px - (double)g;
 }
 
 // Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
@@ -343,6 +400,63 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
   float sky_c = -1.f, sky_m = 0.f, sky_em = 1.f;
+  if (std::is_same<OutT, float>::value && FAST && SKY == 1 && !NOISE) {
+    // PRODUCTION VARIANT (float32 reads, hardware math, alias-table sky, no gaussian-noise stage): the same
+    // stages, streams and draws as the generic loop below with the arithmetic cut to what a float32 read needs --
+    // the sky count joins the accumulator as an integer, one fp64 fma takes fixed point -> DN -> cumulative sum,
+    // dark and read noise are float32 fmas, the non-linearity is solved on the gap in float32 (nonlinear_gap), and
+    // the per-read numbers (bg_count, first table) come in scalar registers, so that what depends on them alone is
+    // recomputed only when the read interval changes.  Against the exact / float64 variants: <= 0.02 DN + 2e-7
+    // (tests/test_modes_gpu.py, tests/test_fullsize_oracle_gpu.py).
+    const double inv_gq = inv_g * kInvQ;                   // accumulator unit -> DN
+    const float c1p = (1.0f + c1) - 1.0f;
+    const float zf = (float)z;
+    uint32_t bg_prev = 0xFFFFFFFFu;                        // bits of the previous read's bg (a scalar, like bg)
+    for (int r = 0; r < a.R; ++r) {
+      const long long q = q_next;
+      const float ds = ds_next, de = de_next;
+      if (r + 1 < a.R) {
+        if (interior) q_next = ld_acc(r + 1);
+        if (ld_dark) { ds_next = ld_f32(rs_ds, r + 1); de_next = ld_f32(rs_de, r + 1); }
+      }
+      const float bg = a.bg[r];                            // wave-uniform: scalar loads
+      const int tab = a.tab0[r];
+      const uint32_t bg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(bg));
+      if (bg_bits != bg_prev) {                            // a new read interval (a scalar branch): the pixel's
+        bg_prev = bg_bits;                                 // remainder mean and its e^-m
+        sky_m = fmaxf(skyv * bg - sky_base * bg, 0.f);
+        asm volatile("v_exp_f32 %0, %1" : "=v"(sky_em) : "v"(-1.4426950408889634f * sky_m));   // (volatile: not to be speculated into every read)
+      }
+      if (interior) {
+        if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);
+        long long qq = q;
+        if (skyv > 0.f) {
+          if (skyv * bg > 0.f)
+            qq += (long long)sky_draw_count(s_tab[tab + sky_lvl], sky_m, sky_em, rs) << kQBits;
+        }
+        // fixed point -> double (hi 2^32 + lo, exact), -> DN and onto the cumulative sum in one fma
+        const double d = fma((double)(int)(qq >> 32), 4294967296.0, (double)(unsigned)qq);
+        cum = fma(d, inv_gq, cum);
+      }
+      float zd = 0.f, zr = 0.f;
+      uint32_t w0, w1;
+      rn.next2(w0, w1);
+      if (rdn || ld_dark) bm_pair<true>(w0, w1, zd, zr);
+      double v = 0.;                                       // reference pixels (exposure.py:122-131)
+      if (interior) {
+        v = cum;
+        if (do_dark) v = cum + (double)fmaf((de > 0.f) ? de : 0.00001f, zd, ds);
+        if (do_lin) v = nonlinear_gap(v, c1p, c2, c3, c4, nl);
+        if (clip) {                                        // (plain v_max / v_min: fmax() would canonicalise first)
+          asm volatile("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(v) : "v"(v), "s"(kMinCounts), "s"(kMaxCounts));
+        }
+      }
+      // + zero read + read noise (exposure.py:94-104, detector.py:193-198)
+      const float tail = rdn ? fmaf((float)kReadNoise, zr, zf) : zf;
+      st_out(r + 1, (OutT)(float)(v + (double)tail));
+    }
+    return;
+  }
   for (int r = 0; r < a.R; ++r) {
     const long long q = q_next;
     const float ds = ds_next, de = de_next;

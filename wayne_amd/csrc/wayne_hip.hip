@@ -86,7 +86,7 @@ struct Slot {
   std::vector<double> read_dt_host;
   double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
-  unsigned char chunk_order[kMaxChunks] = {0};   // chunks of 256 bins, most electrons first (ThrowArgs::chunk_order)
+  unsigned char chunk_order[kMaxChunks] = {0};   // chunks of kNarrowThreads bins, most electrons first (ThrowArgs::chunk_order)
   unsigned char lane_order[kMaxChunks] = {0};    // chunks of kLaneThreads bins, most electrons first
   // pinned staging arena of the descriptor's arrays: uploads are enqueued from here, so
   // wayne_exposure_upload returns without waiting for the slot's stream to drain
@@ -1198,7 +1198,8 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   a.sky_alias = s.sky_alias_on ? s.sky_tab.as<uint32_t>() : nullptr;
   a.alias_mask = s.sky_alias_on ? s.sky_mask : 0u;
   a.sky_levels = s.sky_L;
-  for (int l = 0; l < 16; ++l) { a.sky_level[l] = s.sky_level[l]; a.sky_tab0[l] = s.sky_tab0[l]; }
+  for (int l = 0; l < 16; ++l) { a.sky_level[l] = s.sky_level[l]; a.sky_tab0[l] = s.sky_tab0[l]; a.tab0[l] = s.sky_tab0[l]; a.bg[l] = 0.f; }
+  for (int r = 0; r < s.R && r < 16; ++r) a.bg[r] = (float)(d.sky_ct_s * s.read_dt_host[r]);
   const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
