@@ -62,7 +62,7 @@ struct PrepArgs {
   uint32_t seed, exposure;
   uint32_t flags;
   int split_min;             // > 0: WAYNE_RNG_SPLIT -- bins with >= split_min narrow electrons go to k_narrow
-  int lane_max;              // WAYNE_RNG_SPLIT: most one-by-one electrons a bin's own lane takes (kLaneMax; unlimited
+  int lane_max;              // WAYNE_RNG_SPLIT: most one-by-one electrons a bin's own lane takes (kLaneMax; kLaneReach
                              // when the host launches no k_throw for the exposure because it expects no larger bin)
   double scale_factor;
   const double* wl;          // [W]
@@ -94,6 +94,8 @@ constexpr int kPrepThreads = 512;
 constexpr int kMaxPrepChunks = 128;     // chunks of kPrepThreads bins per sub-sample (32768 bins)
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
+constexpr int kLaneReach = 64 * kLaneMax;   // ... and up to this many in an exposure launched without k_throw (a lane then needs
+                                       // ~10 ms for its bin; beyond it the exposure is run again with k_throw)
 constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
 
 __device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
@@ -348,9 +350,12 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
       a.nlane[(size_t)k * W + w] = lane ? (int32_t)ind : 0;
       n_split_total += (split ? narrow : 0u) + (lane ? ind : 0u);
       c = lane ? 0u : ind;                                   // c: electrons left for k_throw
+      // launched without k_throw (the host expected no bin beyond a lane's reach) and here is one after all:
+      // tell the host, which runs the exposure again with k_throw (wayne_hip.hip, check_status)
+      if (a.fix_inline && c > 0u) atomicOr(a.status, 2);
     }
   }
-  if (overflow) atomicExch(a.status, 1);
+  if (overflow) atomicOr(a.status, 1);
   // electrons handed to k_lane / k_narrow: one atomic per workgroup (wave shuffle, then LDS)
   for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
   __shared__ unsigned long long s_split[NW];
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
       if (i < wave) wave_off += t;
       chunk_total += t;
     }
-    if (chunk_total > 0xFFFFFFFFull) atomicExch(a.status, 1);
+    if (chunk_total > 0xFFFFFFFFull) atomicOr(a.status, 1);
     if (w < W) a.prefix[(size_t)k * (W + 1) + w] = (uint32_t)(wave_off + incl - c);   // chunk-local for now
     if (tid == 0) {
       for (int i = 1; i < NW; ++i) {
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
   __syncthreads();
   for (int w = tid; w < W; w += kPrepThreads) a.prefix[(size_t)k * (W + 1) + w] += s_off[w / kPrepThreads];
   if (tid == 0) {
-    if (s_over) atomicExch(a.status, 1);
+    if (s_over) atomicOr(a.status, 1);
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int i = 0; i < n_chunks; ++i) {
       const size_t ci = (size_t)k * n_chunks + i;

@@ -60,6 +60,7 @@ struct Slot {
   bool front_done = false;
   bool acc_dirty = false;
   bool acc_init = false;
+  bool force_throw = false;   // the last run met a bin beyond a lane's reach: run with k_throw (set by check_status)
   wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
   int W = 0, K = 0, R = 0;
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
@@ -970,6 +971,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order);
   if ((rc = prepare_sky_tables(c, s))) return rc;
+  s.force_throw = false;
   s.uploaded = true;
   s.front_done = false;
   return WAYNE_OK;
@@ -1030,7 +1032,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   }
   // margin of a thrower workgroup's tile around its slice of the trace: 5 sigma_h, so that practically no electron
   // takes the in-loop global-atomic path (see k_lane)
-  bool lane_unlimited = false;
+  bool lane_unlimited = false;   // split mode without a k_throw launch: the lanes take every bin (up to kLaneReach)
   const int margin = d.thrower_margin > 0 ? d.thrower_margin : 30;
   {
     PrepArgs a{};
@@ -1052,11 +1054,15 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.nlane = s.nlane.as<int32_t>();
     a.split_min = (d.rng_mode == WAYNE_RNG_SPLIT) ? kSplitMin : 0;
     // no bin expected beyond a lane's cap (the rule on every BASELINE configuration): k_throw is not launched at
-    // all -- an empty launch still costs ~8 us of the exposure's critical path -- and the lanes take whatever
-    // they find (a bin that defies the estimate is thrown by its lane, slowly but completely)
-    a.lane_max = (d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0. && d.thrower_splits <= 0 &&
-                  !std::getenv("WAYNE_THROW_WGS")) ? 0x7FFFFFFF : kLaneMax;
-    lane_unlimited = a.lane_max == 0x7FFFFFFF;
+    // all -- an empty launch still costs ~8 us of the exposure's critical path -- and the lanes take what they
+    // find up to kLaneReach electrons; a bin beyond that (the estimate carries no Poisson noise) sets status bit 1
+    // and the exposure is run again with k_throw when its status is read (check_status)
+    // (WAYNE_LANE_REACH: a test knob that lowers the lanes' reach so that the re-run path can be exercised)
+    int reach = kLaneReach;
+    if (const char* e = std::getenv("WAYNE_LANE_REACH")) reach = std::min(std::max(std::atoi(e), 1), kLaneReach);
+    lane_unlimited = d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0. && d.thrower_splits <= 0 && !s.force_throw &&
+                     !std::getenv("WAYNE_THROW_WGS");
+    a.lane_max = lane_unlimited ? reach : kLaneMax;
     a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sub = s.sub.as<SubInfo>();
     a.total_electrons = c->counters.as<unsigned long long>();
@@ -1094,7 +1100,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
         splits = (int)std::min(4096., std::ceil(lanes / kThrowThreads));
         // split mode with no bin expected beyond a lane's cap: k_throw finds nothing to do (any stray bin is
         // handled by the one workgroup per sub-sample launched here)
-        if (d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0.) splits = -1;
+        if (d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0. && !s.force_throw) splits = -1;
         // a lane takes several units when the launch would exceed ~24 workgroups per CU: then ~12 per CU
         // (each lane a handful of units) is the measured optimum (scripts/sweep_throw.py)
         const int cap = std::max(1, (3072 + K - 1) / K);
@@ -1223,11 +1229,14 @@ int wayne_exposure_run(wayne_ctx* c, int slot) {
   return wayne_exposure_run_back(c, slot);
 }
 
-static int check_status(wayne_ctx* c, Slot& s) {
+// Status word of the slot's last run: bit 0 = overflow (an error), bit 1 = a bin beyond the lanes' reach in an
+// exposure launched without k_throw (*rerun is set: the caller runs the exposure again, now with k_throw).
+static int check_status(wayne_ctx* c, Slot& s, bool* rerun = nullptr) {
   struct { unsigned long long electrons; int status; int pad; } m{};
   HIP_TRY(c, hipMemcpyAsync(&m, s.misc.p, sizeof m, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (m.status != 0) return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  if (m.status & 1) return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  if (rerun) *rerun = (m.status & 2) != 0;
   return WAYNE_OK;
 }
 
@@ -1240,6 +1249,12 @@ int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
   use_slot_stream(c, slot);
   const size_t SS = (size_t)c->S * c->S;
   const size_t out_elem = (s.d.flags & WAYNE_F_OUT_F64) ? sizeof(double) : sizeof(float);
+  HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
+  bool rerun = false;
+  int rc = check_status(c, s, &rerun);
+  if (rc || !rerun) return rc;
+  s.force_throw = true;
+  if ((rc = wayne_exposure_run(c, slot))) return rc;
   HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
   return check_status(c, s);
 }
@@ -1284,8 +1299,17 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
   use_slot_stream(c, slot);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *host_reads = s.pinned;
-  if (s.pinned_misc->status != 0)
+  if (s.pinned_misc->status & 1)
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  if (s.pinned_misc->status & 2) {           // a bin beyond the lanes' reach: once more, with k_throw
+    s.force_throw = true;
+    int rc = wayne_exposure_run(c, slot);
+    if (rc == WAYNE_OK) rc = wayne_exposure_fetch_async(c, slot);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (s.pinned_misc->status & 1)
+      return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+  }
   return WAYNE_OK;
 }
 
@@ -1313,6 +1337,17 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
   if (counts) HIP_TRY(c, hipMemcpyAsync(counts, s.counts.p, KW * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   if (x_pos) HIP_TRY(c, hipMemcpyAsync(x_pos, s.xpos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (y_pos) HIP_TRY(c, hipMemcpyAsync(y_pos, s.ypos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  {
+    // (between run_front and run_back: a run that met a bin beyond the lanes' reach is repeated with k_throw first)
+    bool rerun = false;
+    int rc = check_status(c, s, &rerun);
+    if (rc) return rc;
+    if (rerun && s.front_done) {
+      s.force_throw = true;
+      if ((rc = wayne_exposure_run_front(c, slot))) return rc;
+      return wayne_exposure_debug_fetch(c, slot, counts, x_pos, y_pos, acc_e);
+    }
+  }
   if (acc_e) {
     const size_t n = (size_t)s.R * c->S * c->S;
     std::vector<long long> tmp(n);

@@ -19,6 +19,7 @@ class Engine(object):
         self.grism, self.detector, self.calibration = grism, detector, calibration
         self.NSAMP, self.SAMPSEQ, self.SUBARRAY = NSAMP, SAMPSEQ, SUBARRAY
         self.read_times = detector.get_read_times(NSAMP, SUBARRAY, SAMPSEQ)    # seconds
+        self.flat_shift = int(flat_shift)      # +5 px roll of the flat planes that goes with sub_scale = -5 (reference_quirks)
         self.ctx = _lib.Context(device)
         sens_wl, sens_val = calibration.sensitivity(grism.name)
         # the reference's G102 inherits the G141 flat cube and its WMIN / WMAX (grism.py:428: G102.__init__
@@ -37,6 +38,15 @@ class Engine(object):
                                  dark_sci=planes.get("dark_sci"), dark_err=planes.get("dark_err"),
                                  zero_read=planes.get("zero_read"))
         self.N, self.S, self.R = self.ctx.N, self.ctx.S, self.ctx.R
+
+    def check_descriptor(self, sub_scale):
+        """The descriptor's frame offset also indexes the flat (wayne_hip.hip: flat_off = sub_scale), so it must be
+        the offset this engine's flat planes were laid out for: at SUBARRAY 1024 that is -5 with the planes rolled
+        by +5 px (reference_quirks) or 0 with the planes as they are -- never a mix of the two."""
+        if self.SUBARRAY == 1024 and int(sub_scale) != -self.flat_shift:
+            raise ValueError("descriptor sub_scale %d does not go with this engine's flat planes (rolled by %d px): "
+                             "build the engine and the descriptor with the same reference_quirks" % (
+                                 sub_scale, self.flat_shift))
 
     def close(self):
         self.ctx.close()

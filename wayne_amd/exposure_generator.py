@@ -284,6 +284,8 @@ class ExposureGenerator(object):
         if self.SUBARRAY == 1024 and not reference_quirks:
             sub_scale = 0
 
+        if eng is not None:
+            eng.check_descriptor(sub_scale)
         self._read_dt = read_dt
         self._host_vectors = {"x_ref": s_x, "y_ref": s_y, "dur": s_dur, "seeds": s_rand_seeds}
         return _lib.make_desc(

@@ -57,7 +57,8 @@ class VisitRunner(object):
         if self._eng is None:
             v = self.visit
             self._eng = _engine.get_engine(self.device, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ,
-                                           v.SUBARRAY)
+                                           v.SUBARRAY,
+                                           g102_flat_quirk=bool(self.frame_overrides.get("reference_quirks", False)))
         return self._eng
 
     def generator(self, i):
