@@ -98,7 +98,7 @@ constexpr int kLaneReach = 64 * kLaneMax;   // ... and up to this many in an exp
                                        // ~10 ms for its bin; beyond it the exposure is run again with k_throw)
 constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
 
-__device__ __forceinline__ void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
+WAYNE_HD void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
   // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
     // wavelength_calibration_coeffs (grism.py:779-803)
     const double* t = g.trace;
@@ -136,6 +136,8 @@ struct CosmicArgs {
   double rate;               // hits per second per 1024^2 pixels; < 0: no cosmic rays
   const double* read_dt;     // [R]
   long long* acc;            // [R*S*S]
+  uint32_t* seg;             // [ceil(S*S / 64)] bit r: read interval r has a hit among the segment's 64 accumulators
+                             // (k_ramp loads the accumulators outside the spectrum's box only where a bit says so)
 };
 
 __device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t* s_n) {
@@ -156,8 +158,9 @@ __device__ __forceinline__ void cosmic_hits(const CosmicArgs& a, int r, uint32_t
     const uint32_t y = uint_below(w.v[1], (uint32_t)a.N);          // randint(0, len(array))  (:80)
     const uint32_t x = uint_below(w.v[2], (uint32_t)a.N);          // randint(0, len(array[0])) (:81)
     const long long q = (long long)energy << kQBits;
-    atomicAdd((unsigned long long*)&a.acc[((size_t)r * a.S + (y + kBorder)) * a.S + (x + kBorder)],
-              (unsigned long long)q);
+    const size_t pix = (size_t)(y + kBorder) * a.S + (x + kBorder);
+    atomicAdd((unsigned long long*)&a.acc[(size_t)r * a.S * a.S + pix], (unsigned long long)q);
+    atomicOr(&a.seg[pix >> 6], 1u << r);
   }
 }
 

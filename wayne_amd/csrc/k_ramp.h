@@ -31,6 +31,13 @@ struct RampArgs {
   // the same per-read numbers laid out for wave-uniform (scalar) loads in the production variant's read loop
   float bg[16];              // (float)(sky_ct_s * read_dt[r]): bg_count of read r (:489-491)
   int tab0[16];              // sky_tab0[r]
+  // Which accumulators of read interval r can be non-zero: those inside box[r] = {x0, x1, y0, y1} (bordered
+  // coordinates, half open; the host's bound on where the thrower's electrons of that interval can land) and those of
+  // a 64-pixel segment whose bit r is set in `seg` (cosmic-ray hits).  A wave loads its 64 accumulators of a read
+  // only when one of the two says so -- ~95 % of a frame never leaves zero.  use_box = 0: load everything.
+  int use_box;
+  int box[16][4];
+  uint32_t* seg;             // [ceil(S*S / 64)] read and cleared
 };
 
 constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
@@ -369,6 +376,22 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
   };
 
+  // the wave's 64 consecutive pixels against the boxes: all scalar
+  const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
+  const int wy0 = p0 / S, wy1 = min(p0 + 63, S * S - 1) / S, wx0 = p0 - wy0 * S;
+  uint32_t cbits = 0u;
+  if (a.use_box && p0 < S * S) {
+    cbits = __builtin_amdgcn_readfirstlane(a.seg[p0 >> 6]);
+    if (cbits != 0u && (tid & 63) == 0) a.seg[p0 >> 6] = 0u;     // left clean for the next exposure, like the accumulators
+  }
+  auto acc_live = [&](int r) -> bool {
+    if (!a.use_box) return true;
+    const int bx0 = a.box[r][0], bx1 = a.box[r][1], by0 = a.box[r][2], by1 = a.box[r][3];
+    const bool rows = wy0 < by1 && wy1 >= by0;
+    const bool cols = (wy0 != wy1) || (wx0 < bx1 && wx0 + 64 > bx0);
+    return (rows && cols) || ((cbits >> r) & 1u) != 0u;
+  };
+
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
   double z = (a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
   // (VALU-heavy) work on read r so that HBM latency hides behind it.  The dark planes and the reads are
   // streamed once: non-temporal loads / stores (kNT; measured: 0.076 -> 0.070 ms)
   const bool ld_dark = do_dark && interior;
-  long long q_next = interior ? ld_acc(0) : 0;
+  long long q_next = (interior && acc_live(0)) ? ld_acc(0) : 0;
   float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
       const long long q = q_next;
       const float ds = ds_next, de = de_next;
       if (r + 1 < a.R) {
-        if (interior) q_next = ld_acc(r + 1);
+        q_next = 0; if (interior && acc_live(r + 1)) q_next = ld_acc(r + 1);
         if (ld_dark) { ds_next = ld_f32(rs_ds, r + 1); de_next = ld_f32(rs_de, r + 1); }
       }
       const float bg = a.bg[r];                            // wave-uniform: scalar loads
@@ -461,7 +484,7 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     const long long q = q_next;
     const float ds = ds_next, de = de_next;
     if (r + 1 < a.R) {
-      if (interior) q_next = ld_acc(r + 1);
+      q_next = 0; if (interior && acc_live(r + 1)) q_next = ld_acc(r + 1);
       if (ld_dark) { ds_next = ld_f32(rs_ds, r + 1); de_next = ld_f32(rs_de, r + 1); }
     }
     double px = 0.;

@@ -68,6 +68,9 @@ struct Slot {
   DevBuf ratio, sigl, sigh, sens, dlam;
   DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
+  DevBuf seg;             // cosmic-ray segments (CosmicArgs::seg): zeroed when allocated, k_ramp clears what it reads
+  bool use_box = false;   // acc_box is valid: k_ramp loads the accumulators of a read only inside it (and where `seg` says)
+  int acc_box[16][4] = {{0}};
   DevBuf in_dev;          // device mirror of the staging arena: the descriptor's arrays arrive in ONE copy
   void* pinned = nullptr;  // pinned host copy of `out` (fetch_async / wait), followed by a copy of `misc`
   size_t pinned_cap = 0;
@@ -98,7 +101,7 @@ struct Slot {
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
                       &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &nlane, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
-                      &misc, &sky_tab, &in_dev})
+                      &misc, &seg, &sky_tab, &in_dev})
       b->release();
     if (sky_tab_host) (void)hipHostFree(sky_tab_host);
     sky_tab_host = nullptr;
@@ -379,6 +382,50 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
   std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return lane_e[a_] > lane_e[b_]; });
   for (int i = 0; i < n_lane_chunks && i < kMaxChunks; ++i) lane_order[i] = (unsigned char)order[i];
   return total;
+}
+
+// Where can the accumulators of read interval r be non-zero after the thrower?  An electron lands within
+// sigma sqrt(2 ln 2^33) = 6.764 sigma of its bin in every rng mode (k_lane: "a tile that holds every electron"; the
+// replay thrower's rand_r / RAND_MAX reaches 6.56 sigma; k_narrow's window is +-6 px), and the bins of a sub-sample lie
+// on the straight trace between its first and its last wavelength.  So per read: the union over its sub-samples of
+// the trace's end points, +- (6.8 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
+// everything) when the numbers are not ones a bound can be built on.
+bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
+  const int W = d->n_wl, K = d->n_samples, R = d->n_reads, S = c->S;
+  const GrismDev& g = c->g;
+  auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
+  double smax = 0.;
+  for (int i = 0; i < W; ++i) {
+    const double sl = poly3(g.p_sigl, d->wl_um[i]), sh = poly3(g.p_sigh, d->wl_um[i]);
+    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3)) return false;
+    smax = std::max(smax, std::max(sl, sh));
+  }
+  const double reach = 6.8 * smax + 2.;
+  if (!(reach < 400.)) return false;
+  for (int r = 0; r < 16; ++r) { box[r][0] = box[r][2] = 0x3FFFFFFF; box[r][1] = box[r][3] = -0x3FFFFFFF; }
+  for (int k = 0; k < K; ++k) {
+    const int r = d->sample_read[k];
+    if (r < 0 || r >= R || r >= 16) return false;
+    double tr[6];
+    trace_coeffs(g, d->x_ref[k], d->y_ref[k], tr);
+    for (int e = 0; e < 2; ++e) {
+      const double wl = d->wl_um[e ? W - 1 : 0];
+      const double x = (wl - tr[5]) / tr[4];
+      const double y = tr[0] * (x - d->x_ref[k]) + tr[1] + d->y_ref[k];
+      const double xs = x - (double)d->sub_scale + kBorder, ys = y - (double)d->sub_scale + kBorder;
+      if (!(std::fabs(xs) < 1e6 && std::fabs(ys) < 1e6)) return false;
+      box[r][0] = std::min(box[r][0], (int)std::floor(xs - reach));
+      box[r][1] = std::max(box[r][1], (int)std::floor(xs + reach) + 1);
+      box[r][2] = std::min(box[r][2], (int)std::floor(ys - reach));
+      box[r][3] = std::max(box[r][3], (int)std::floor(ys + reach) + 1);
+    }
+  }
+  for (int r = 0; r < 16; ++r) {
+    if (box[r][0] > box[r][1]) { box[r][0] = box[r][1] = box[r][2] = box[r][3] = 0; continue; }   // a read without sub-samples
+    box[r][0] = std::max(box[r][0], 0); box[r][2] = std::max(box[r][2], 0);
+    box[r][1] = std::min(box[r][1], S); box[r][3] = std::min(box[r][3], S);
+  }
+  return true;
 }
 
 // Plan the sky draws of an exposure (k_ramp, sky_draw): levels of the master sky, one alias table of
@@ -970,6 +1017,14 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order);
+  s.use_box = accumulator_boxes(c, d, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
+  {
+    const size_t seg_bytes = ((SS + 63) / 64) * sizeof(uint32_t);
+    if (s.seg.cap < seg_bytes) {
+      HIP_TRY(c, s.seg.reserve(seg_bytes));
+      HIP_TRY(c, hipMemsetAsync(s.seg.p, 0, s.seg.cap, c->stream));
+    }
+  }
   if ((rc = prepare_sky_tables(c, s))) return rc;
   s.force_throw = false;
   s.uploaded = true;
@@ -994,8 +1049,9 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       c->kdone_valid[other] = false;
     }
   }
-  if (s.acc_dirty) {
+  if (s.acc_dirty) {     // a front half without its back half: start from clean accumulators (and segment bits)
     HIP_TRY(c, hipMemsetAsync(s.acc.p, 0, (size_t)R * SS * sizeof(long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(s.seg.p, 0, s.seg.cap, c->stream));
     s.acc_dirty = false;
   }
   if (s.has_lc) {
@@ -1075,6 +1131,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
     ca.rate = (d.cosmic_rate >= 0.) ? d.cosmic_rate : -1.;
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
+    ca.seg = s.seg.as<uint32_t>();
     ProfScope ps(c, PK_PREP_SUB);
     hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
     HIP_TRY(c, hipGetLastError());
@@ -1206,6 +1263,9 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   a.sky_levels = s.sky_L;
   for (int l = 0; l < 16; ++l) { a.sky_level[l] = s.sky_level[l]; a.sky_tab0[l] = s.sky_tab0[l]; a.tab0[l] = s.sky_tab0[l]; a.bg[l] = 0.f; }
   for (int r = 0; r < s.R && r < 16; ++r) a.bg[r] = (float)(d.sky_ct_s * s.read_dt_host[r]);
+  a.use_box = s.use_box ? 1 : 0;
+  std::memcpy(a.box, s.acc_box, sizeof a.box);
+  a.seg = s.seg.as<uint32_t>();
   const int threads = kRampThreads;
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
