@@ -813,6 +813,71 @@ class SSVSine(object):
         return sample_durations * ssv_scaling
 
 
+class SSVModulatedSine(object):
+    """scan_speed_varations.py:63-171, statement for statement and draw for draw, over a numpy legacy generator
+    `rs` standing in for the reference's global np.random stream (run_visit.py:68-77), with the astropy units
+    written out: `read_times` in seconds, `sample_rate` in MILLISECONDS (what ExposureGenerator passes,
+    exposure_generator.py:263-267; the reference converts both to seconds, :90-91).  Returns (durations in ms,
+    read indexes) as the reference does (:171)."""
+
+    def __init__(self, amplitude=10, period=1.1, blip_proba=1):
+        self.amplitude, self.period, self.blip_proba = amplitude, period, blip_proba      # :78-80
+
+    def get_subsample_exposure_times(self, y_mid_points, sample_durations, read_times, sample_rate, rs=None):
+        read_times = np.asarray(read_times, dtype=float)             # :90
+        sample_rate = float(sample_rate) / 1000.                     # :91 (ms -> s)
+        period = self.period
+        amplitude = self.amplitude
+        exptime = np.round(read_times[-1], 6)                        # :96
+        tt = np.arange(0, exptime, sample_rate)                      # :97
+        amp1 = np.ones_like(tt)
+        amp2 = rs.normal(0.1, 0.05) * np.sin(
+            (2 * np.pi / rs.normal(2.0 * exptime, 0.5 * exptime)) * tt + rs.random_sample() * 2 * np.pi)   # :100-102
+        if 100.0 * rs.random_sample() < self.blip_proba:             # :103
+            amp3 = rs.normal(1.0, 0.1) * np.exp(-(tt - rs.random_sample() * exptime) ** 2 / (2 * (period / 2) ** 2))
+        else:
+            amp3 = 0
+        final_amp = sample_rate * (amplitude / 100.0) * (amp1 + amp2 + amp3)     # :110
+        per1 = np.ones_like(tt)
+        per2 = rs.normal(0.1, 0.05) * np.sin(
+            (2 * np.pi / rs.normal(2.0 * exptime, 0.5 * exptime)) * tt + rs.random_sample() * 2 * np.pi)   # :113-115
+        final_per = period * (per1 + per2)
+        final_phase = rs.random_sample() * 2 * np.pi                 # :118
+        final_sub_exptimes = np.round(sample_rate + final_amp * np.sin((2 * np.pi / final_per) * tt + final_phase), 6)
+        difference = int((10 ** 6) * np.round(exptime - np.sum(final_sub_exptimes), 6))   # :122-123
+        if difference < 0:
+            for i in range(abs(difference)):
+                final_sub_exptimes[rs.randint(len(final_sub_exptimes))] -= 0.000001
+        else:
+            for i in range(abs(difference)):
+                final_sub_exptimes[rs.randint(len(final_sub_exptimes))] += 0.000001
+        breaks = []
+        for i in read_times:                                         # :133-135
+            breaks.append(int(np.argmin(abs(np.cumsum(final_sub_exptimes) - i))))
+        difference = int((10 ** 6) * np.round(read_times[0] - np.sum(final_sub_exptimes[:breaks[0] + 1]), 6))
+        dis = np.int_(rs.power(3, abs(difference)) * (breaks[0] + 1))             # :139
+        if difference < 0:
+            for i in dis:
+                final_sub_exptimes[breaks[0] - i] -= 0.000001
+                final_sub_exptimes[rs.randint(breaks[0] + 1, len(final_sub_exptimes))] += 0.000001
+        else:
+            for i in dis:
+                final_sub_exptimes[breaks[0] - i] += 0.000001
+                final_sub_exptimes[rs.randint(breaks[0] + 1, len(final_sub_exptimes))] -= 0.000001
+        for read in range(1, len(read_times) - 1):                   # :151-167
+            difference = int((10 ** 6) * np.round(read_times[read] - np.sum(final_sub_exptimes[:breaks[read] + 1]), 6))
+            if difference < 0:
+                for i in range(abs(difference)):
+                    final_sub_exptimes[rs.randint(breaks[read - 1] + 1, breaks[read] + 1)] -= 0.000001
+                    final_sub_exptimes[rs.randint(breaks[read] + 1, len(final_sub_exptimes))] += 0.000001
+            else:
+                for i in range(abs(difference)):
+                    final_sub_exptimes[rs.randint(breaks[read - 1] + 1, breaks[read] + 1)] += 0.000001
+                    final_sub_exptimes[rs.randint(breaks[read] + 1, len(final_sub_exptimes))] -= 0.000001
+        read_indexes = breaks
+        return final_sub_exptimes * 1000., read_indexes              # :171 (s -> ms)
+
+
 def from_calibration(cal, grism_name, NSAMP, SAMPSEQ, SUBARRAY, g102_flat_quirk=False):
     """Build (Detector, Grism, ExposureOracle) over the UNCROPPED arrays of a
     calibration set (any object with .flat/.flat_wl/.sky/.sens/.pfl/.lin/.bias_256

@@ -41,3 +41,17 @@ def oracle_kwargs(kw):
     if ssv is not None:
         kw["ssv_generator"] = wo.SSVSine(ssv.stddev, ssv.period, ssv.start_phase)
     return kw
+
+
+def split_moved_bound(counts, total, exact=False):
+    """Most electrons the device's split thrower may place in another pixel than oracle/split_oracle.c on the same
+    counters.  A binomial draw of a chain comes out differently when its uniform lands within
+    the last bits of a step of the cdf / of a rejection test -- glibc against ocml with exact samplers, hardware
+    rcp / exp / log in production math -- and the rest of THAT chain is then drawn afresh: a few sqrt(n) electrons
+    of one bin or, where a group of 16 bins pools its rows, of one pooled column (n up to the group's electrons),
+    whatever the total (scripts/diagnose_split_flip.py names such a draw: soak case 217, Binomial(8321, 0.1763),
+    1 ulp of p).  So: a rate term for the many draws of a large input plus room for one flipped chain."""
+    counts = np.asarray(counts, dtype=np.float64)
+    n_chain = 16.0 * float(counts.max()) if counts.size else 0.0
+    rate = 2e-6 if exact else 1e-4        # measured: 3.5e-7 / 5e-6 at 1e9 electrons, 2.5e-8 / 2.3e-5 at 1.2e8
+    return 2 + rate * float(total) + 3.0 * np.sqrt(n_chain)

@@ -1,0 +1,55 @@
+"""GPU: a short fixed-seed run of scripts/soak.py -- many exposures through the VisitRunner pipeline (slots in
+rotation over the context's two streams, pinned staging and fetch buffers reused again and again), then a sample of
+them regenerated one at a time and compared bit for bit."""
+import numpy as np
+import pytest
+
+import helpers
+from wayne_amd import visit
+from wayne_amd.exposure_generator import ExposureGenerator
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_visit_equals_one_at_a_time_generation():
+    n = 160
+    v = helpers.make_visit("cfg3", n_exposures=n)
+    runner = visit.VisitRunner(v, 0)
+    seen = {}
+    runner.run(range(n), on_reads=lambda i, r: seen.__setitem__(i, (float(r[-1].sum()), float(r[1].max()),
+                                                                    r[-1][::7, ::5].copy())))
+    assert len(seen) == n and all(np.isfinite(s[0]) for s in seen.values())
+    for i in sorted(set([0, 1, 2, n // 3, n // 2, n - 2, n - 1] + [int(j) for j in np.random.default_rng(1).integers(0, n, 6)])):
+        eg = ExposureGenerator(v.detector, v.grism, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=v.calibration,
+                               seed=v.seed, exposure_index=i)
+        reads = np.stack([r[0] for r in eg.scanning_frame(**v.frame_kwargs(i)).reads])
+        assert float(reads[-1].sum()) == seen[i][0] and float(reads[1].max()) == seen[i][1], i
+        np.testing.assert_array_equal(reads[-1][::7, ::5], seen[i][2])
+
+
+def test_a_bin_beyond_the_lanes_reach_reruns_with_k_throw(monkeypatch):
+    # the default launch has no k_throw (the host expects no bin beyond a lane's cap) and the lanes then take bins of
+    # up to 64 x 4096 one-by-one electrons; a bin beyond that flags the run (status bit 1) and the exposure is
+    # repeated with k_throw when its status is read.  With the reach lowered to 5 electrons (a test knob) nearly every
+    # bin of this exposure is "beyond": the repeated run routes them as an ordinary launch does (lanes up to 4096),
+    # so the frame must equal the ordinary one bit for bit -- nothing lost, nothing thrown twice
+    v = helpers.make_visit("small256")
+    kw = v.frame_kwargs(0)
+    pg = helpers.product_generator(v, 0)
+    want = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    monkeypatch.setenv("WAYNE_LANE_REACH", "5")
+    rec = {}
+    via_record = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw).reads])     # debug_fetch re-runs the front half
+    via_download = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])              # download re-runs the exposure
+    from wayne_amd import engine
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    desc = pg.build_descriptor(eng, **kw)
+    eng.ctx.upload(3, desc)
+    eng.ctx.run(3)
+    eng.ctx.fetch_async(3)
+    via_wait = np.array(eng.ctx.wait(3))                                                 # the pipelined path re-runs too
+    monkeypatch.delenv("WAYNE_LANE_REACH")
+    assert (rec["counts"] * 0.2 > 5).mean() > 0.5                                        # most bins were beyond the reach
+    np.testing.assert_array_equal(via_record, want)
+    np.testing.assert_array_equal(via_download, want)
+    np.testing.assert_array_equal(via_wait, want)

@@ -13,6 +13,8 @@ checks are statistical, each against an analytic expectation:
   * whole exposures in the two modes: pixel differences scaled by their Poisson
     error have zero mean and unit variance.
 """
+import os
+
 import numpy as np
 import pytest
 from scipy import special, stats
@@ -100,7 +102,12 @@ def test_split_mode_against_oracle_same_counters(gpu_ctx, name, scale):
         total = int(want.sum())
         moved = int(np.abs(got.astype(np.int64) - want.astype(np.int64)).sum()) // 2
         assert abs(int(got.sum()) - total) <= 2 + total // 100000
-        assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
+        assert moved <= helpers.split_moved_bound(counts, total), "%d of %d electrons moved" % (moved, total)
+        # exact samplers: IEEE divide, ocml exp / log -- only glibc-vs-ocml last bits are left
+        got = gpu_ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, seed,
+                                rng_mode=_lib.RNG_SPLIT, exposure=exp, subsample=sub, exact_samplers=True)
+        moved = int(np.abs(got.astype(np.int64) - want.astype(np.int64)).sum()) // 2
+        assert moved <= helpers.split_moved_bound(counts, total, exact=True), "%d of %d electrons moved" % (moved, total)
 
 
 def test_pooled_row_groups_against_oracle_same_counters(gpu_ctx):
@@ -142,7 +149,38 @@ def test_pooled_row_groups_against_oracle_same_counters(gpu_ctx):
         assert total > 0.6 * counts.sum()
         assert abs(int(got.sum()) - total) <= 2 + total // 100000
         moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
-        assert moved <= 2 + 5e-4 * total, "%d of %d electrons moved" % (moved, total)
+        # (bin 14/3 holds 2^24 + 77 electrons, but it is thrown one by one: the largest CHAIN is an ordinary group's)
+        assert moved <= helpers.split_moved_bound(np.minimum(counts, 5000), total), "%d of %d electrons moved" % (moved, total)
+
+
+def test_soak_cases_against_oracle(gpu_ctx):
+    # a fixed-seed stretch of scripts/soak_split.py (random numbers of bins, trace-like and scattered positions, thin
+    # and dense bins, sigma ranges that pool, fall back or mix inside a wave) -- and the case that once exceeded the
+    # old "5e-4 of the total" bound: case 217 of seed 23, 17 bins, ONE flipped draw
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_split
+    from oracle import clib
+    rng = np.random.default_rng(23)
+    worst = 0.0
+    for i in range(218):
+        counts, x, y, ratio, sl, sh, N = soak_split.case(rng)
+        seed, exp, sub = int(rng.integers(0, 2**31)), int(rng.integers(0, 100)), int(rng.integers(0, 3000))
+        if i >= 40 and i != 217:
+            continue
+        want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, seed, exp, sub)
+        total = int(want.sum())
+        for exact in (False, True):
+            got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, seed, rng_mode=_lib.RNG_SPLIT, exposure=exp,
+                                    subsample=sub, exact_samplers=exact)
+            assert abs(int(got.sum()) - total) <= 2 + total // 100000
+            moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
+            assert moved <= helpers.split_moved_bound(counts, total, exact=exact), (i, exact, moved, total)
+            if not exact:
+                worst = max(worst, moved / max(total, 1))
+        if i == 217:
+            assert counts.size == 17 and total == 396579          # the case of gpurun_out/soak_split4.txt:218
+    assert worst < 1e-3
 
 
 def test_thin_bins_against_oracle_same_counters(gpu_ctx):
@@ -162,7 +200,7 @@ def test_thin_bins_against_oracle_same_counters(gpu_ctx):
         got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, seed, rng_mode=_lib.RNG_SPLIT, exposure=exp, subsample=sub)
         assert got.sum() == want.sum() == counts.sum()
         moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
-        assert moved <= 2 + 5e-4 * counts.sum(), "%d of %d electrons moved" % (moved, counts.sum())
+        assert moved <= helpers.split_moved_bound(counts, counts.sum()), "%d of %d electrons moved" % (moved, counts.sum())
     # only thin bins: nothing for the multinomial, nothing for k_throw
     counts = rng.integers(0, 16, W).astype(np.int32)
     want = clib.psf_split_oracle(counts, x, y, ratio, sl, sh, N, 9, 1, 2)

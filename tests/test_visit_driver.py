@@ -357,6 +357,26 @@ def test_ssv_modulated_sine_preserves_read_times():
         assert abs(dur[sread <= r].sum() / 1000 - rt[r]) < 2e-6
 
 
+@pytest.mark.parametrize("mode", [(5, 256, "SPARS10", 10.0), (16, 1024, "SPARS10", 40.0), (8, 512, "SPARS25", 25.0),
+                                  (4, 64, "RAPID", 1.0)])
+def test_ssv_modulated_sine_against_the_oracle(mode):
+    # the product's generator against oracle/wayne_oracle.py's statement-for-statement restatement of
+    # scan_speed_varations.py:63-171, both over a numpy legacy stream with the same seed: same draws in the same
+    # order -> the same microsecond bookkeeping -> equal durations and read indexes
+    from oracle import wayne_oracle as wo
+    from wayne_amd.trend_generators.scan_speed_varations import SSVModulatedSine
+    nsamp, sub, seq, rate = mode
+    rt = detector.WFC3_IR().get_read_times(nsamp, sub, seq)
+    for seed in (0, 1, 7, 2024):
+        for blip in (0, 100):
+            got_d, got_i = SSVModulatedSine(10, 1.1, blip, rng_seed=seed).get_subsample_exposure_times(None, None, rt, rate)
+            want_d, want_i = wo.SSVModulatedSine(10, 1.1, blip).get_subsample_exposure_times(
+                None, None, rt, rate, rs=np.random.RandomState(seed))
+            assert list(got_i) == list(want_i), (seed, blip)
+            np.testing.assert_array_equal(got_d, want_d)
+            assert len(want_i) == nsamp - 1 and abs(want_d.sum() / 1000 - rt[-1]) < 2e-6
+
+
 @pytest.mark.gpu
 def test_exposure_with_modulated_sine_ssv():
     import helpers

@@ -39,7 +39,8 @@ def stale():
 def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
+    # WAYNE_CXXFLAGS: extra compiler flags for experiments (e.g. -DWAYNE_RAMP_PF=2); not used by any shipped build
+    cmd = [HIPCC] + FLAGS + os.environ.get("WAYNE_CXXFLAGS", "").split() + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

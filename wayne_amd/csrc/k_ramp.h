@@ -376,21 +376,28 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
   };
 
-  // the wave's 64 consecutive pixels against the boxes: all scalar
+  // Per-read numbers without a memory access in the read loop: lane l of every wave fetches those of read l once
+  // (bg_count, first sky table, the box of the read's accumulators), tests the wave's 64 consecutive pixels against
+  // box l, and the loop then takes read r's numbers with v_readlane and its "load the accumulators?" bit from a
+  // ballot.  (Scalar loads of a.bg[r] / a.box[r] at the top of every iteration measured no gain over the LDS reads
+  // they replaced: their latency sat in front of the iteration's first use.)
+  const int lane_r = min(tid & 63, kMaxReads);
+  const int v_bg = __float_as_int(a.bg[lane_r]), v_tab0 = a.tab0[lane_r];
   const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
   const int wy0 = p0 / S, wy1 = min(p0 + 63, S * S - 1) / S, wx0 = p0 - wy0 * S;
-  uint32_t cbits = 0u;
-  if (a.use_box && p0 < S * S) {
-    cbits = __builtin_amdgcn_readfirstlane(a.seg[p0 >> 6]);
-    if (cbits != 0u && (tid & 63) == 0) a.seg[p0 >> 6] = 0u;     // left clean for the next exposure, like the accumulators
-  }
-  auto acc_live = [&](int r) -> bool {
-    if (!a.use_box) return true;
-    const int bx0 = a.box[r][0], bx1 = a.box[r][1], by0 = a.box[r][2], by1 = a.box[r][3];
+  unsigned long long live_bits = ~0ull;
+  if (a.use_box) {
+    uint32_t cbits = 0u;
+    if (p0 < S * S) {
+      cbits = __builtin_amdgcn_readfirstlane(a.seg[p0 >> 6]);
+      if (cbits != 0u && (tid & 63) == 0) a.seg[p0 >> 6] = 0u;   // left clean for the next exposure, like the accumulators
+    }
+    const int bx0 = a.box[lane_r][0], bx1 = a.box[lane_r][1], by0 = a.box[lane_r][2], by1 = a.box[lane_r][3];
     const bool rows = wy0 < by1 && wy1 >= by0;
     const bool cols = (wy0 != wy1) || (wx0 < bx1 && wx0 + 64 > bx0);
-    return (rows && cols) || ((cbits >> r) & 1u) != 0u;
-  };
+    live_bits = __ballot((rows && cols) || ((cbits >> lane_r) & 1u) != 0u);
+  }
+  auto acc_live = [&](int r) -> bool { return ((live_bits >> r) & 1ull) != 0ull; };
 
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
@@ -435,15 +442,33 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     const float c1p = (1.0f + c1) - 1.0f;
     const float zf = (float)z;
     uint32_t bg_prev = 0xFFFFFFFFu;                        // bits of the previous read's bg (a scalar, like bg)
-    for (int r = 0; r < a.R; ++r) {
-      const long long q = q_next;
-      const float ds = ds_next, de = de_next;
-      if (r + 1 < a.R) {
-        q_next = 0; if (interior && acc_live(r + 1)) q_next = ld_acc(r + 1);
-        if (ld_dark) { ds_next = ld_f32(rs_ds, r + 1); de_next = ld_f32(rs_de, r + 1); }
+#ifndef WAYNE_RAMP_PF
+#define WAYNE_RAMP_PF 1                                    // reads whose planes are in flight ahead of the one in work
+#endif
+    constexpr int PF = WAYNE_RAMP_PF;
+    long long qn[PF];
+    float dsn[PF], den[PF];
+    qn[0] = q_next; dsn[0] = ds_next; den[0] = de_next;
+#pragma unroll
+    for (int i = 1; i < PF; ++i) {
+      qn[i] = 0; dsn[i] = den[i] = 0.f;
+      if (i < a.R) {
+        if (interior && acc_live(i)) qn[i] = ld_acc(i);
+        if (ld_dark) { dsn[i] = ld_f32(rs_ds, i); den[i] = ld_f32(rs_de, i); }
       }
-      const float bg = a.bg[r];                            // wave-uniform: scalar loads
-      const int tab = a.tab0[r];
+    }
+    for (int r = 0; r < a.R; ++r) {
+      const long long q = qn[0];
+      const float ds = dsn[0], de = den[0];
+#pragma unroll
+      for (int i = 0; i + 1 < PF; ++i) { qn[i] = qn[i + 1]; dsn[i] = dsn[i + 1]; den[i] = den[i + 1]; }
+      qn[PF - 1] = 0;
+      if (r + PF < a.R) {
+        if (interior && acc_live(r + PF)) qn[PF - 1] = ld_acc(r + PF);
+        if (ld_dark) { dsn[PF - 1] = ld_f32(rs_ds, r + PF); den[PF - 1] = ld_f32(rs_de, r + PF); }
+      }
+      const float bg = __int_as_float(__builtin_amdgcn_readlane(v_bg, r));   // wave-uniform (see lane_r)
+      const int tab = __builtin_amdgcn_readlane(v_tab0, r);
       const uint32_t bg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(bg));
       if (bg_bits != bg_prev) {                            // a new read interval (a scalar branch): the pixel's
         bg_prev = bg_bits;                                 // remainder mean and its e^-m
