@@ -54,17 +54,19 @@ SUSTAIN_S = 2.5       # length of the sustained-rate pass
 RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th exposure (they cost the stream ~10 us a pair)
 
 
-def ramp_bytes(N, S, R, out_bytes):
+def ramp_bytes(N, S, R, out_bytes, acc_segments=None):
     """Compulsory HBM bytes of ONE k_ramp launch as designed (DESIGN.md "k_ramp"):
-    per interior pixel and read: int64 accumulator read (8), dark SCI + ERR (4 + 4), read written
-    (out_bytes); once per pixel: pixel flat 4, sky 4, c1..c4 16, zero read written (out_bytes).
-    Border pixels only write their reads.  The accumulators the thrower touched (~10 % of a frame)
-    are also written back as zeros: exposure dependent, left out here (the conservative choice for
-    `roofline.achieved`; the PMC figure `roofline.traffic` contains them)."""
+    per interior pixel and read: dark SCI + ERR (4 + 4), read written (out_bytes); the int64 accumulator
+    (8) only where the read's electrons can have landed -- `acc_segments` 64-accumulator segments in all
+    (wayne_exposure_debug_boxes: the segments one wave loads; None: every interior pixel of every read, the
+    design of rounds 1-2); once per pixel: pixel flat 4, sky 4, c1..c4 16, zero read written (out_bytes).
+    Border pixels only write their reads.  The accumulators that left zero are also written back as
+    zeros and cosmic-ray segments are loaded too: exposure dependent, left out here (the conservative
+    choice for `roofline.achieved`; the PMC figure `roofline.traffic` contains them)."""
     inner = N * N
-    per_read_inner = 8 + 4 + 4
+    acc = R * inner * 8 if acc_segments is None else int(acc_segments) * 64 * 8
     once_inner = 4 + 4 + 16
-    return R * (inner * per_read_inner + S * S * out_bytes) + inner * once_inner + S * S * out_bytes
+    return R * (inner * (4 + 4) + S * S * out_bytes) + acc + inner * once_inner + S * S * out_bytes
 
 
 def survey_bytes(N, S, R, K, W, out_bytes, A_fp):
@@ -425,7 +427,9 @@ def main():
         ob = 8 if args.out_f64 else 4
         launches = max(prof["k_ramp"]["launches"], 1)
         ramp_ms = prof["k_ramp"]["ms"] / launches
-        rb = ramp_bytes(N, S, R, ob)
+        use_box, _, segs = ctx.debug_boxes(slot_of(0))
+        rb = ramp_bytes(N, S, R, ob, int(segs.sum()) if use_box else None)
+        rb_all = ramp_bytes(N, S, R, ob)
         achieved = rb / (ramp_ms * 1e-3) / 1e9
         sb = survey_bytes(N, S, R, K, W, ob, 1.64e5)
         throw_ms = prof["k_throw"]["ms"] / max(prof["k_throw"]["launches"], 1)
@@ -462,6 +466,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_ramp", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": rb, "ms_per_launch": ramp_ms,
+                         "accumulator_segments_loaded": int(segs.sum()) if use_box else None,
+                         "bytes_per_launch_loading_every_accumulator": rb_all,
+                         "achieved_loading_every_accumulator": rb_all / (ramp_ms * 1e-3) / 1e9,
+                         "note": "bytes_per_launch counts the int64 accumulators only where the kernel loads them (the "
+                                 "per-read boxes of the thrower's reach); the r01/r02 kernel loaded all of them: that "
+                                 "byte count and the GB/s it would give are listed beside it, not used for `frac`",
                          "launches_timed": prof_ramp["k_ramp"]["launches"],
                          "timing": "HIP events on the kernel's own stream, every %d-th launch of the timed region" % RAMP_EVENTS_EVERY,
                          "survey_formula_bytes_per_exposure": sb,

@@ -251,6 +251,12 @@ int wayne_exposure_debug_fetch(wayne_ctx *ctx, int slot, int32_t *counts,
 /* The K*W transit-depth matrix of `slot` (as uploaded, or as computed by k_lightcurve
  * in the last run_front), for parity tests. */
 int wayne_exposure_debug_depth(wayne_ctx *ctx, int slot, double *depth);
+/* Which accumulators the ramp kernel of `slot` loads (for the byte accounting of bench.py): boxes[r*4 .. r*4+3] =
+ * {x0, x1, y0, y1} of read interval r in bordered coordinates, the host's bound on where the thrower's electrons of
+ * that interval can land (all zero: everything is loaded), and segments[r] = the number of 64-accumulator segments
+ * (one per wave) that intersect it.  Segments with a cosmic-ray hit are loaded too and not counted here.
+ * boxes: 16*4 ints, segments: 16 ints.  Returns WAYNE_OK, *use_box = 0 when the slot loads every accumulator. */
+int wayne_exposure_debug_boxes(wayne_ctx *ctx, int slot, int32_t *boxes, int32_t *segments, int *use_box);
 /* The two halves of wayne_exposure_run: front = prep + thrower + cosmic rays,
  * back = the fused up-the-ramp kernel. */
 int wayne_exposure_run_front(wayne_ctx *ctx, int slot);

@@ -101,6 +101,7 @@ SYMBOLS = {
     "wayne_exposure_synthesize": (C.c_int, [_vp, C.POINTER(ExposureDesc), _vp]),
     "wayne_exposure_debug_fetch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "wayne_exposure_debug_depth": (C.c_int, [_vp, C.c_int, _vp]),
+    "wayne_exposure_debug_boxes": (C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
     "wayne_exposure_run_front": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_run_back": (C.c_int, [_vp, C.c_int]),
     "wayne_profile_enable": (C.c_int, [_vp, C.c_int]),
@@ -315,6 +316,14 @@ class Context(object):
         out = np.empty((K, W), dtype=np.float64)
         self.check(self._L.wayne_exposure_debug_depth(self._h, int(slot), ptr(out)))
         return out
+
+    def debug_boxes(self, slot):
+        """(use_box, boxes[16, 4], segments[16]): which accumulators k_ramp loads for the slot's exposure."""
+        boxes = np.zeros((16, 4), dtype=np.int32)
+        seg = np.zeros(16, dtype=np.int32)
+        use = C.c_int(0)
+        self.check(self._L.wayne_exposure_debug_boxes(self._h, int(slot), ptr(boxes), ptr(seg), C.byref(use)))
+        return bool(use.value), boxes, seg
 
     def debug_fetch(self, slot, acc=False):
         K, W, R, _ = self._slot_meta[slot]

@@ -1418,6 +1418,31 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
   return check_status(c, s);
 }
 
+int wayne_exposure_debug_boxes(wayne_ctx* c, int slot, int32_t* boxes, int32_t* segments, int* use_box) {
+  if (!c || !boxes || !segments || !use_box) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "debug_boxes: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "debug_boxes: slot not uploaded");
+  *use_box = s.use_box ? 1 : 0;
+  const int S = c->S;
+  for (int r = 0; r < 16; ++r) {
+    for (int i = 0; i < 4; ++i) boxes[4 * r + i] = s.use_box ? s.acc_box[r][i] : 0;
+    int n = 0;
+    if (r < s.R) {
+      // the wave test of k_ramp (acc_live) over the frame's 64-pixel segments
+      for (int p0 = 0; p0 < S * S; p0 += 64) {
+        const int wy0 = p0 / S, wy1 = std::min(p0 + 63, S * S - 1) / S, wx0 = p0 - wy0 * S;
+        const int* b = s.acc_box[r];
+        const bool rows = wy0 < b[3] && wy1 >= b[2];
+        const bool cols = (wy0 != wy1) || (wx0 < b[1] && wx0 + 64 > b[0]);
+        n += (!s.use_box || (rows && cols)) ? 1 : 0;
+      }
+    }
+    segments[r] = n;
+  }
+  return WAYNE_OK;
+}
+
 int wayne_exposure_debug_depth(wayne_ctx* c, int slot, double* depth) {
   if (!c || !depth) return WAYNE_E_INVALID;
   if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "debug_depth: slot");
