@@ -199,7 +199,7 @@ static int so_trunc(float v) {
  * multinomial.  What is left to throw one by one -- the wide electrons of such a
  * bin, or the whole of a bin that does not qualify -- is thrown from the bin's
  * OWN stream when it is at most `lane_max` electrons (the device gives each bin a
- * lane, k_lane): electron j takes pair j of the xoshiro128+ stream seeded by
+ * lane, k_lane): electron j takes WORD j of the xoshiro128+ stream seeded by
  * Philox block (bin, 0, sub-sample, exposure), stage LANE.  Beyond `lane_max`
  * the electrons are numbered bin-major over the bins thrown that way and drawn
  * from the STAGE_THROW block streams exactly as wayne_oracle_psf_philox does.
@@ -212,6 +212,28 @@ static void so_throw_one(uint32_t g[4], float x, float y, float sig, int n, int3
   const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
   const float c = (-1.3862943611198906f * sig) * sig;
   const float Rs = sqrtf(c * log2f(so_u01(w[1])));
+  const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
+  const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
+  if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
+}
+
+/* An electron of a bin's own lane (stage LANE): ONE word of the bin's stream -- its high 23 bits the angle (as the
+ * mantissa of a float in [1, 2) revolutions), its low half h the radius, u = (h + 1/2) / 2^16; h = 0 (the far tail,
+ * where the cell is not small) is subdivided by 17 bits of the bin's side LCG: u = (h' + 1/2) / 2^33.  Same arithmetic
+ * as the device's k_lane (k_narrow.h), libm for the hardware's log2 / sqrt / sin / cos. */
+static void so_throw_word(uint32_t wd, uint32_t *refine, float x, float y, float sig, int n, int32_t *out) {
+  const uint32_t bits = 0x3f800000u | (wd >> 9);
+  float rev;
+  memcpy(&rev, &bits, 4);
+  const float ang = 6.283185307179586f * (rev - 1.0f);
+  const float c = (-1.3862943611198906f * sig) * sig;
+  const uint32_t h = wd & 0xFFFFu;
+  float r2 = fmaf(c, log2f((float)h + 0.5f), -16.0f * c);
+  if (h == 0u) {
+    *refine = *refine * 1664525u + 1013904223u;
+    r2 = fmaf(c, log2f((float)(*refine >> 15) + 0.5f), -33.0f * c);
+  }
+  const float Rs = sqrtf(r2);
   const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
   const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
   if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
@@ -419,7 +441,11 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
         const uint32_t ctr[4] = {(uint32_t)b, 0u, subsample, exposure};
         uint32_t gl[4];
         wayne_oracle_philox4x32(ctr, key_l, gl);
-        for (int64_t j = 0; j < thrown; ++j) so_throw_one(gl, x, y, (j < n_wide) ? sh : sl, n, out);
+        uint32_t refine = (gl[1] * 0x9E3779B9u) ^ gl[3], w2[2] = {0u, 0u};
+        for (int64_t j = 0; j < thrown; ++j) {
+          if ((j & 1) == 0) wayne_oracle_xo_next2(gl, w2);          /* a pair of the stream serves two electrons */
+          so_throw_word(w2[j & 1], &refine, x, y, (j < n_wide) ? sh : sl, n, out);
+        }
       } else {
         for (int64_t j = 0; j < thrown; ++j, ++e) {
           if ((e & 127u) == 0) {

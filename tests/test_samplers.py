@@ -290,6 +290,34 @@ def test_split_oracle_lane_bins_use_their_own_streams():
     np.testing.assert_array_equal(one, two + three)
 
 
+def test_lane_electron_is_the_gaussian_including_the_refined_tail():
+    # a lane-thrown electron takes ONE word: 16 bits of radius (midpoint rule in u) + the far cell h = 0 subdivided
+    # from the bin's side stream, 23 bits of angle.  1e7 electrons of one wide gaussian against the analytic pixel
+    # probabilities, and the tail beyond the un-refined reach sqrt(2 ln 2^17) = 4.85 sigma must be populated
+    W, N, sig = 2500, 96, 3.0
+    x0, y0 = 48.3, 47.7
+    counts = np.full(W, 4000, np.int32)
+    f = clib.psf_split_oracle(counts, np.full(W, x0), np.full(W, y0), np.ones(W), np.full(W, 1.0), np.full(W, sig), N,
+                              seed=77, exposure=3, subsample=9).reshape(N, N).astype(np.float64)
+    n = float(counts.sum())
+    assert f.sum() == n                                               # 16 sigma to the frame's edge: nothing leaves
+    edges = np.arange(N + 1)
+    px = np.diff(stats.norm.cdf((edges - x0) / sig))
+    py = np.diff(stats.norm.cdf((edges - y0) / sig))
+    expect = n * np.outer(py, px)
+    big = expect > 50
+    chi2 = ((f[big] - expect[big]) ** 2 / expect[big]).sum()
+    assert big.sum() > 400 and abs(chi2 - big.sum()) < 5 * np.sqrt(2.0 * big.sum()), (chi2, big.sum())
+    # radial tail: pixels wholly beyond r
+    yy, xx = np.mgrid[0:N, 0:N]
+    near = np.hypot(np.minimum(np.abs(xx - x0), np.abs(xx + 1 - x0)), np.minimum(np.abs(yy - y0), np.abs(yy + 1 - y0)))
+    for r_sig in (4.0, 4.85, 5.3):
+        sel = near > r_sig * sig
+        got, want = f[sel].sum(), expect[sel].sum()
+        assert abs(got - want) < 5 * np.sqrt(want) + 3, (r_sig, got, want)
+    assert f[near > 4.85 * sig].sum() >= 20
+
+
 @pytest.mark.parametrize("lam", [0.0, 0.05, 3.3, 16.4, 55.86, 146.0])
 def test_sky_alias_table_is_the_poisson_pmf(lam):
     # the table decoded analytically: P(k) = (sum over columns that keep k + columns that alias to k) / 256

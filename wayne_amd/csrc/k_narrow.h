@@ -360,21 +360,21 @@ constexpr int kLaneThreads = 512;
 // 63 lanes of the wave idle).  At a margin of 22 px (3.7 sigma_h) 3 % of the wave-iterations had such a lane and
 // the kernel ran at 220 cycles per iteration instead of ~135; 30 px is 5 sigma_h.
 //
-// Better still, the tile can hold EVERY electron: u01f() >= 2^-33, so an electron lands within
-// sigma sqrt(2 ln 2^33) = 6.764 sigma of its bin.  A workgroup whose tile -- the bins' bounding box +- (6.8
-// sigma_max + 1) px -- fits the LDS budget and lies inside the frame needs no bounds test at all: the deposit is
+// Better still, the tile can hold EVERY electron: the radius' uniform is >= 2^-34 (see the electron loop), so an
+// electron lands within sigma sqrt(2 ln 2^34) = 6.87 sigma of its bin.  A workgroup whose tile -- the bins' bounding
+// box +- (6.9 sigma_max + 1) px -- fits the LDS budget and lies inside the frame needs no bounds test at all: the deposit is
 // cvt, cvt, lshl_add, mad, ds_add (the tile origin folded into one scalar), four vector instructions fewer per
 // electron and no branch in the loop.  Other workgroups (frame edge, huge sigma, wild positions) keep the test and
 // the fixed margin.
 constexpr int kLaneMargin = 30;
-constexpr int kLaneReachMax = 48;       // largest margin of a test-free tile (sigma_h up to 6.9 px)
+constexpr int kLaneReachMax = 48;       // largest margin of a test-free tile (sigma_h up to 6.8 px)
 constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
 
 template <int FLUSH>
 __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   __shared__ int tile[kLaneTile];
   __shared__ int s_box[4];
-  __shared__ int s_reach;                 // max over the lanes of 6.8 sigma + 1 (float bits; 0x7F800000 if a lane is not sane)
+  __shared__ int s_reach;                 // max over the lanes of 6.9 sigma + 1 (float bits; 0x7F800000 if a lane is not sane)
   const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
   const int w = (int)a.lane_order[blockIdx.y] * kLaneThreads + tid;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     cl = (-1.3862943611198906f * sl) * sl;
     nw = min(max(a.nwide[kw], 0), n);
     const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
-    reach = (smax >= 0.f && smax < 1e6f) ? 6.8f * smax + 1.f : __int_as_float(0x7F800000);
+    reach = (smax >= 0.f && smax < 1e6f) ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
   }
   const bool in = n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
   if (n > 0 && !in) reach = __int_as_float(0x7F800000);
@@ -427,34 +427,53 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   for (int i = tid; i < tarea; i += kLaneThreads) tile[i] = 0;
   __syncthreads();
 
-  // Electron j of the bin takes pair j of the bin's stream; the first nw take sigma_h.  A wave whose bins all
-  // had their narrow electrons taken by k_narrow (nw = n everywhere: the usual case) runs with sigma as a loop
-  // constant: first the iterations EVERY lane has, with no per-lane test at all (neighbouring bins hold nearly the
-  // same number of electrons), then the tail, where the stream still advances in every lane and only the deposit
-  // is suppressed for the lanes that are done.  A wave with thin, unsplit bins selects sigma per electron.
+  // Electron j of the bin takes WORD j of the bin's stream (a pair of the stream serves two electrons); the first nw
+  // take sigma_h.  One 32-bit word per electron:
+  //   angle   = its high half / 2^16 revolutions (+ see `rev`).  65536 equally spaced directions: a pixel's probability is an
+  //             integral over the angle of a piecewise smooth periodic function, which an equispaced rule of that
+  //             many nodes gives to ~1e-8 -- the position itself moves by < 1e-4 R;
+  //   radius  = sigma sqrt(-2 ln u), u = (h + 1/2) / 2^16 from its low half h, the midpoint rule in u -- and where
+  //             the cell is not small against the scale on which the radius changes, h = 0 (R > 4.7 sigma, 1.5e-5 of
+  //             the electrons), the cell is subdivided by 17 bits h' of a side stream of the bin (a 32-bit LCG seeded from
+  //             the bin's Philox block, advanced only here): u = (h' + 1/2) 2^-33, so the radius reaches
+  //             sigma sqrt(2 ln 2^34) = 6.87 sigma (it was 6.76 with 32 bits per radius).
+  // Half the random words of a pair per electron: 9 of the 23 vector instructions of an electron were the pair.
+  // A wave whose bins all had their narrow electrons taken by k_narrow (nw = n everywhere: the usual case) runs with
+  // sigma as a loop constant: first the iterations EVERY lane has, with no per-lane test at all (neighbouring bins
+  // hold nearly the same number of electrons), then the tail, where the stream still advances in every lane and only
+  // the deposit is suppressed for the lanes that are done.  A wave with thin, unsplit bins selects sigma per electron.
   const int tw4 = tw * 4;
   const int origin = -(ty0 * tw4 + tx0 * 4);                 // tile[(yi - ty0) * tw + (xi - tx0)] as a byte offset from yi, xi
-  auto draw = [&](SeededStream& rng, float c, float px, float py, int& xi, int& yi) {
-    uint32_t wa, wb;
-    rng.next2(wa, wb);
-    const float rev = rev12(wa);
-    const float Rs = __builtin_amdgcn_sqrtf(c * __builtin_amdgcn_logf(u01f(wb)));
+  // (c = -2 ln2 sigma^2, c16 = -16 c: (R sigma)^2 = c log2 u = c (log2(h + 1/2) - 16) as one fma)
+  uint32_t refine = 0u;
+  auto draw = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py, int& xi, int& yi) {
+    // angle in [1, 2) revolutions = the word's high 23 bits as a mantissa (one v_alignbit_b32).  Its 7 lowest bits
+    // are the radius half-word's 7 highest: given the radius, the angle still runs over 65536 equally spaced
+    // directions -- offset by a fraction of their spacing that depends on the radius
+    const float rev = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wd, 9));
+    const uint32_t h = wd & 0xFFFFu;
+    float r2 = fmaf(c, __builtin_amdgcn_logf((float)h + 0.5f), c16);
+    if (__builtin_expect(h == 0u, 0)) {
+      refine = refine * 1664525u + 1013904223u;           // (the bin's side stream: leaves the main stream's state alone)
+      r2 = fmaf(c, __builtin_amdgcn_logf((float)(refine >> 15) + 0.5f), -33.f * c);
+    }
+    const float Rs = __builtin_amdgcn_sqrtf(r2);
     xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);      // C truncation toward zero (:91-92)
     yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
   };
   // (test-free tile) every live electron is inside the tile and on the frame
-  auto throw_sure = [&](SeededStream& rng, float c, bool live) {
+  auto throw_sure = [&](SeededStream& rng, uint32_t wd, float c, float c16, bool live) {
     int xi, yi;
-    draw(rng, c, x, y, xi, yi);
+    draw(rng, wd, c, c16, x, y, xi, yi);
     // byte address = yi * tw4 + (xi * 4 + origin): v_lshl_add_u32, v_mad_u32_u24 (the compiler's own choice is a multiply,
     // a shift and a three-operand add)
     int addr;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(tw4), "v"((xi << 2) + origin));
     if (live) atomicAdd((int*)((char*)tile + addr), 1);
   };
-  auto throw_one = [&](SeededStream& rng, float c, float px, float py) {
+  auto throw_one = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py) {
     int xi, yi;
-    draw(rng, c, px, py, xi, yi);
+    draw(rng, wd, c, c16, px, py, xi, yi);
     const int lx = xi - tx0, ly = yi - ty0;
     if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
       atomicAdd((int*)((char*)tile + (__umul24(ly, tw4) + (lx << 2))), 1);
@@ -470,24 +489,36 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   cmax = __builtin_amdgcn_readfirstlane(cmax);
   if (cmax > 0) {
     SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
+    refine = (rng.s1 * 0x9E3779B9u) ^ rng.s3;
     const bool one_sigma = !__any(n > nw);
+    const int cmin2 = cmin & ~1;                             // electrons 2i and 2i + 1 share pair i
+    const float ch16 = -16.f * ch, cl16 = -16.f * cl;
+    uint32_t wa, wb;
     if (sure) {
       if (one_sigma) {
-        for (int j = 0; j < cmin; ++j) throw_sure(rng, ch, true);
-        for (int j = cmin; j < cmax; ++j) throw_sure(rng, ch, j < n);
+        for (int j = 0; j < cmin2; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, true); throw_sure(rng, wb, ch, ch16, true); }
+        for (int j = cmin2; j < cmax; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, j < n); throw_sure(rng, wb, ch, ch16, j + 1 < n); }
       } else {
-        for (int j = 0; j < cmax; ++j) throw_sure(rng, (j < nw) ? ch : cl, j < n);
+        for (int j = 0; j < cmax; j += 2) {
+          rng.next2(wa, wb);
+          throw_sure(rng, wa, (j < nw) ? ch : cl, (j < nw) ? ch16 : cl16, j < n);
+          throw_sure(rng, wb, (j + 1 < nw) ? ch : cl, (j + 1 < nw) ? ch16 : cl16, j + 1 < n);
+        }
       }
     } else if (one_sigma) {
-      for (int j = 0; j < cmin; ++j) throw_one(rng, ch, x, y);
-      for (int j = cmin; j < cmax; ++j) {
-        const bool live = j < n;
-        throw_one(rng, ch, live ? x : -1e30f, live ? y : -1e30f);
+      for (int j = 0; j < cmin2; j += 2) { rng.next2(wa, wb); throw_one(rng, wa, ch, ch16, x, y); throw_one(rng, wb, ch, ch16, x, y); }
+      for (int j = cmin2; j < cmax; j += 2) {
+        const bool la = j < n, lb = j + 1 < n;
+        rng.next2(wa, wb);
+        throw_one(rng, wa, ch, ch16, la ? x : -1e30f, la ? y : -1e30f);
+        throw_one(rng, wb, ch, ch16, lb ? x : -1e30f, lb ? y : -1e30f);
       }
     } else {
-      for (int j = 0; j < cmax; ++j) {
-        const bool live = j < n;
-        throw_one(rng, (j < nw) ? ch : cl, live ? x : -1e30f, live ? y : -1e30f);
+      for (int j = 0; j < cmax; j += 2) {
+        const bool la = j < n, lb = j + 1 < n;
+        rng.next2(wa, wb);
+        throw_one(rng, wa, (j < nw) ? ch : cl, (j < nw) ? ch16 : cl16, la ? x : -1e30f, la ? y : -1e30f);
+        throw_one(rng, wb, (j + 1 < nw) ? ch : cl, (j + 1 < nw) ? ch16 : cl16, lb ? x : -1e30f, lb ? y : -1e30f);
       }
     }
   }

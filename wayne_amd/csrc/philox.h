@@ -36,9 +36,10 @@ enum Stage : uint32_t {
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
   STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's
                       //   narrow-PSF electrons over pixels (k_narrow, rng_mode WAYNE_RNG_SPLIT)
-  STAGE_LANE = 10,    // seeded stream (bin w, 0, sub-sample k, exposure): pair j -> electron j of the electrons a bin's own
-                      //   lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT): the wide-PSF electrons of a bin whose
-                      //   narrow ones went to the multinomial, or every electron of a thinly populated bin (wide ones first)
+  STAGE_LANE = 10,    // seeded stream (bin w, 0, sub-sample k, exposure): WORD j (pair j / 2) -> electron j of the electrons a
+                      //   bin's own lane throws one by one (k_lane, rng_mode WAYNE_RNG_SPLIT): the wide-PSF electrons of a bin
+                      //   whose narrow ones went to the multinomial, or every electron of a thinly populated bin (wide ones
+                      //   first); an electron whose radius half-word is 0 refines it from a side LCG seeded by the same block (k_lane)
   STAGE_POOL = 11,    // seeded stream (bin group w >> 4, column j of the group's window, sub-sample k, exposure): the row chain
                       //   of the electrons the 16 bins of a group put into that column (k_narrow, pooled rows)
 };

@@ -385,10 +385,10 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
 }
 
 // Where can the accumulators of read interval r be non-zero after the thrower?  An electron lands within
-// sigma sqrt(2 ln 2^33) = 6.764 sigma of its bin in every rng mode (k_lane: "a tile that holds every electron"; the
-// replay thrower's rand_r / RAND_MAX reaches 6.56 sigma; k_narrow's window is +-6 px), and the bins of a sub-sample lie
+// sigma sqrt(2 ln 2^34) = 6.87 sigma of its bin in every rng mode (k_lane: "a tile that holds every electron"; k_throw's
+// per-electron mode reaches 6.76 sigma, the replay thrower's rand_r / RAND_MAX 6.56 sigma; k_narrow's window is +-6 px), and the bins of a sub-sample lie
 // on the straight trace between its first and its last wavelength.  So per read: the union over its sub-samples of
-// the trace's end points, +- (6.8 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
+// the trace's end points, +- (6.9 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
 // everything) when the numbers are not ones a bound can be built on.
 bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
   const int W = d->n_wl, K = d->n_samples, R = d->n_reads, S = c->S;
@@ -400,7 +400,7 @@ bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*b
     if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3)) return false;
     smax = std::max(smax, std::max(sl, sh));
   }
-  const double reach = 6.8 * smax + 2.;
+  const double reach = 6.9 * smax + 2.;
   if (!(reach < 400.)) return false;
   for (int r = 0; r < 16; ++r) { box[r][0] = box[r][2] = 0x3FFFFFFF; box[r][1] = box[r][3] = -0x3FFFFFFF; }
   for (int k = 0; k < K; ++k) {
