@@ -53,3 +53,29 @@ def test_a_bin_beyond_the_lanes_reach_reruns_with_k_throw(monkeypatch):
     np.testing.assert_array_equal(via_record, want)
     np.testing.assert_array_equal(via_download, want)
     np.testing.assert_array_equal(via_wait, want)
+
+
+@pytest.mark.parametrize("name", ["small256", "tiny"])
+def test_frames_do_not_depend_on_batches_or_the_thin_flush(name, monkeypatch):
+    # k_prep_sub / k_lane / k_narrow take `kb` consecutive sub-samples per workgroup (chosen by the host from K), and
+    # k_lane flushes from a first-touch list when it expects few electrons: launch geometry only -- same streams, same
+    # integer sums -- so the reads must not change by a bit
+    v = helpers.make_visit(name)
+    kw = v.frame_kwargs(0)
+    pg = helpers.product_generator(v, 0)
+    want = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    for batch, thin in (("1", "0"), ("1", "1"), ("4", "1"), ("4", "0"), ("32", "1")):
+        monkeypatch.setenv("WAYNE_BATCH", batch)
+        monkeypatch.setenv("WAYNE_THIN", thin)
+        got = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+        np.testing.assert_array_equal(got, want, err_msg="WAYNE_BATCH=%s WAYNE_THIN=%s" % (batch, thin))
+    # the per-electron and replay throwers go through the batched k_prep_sub too
+    from wayne_amd import _lib
+    monkeypatch.delenv("WAYNE_BATCH")
+    monkeypatch.delenv("WAYNE_THIN")
+    for mode in (_lib.RNG_PHILOX, _lib.RNG_REPLAY):
+        a = np.stack([r[0] for r in pg.scanning_frame(rng_mode=mode, **kw).reads])
+        monkeypatch.setenv("WAYNE_BATCH", "5")
+        b = np.stack([r[0] for r in pg.scanning_frame(rng_mode=mode, **kw).reads])
+        monkeypatch.delenv("WAYNE_BATCH")
+        np.testing.assert_array_equal(a, b)

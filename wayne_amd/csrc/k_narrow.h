@@ -102,7 +102,10 @@ __device__ __forceinline__ int wave_maxi(int v) {
              max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int FLUSH, bool FAST>
+// BATCH: the workgroup takes a.kb consecutive sub-samples (k_lane, "BATCHES"); false: one -- the loop below then has
+// one trip and the compiler keeps nothing alive around it (the batched form of this kernel needs 99 registers, the
+// single form 62)
+template <int FLUSH, bool FAST, bool BATCH>
 __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   __shared__ int tile[kNarrowTile];
@@ -114,9 +117,10 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   __shared__ int s_box[4];
   __shared__ float s_fc[10];                            // stirling_tail(0..9), indexed per lane in the rejection sampler
   if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
-  const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
   const int w = (int)a.chunk_order[blockIdx.y] * kNarrowThreads + tid;
+  // the workgroup's batch of consecutive sub-samples (k_lane, "BATCHES"; sub-sample fastest: see ThrowArgs::chunk_order)
+  auto sub_sample = [&](const int k) {
   const SubInfo si = a.sub[k];
   const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // narrow electrons of the bin's multinomial
   if (!__syncthreads_or(n0 > 0)) return;
@@ -341,6 +345,12 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, n);
     }
   }
+  };   // sub_sample
+  if (BATCH) {
+    for (int k = (int)blockIdx.x * a.kb, k_end = min(k + a.kb, a.K); k < k_end; ++k) sub_sample(k);
+  } else {
+    sub_sample((int)blockIdx.x);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -370,41 +380,64 @@ constexpr int kLaneMargin = 30;
 constexpr int kLaneReachMax = 48;       // largest margin of a test-free tile (sigma_h up to 6.8 px)
 constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
 
-template <int FLUSH>
+// BATCHES.  A finely sampled scan (the reference's default 10 ms sampling: K = 2233 sub-samples of ~2.5 electrons
+// per bin) would launch K x chunks workgroups of ~1300 electrons each and spend its time in their prologues and
+// in flushes of nearly empty tiles.  A workgroup therefore takes `kb` consecutive sub-samples of its chunk (the
+// host's choice, 1 on a coarsely sampled exposure): one tile geometry for the batch (the union of its sub-samples'
+// bins), the tile flushed -- with that sub-sample's flat -- and left clean after every sub-sample.  THIN (the host
+// expects few electrons per workgroup and sub-sample): an electron that is the first on its tile cell (the LDS
+// atomic returns 0) puts the cell on a list, and the flush then visits the list's ~1000 cells instead of scanning
+// the tile's 9216 with a tenth of the lanes finding anything.  Same electrons, same streams, same sums (integer
+// accumulation commutes): frames do not depend on kb or THIN.
+constexpr int kLaneListCap = 4096;      // cells on a THIN flush list (beyond it the flush falls back to the scan)
+
+template <int FLUSH, bool THIN, bool BATCH>
 __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   __shared__ int tile[kLaneTile];
+  __shared__ unsigned short s_list[THIN ? kLaneListCap : 1];
+  __shared__ int s_cnt;
   __shared__ int s_box[4];
   __shared__ int s_reach;                 // max over the lanes of 6.9 sigma + 1 (float bits; 0x7F800000 if a lane is not sane)
-  const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
+  // (sub-sample fastest: see ThrowArgs::chunk_order; BATCH = false: one sub-sample, as k_narrow)
+  const int k0 = BATCH ? (int)blockIdx.x * a.kb : (int)blockIdx.x, k1 = BATCH ? min(k0 + a.kb, a.K) : k0 + 1;
   const int tid = threadIdx.x;
   const int w = (int)a.lane_order[blockIdx.y] * kLaneThreads + tid;
-  const size_t kw = (size_t)k * a.W + (w < a.W ? w : 0);
-  const int n = (w < a.W) ? a.nlane[kw] : 0;
-  if (!__syncthreads_or(n > 0)) return;
-  const SubInfo si = a.sub[k];
-
-  float x = -1e30f, y = -1e30f, ch = 0.f, cl = 0.f, reach = 0.f;
-  int nw = 0;
-  if (n > 0) {
-    x = (float)a.xpos[kw];
-    y = (float)a.ypos[kw];
-    const float sh = (float)a.sigh[w], sl = (float)a.sigl[w];
+  const bool inw = w < a.W;
+  float ch = 0.f, cl = 0.f, sh = 0.f, sl = 0.f;
+  if (inw) {
+    sh = (float)a.sigh[w]; sl = (float)a.sigl[w];
     ch = (-1.3862943611198906f * sh) * sh;
     cl = (-1.3862943611198906f * sl) * sl;
-    nw = min(max(a.nwide[kw], 0), n);
-    const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
-    reach = (smax >= 0.f && smax < 1e6f) ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
   }
-  const bool in = n > 0 && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
-  if (n > 0 && !in) reach = __int_as_float(0x7F800000);
+  // the batch's populated bins: bounding box and reach
+  int x_lo = 0x7FFFFFFF, x_hi = -0x7FFFFFFF, y_lo = 0x7FFFFFFF, y_hi = -0x7FFFFFFF;
+  float reach = 0.f;
+  bool any = false;
+  for (int k = k0; k < k1; ++k) {
+    const size_t kw = (size_t)k * a.W + (inw ? w : 0);
+    const int n = inw ? a.nlane[kw] : 0;
+    if (n > 0) {
+      any = true;
+      const float x = (float)a.xpos[kw], y = (float)a.ypos[kw];
+      const int nw = min(max(a.nwide[kw], 0), n);
+      const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
+      float r = (smax >= 0.f && smax < 1e6f) ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
+      if (fabsf(x) < 1e6f && fabsf(y) < 1e6f) {
+        const int ic = (int)floorf(x), jc = (int)floorf(y);
+        x_lo = min(x_lo, ic); x_hi = max(x_hi, ic); y_lo = min(y_lo, jc); y_hi = max(y_hi, jc);
+      } else {
+        r = __int_as_float(0x7F800000);
+      }
+      reach = fmaxf(reach, r);
+    }
+  }
+  if (!__syncthreads_or(any)) return;
   // workgroup tile: bounding box of its bins' positions +- margin, clipped to [1, N) and to the LDS budget
-  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; s_reach = 0; }
+  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; s_reach = 0; s_cnt = 0; }
   __syncthreads();
-  const int ic = (int)floorf(x), jc = (int)floorf(y);
   {
     // (reduced over the wave first: one atomic per wave, see k_narrow)
-    const int x_lo = wave_mini(in ? ic : 0x7FFFFFFF), x_hi = wave_maxi(in ? ic : -0x7FFFFFFF);
-    const int y_lo = wave_mini(in ? jc : 0x7FFFFFFF), y_hi = wave_maxi(in ? jc : -0x7FFFFFFF);
+    x_lo = wave_mini(x_lo); x_hi = wave_maxi(x_hi); y_lo = wave_mini(y_lo); y_hi = wave_maxi(y_hi);
     const int r_hi = wave_maxi(__float_as_int(reach));       // (non-negative floats order as their bit patterns)
     if ((tid & 63) == 0) {
       atomicMin(&s_box[0], x_lo); atomicMax(&s_box[1], x_hi);
@@ -425,7 +458,35 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   if ((long long)tw * th > kLaneTile) { tw = 0; th = 0; }
   const int tarea = tw * th;
   for (int i = tid; i < tarea; i += kLaneThreads) tile[i] = 0;
-  __syncthreads();
+
+  // the tile cell at byte offset `addr` gets an electron; THIN: the first one there puts the cell on the flush list
+  auto tile_add = [&](int addr) {
+    if (THIN) {
+      if (atomicAdd((int*)((char*)tile + addr), 1) == 0) {
+        const unsigned long long m = __ballot(1);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        int base = 0;
+        if (before == 0) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + before < kLaneListCap) s_list[base + before] = (unsigned short)(addr >> 2);
+      }
+    } else {
+      atomicAdd((int*)((char*)tile + addr), 1);
+    }
+  };
+
+  for (int k = k0; k < k1; ++k) {
+  const size_t kw = (size_t)k * a.W + (inw ? w : 0);
+  const int n = inw ? a.nlane[kw] : 0;
+  if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and s_cnt is 0 again)
+  const SubInfo si = a.sub[k];
+  float x = -1e30f, y = -1e30f;
+  int nw = 0;
+  if (n > 0) {
+    x = (float)a.xpos[kw];
+    y = (float)a.ypos[kw];
+    nw = min(max(a.nwide[kw], 0), n);
+  }
 
   // Electron j of the bin takes WORD j of the bin's stream (a pair of the stream serves two electrons); the first nw
   // take sigma_h.  One 32-bit word per electron:
@@ -469,14 +530,14 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     // a shift and a three-operand add)
     int addr;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(tw4), "v"((xi << 2) + origin));
-    if (live) atomicAdd((int*)((char*)tile + addr), 1);
+    if (live) tile_add(addr);
   };
   auto throw_one = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py) {
     int xi, yi;
     draw(rng, wd, c, c16, px, py, xi, yi);
     const int lx = xi - tx0, ly = yi - ty0;
     if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
-      atomicAdd((int*)((char*)tile + (__umul24(ly, tw4) + (lx << 2))), 1);
+      tile_add(__umul24(ly, tw4) + (lx << 2));
     else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)               // (:93)
       deposit_global<FLUSH>(a, si, xi, yi, 1);
   };
@@ -523,13 +584,28 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     }
   }
   __syncthreads();
-  for (int i = tid; i < tarea; i += kLaneThreads) {
-    const int m = tile[i];
-    if (m > 0) {
+  // flush with THIS sub-sample's flat, leaving the tile clean
+  const int listed = THIN ? s_cnt : 0;
+  if (THIN && listed <= kLaneListCap) {
+    for (int t = tid; t < listed; t += kLaneThreads) {
+      const int i = (int)s_list[t];
+      const int m = tile[i];
+      tile[i] = 0;
       const int ly = i / tw, lx = i - ly * tw;
       deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, m);
     }
+  } else {
+    for (int i = tid; i < tarea; i += kLaneThreads) {
+      const int m = tile[i];
+      if (m > 0) {
+        tile[i] = 0;
+        const int ly = i / tw, lx = i - ly * tw;
+        deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, m);
+      }
+    }
   }
+  if (THIN && tid == 0) s_cnt = 0;
+  }   // sub-samples of the batch
 }
 
 }  // namespace wayne

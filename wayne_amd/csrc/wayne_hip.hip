@@ -69,6 +69,8 @@ struct Slot {
   DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   DevBuf seg;             // cosmic-ray segments (CosmicArgs::seg): zeroed when allocated, k_ramp clears what it reads
+  int kb = 1;             // sub-samples a workgroup of k_prep_sub / k_lane / k_narrow takes (k_lane, "BATCHES")
+  bool thin = false;      // few electrons per (workgroup, sub-sample): k_lane flushes from its first-touch list
   bool use_box = false;   // acc_box is valid: k_ramp loads the accumulators of a read only inside it (and where `seg` says)
   int acc_box[16][4] = {{0}};
   DevBuf in_dev;          // device mirror of the staging arena: the descriptor's arrays arrive in ONE copy
@@ -89,6 +91,7 @@ struct Slot {
   unsigned char sky_tab0[16] = {0};
   std::vector<double> read_dt_host;
   double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
+  double max_chunk_electrons = 0.;   // host estimate: electrons of the fullest k_lane chunk in the longest sub-sample
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   unsigned char chunk_order[kMaxChunks] = {0};   // chunks of kNarrowThreads bins, most electrons first (ThrowArgs::chunk_order)
   unsigned char lane_order[kMaxChunks] = {0};    // chunks of kLaneThreads bins, most electrons first
@@ -334,7 +337,7 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
 // (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
 // the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
 double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
-                       unsigned char* lane_order) {
+                       unsigned char* lane_order, double* max_chunk_electrons) {
   const int W = d->n_wl, K = d->n_samples;
   const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
   const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
@@ -377,6 +380,8 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
   for (int i = 0; i < n_chunks; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return chunk_e[a_] > chunk_e[b_]; });
   for (int i = 0; i < n_chunks && i < kMaxChunks; ++i) chunk_order[i] = (unsigned char)order[i];
+  *max_chunk_electrons = 0.;
+  for (double e : lane_e) *max_chunk_electrons = std::max(*max_chunk_electrons, e);
   order.resize((size_t)n_lane_chunks);
   for (int i = 0; i < n_lane_chunks; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return lane_e[a_] > lane_e[b_]; });
@@ -543,9 +548,14 @@ static_assert(kSplitMin == kSplitMinHost, "split threshold");
 
 template <int FLUSH>
 int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
-  const dim3 grid((unsigned)a.K, (unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads));
-  if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
-  else hipLaunchKernelGGL((k_narrow<FLUSH, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  const dim3 grid((unsigned)((a.K + a.kb - 1) / a.kb), (unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads));
+  if (a.kb > 1) {
+    if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_narrow<FLUSH, true, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  } else {
+    if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_narrow<FLUSH, true, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  }
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
 }
@@ -563,9 +573,15 @@ void (*pick_ramp(bool f64, bool exact, int sky, bool noise))(RampArgs) {
 }
 
 template <int FLUSH>
-int launch_lane(wayne_ctx* c, const ThrowArgs& a) {
-  const dim3 grid((unsigned)a.K, (unsigned)((a.W + kLaneThreads - 1) / kLaneThreads));
-  hipLaunchKernelGGL((k_lane<FLUSH>), grid, dim3(kLaneThreads), 0, c->stream, a);
+int launch_lane(wayne_ctx* c, const ThrowArgs& a, bool thin) {
+  const dim3 grid((unsigned)((a.K + a.kb - 1) / a.kb), (unsigned)((a.W + kLaneThreads - 1) / kLaneThreads));
+  if (a.kb > 1) {
+    if (thin) hipLaunchKernelGGL((k_lane<FLUSH, true, true>), grid, dim3(kLaneThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_lane<FLUSH, false, true>), grid, dim3(kLaneThreads), 0, c->stream, a);
+  } else {
+    if (thin) hipLaunchKernelGGL((k_lane<FLUSH, true, false>), grid, dim3(kLaneThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_lane<FLUSH, false, false>), grid, dim3(kLaneThreads), 0, c->stream, a);
+  }
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
 }
@@ -780,7 +796,7 @@ int wayne_psf_apply_ex(wayne_ctx* c, const int32_t* counts, int size, const doub
     if ((rc = upload(c, c->pa_sub, &si, 1))) return rc;
 
     ThrowArgs a{};
-    a.W = size; a.K = 1; a.N = N; a.S = N + 2 * kBorder;
+    a.W = size; a.K = 1; a.N = N; a.S = N + 2 * kBorder; a.kb = 1;
     // enough workgroups to fill the chip when the call is big, one when small
     a.splits = (int)std::min<long long>(512, std::max<long long>(1, total / (64LL * kThrowThreads)));
     a.min_wgs = a.splits;   // one call, one sub-sample: share the electrons among all launched workgroups
@@ -810,7 +826,7 @@ int wayne_psf_apply_ex(wayne_ctx* c, const int32_t* counts, int size, const doub
     }
     if (any_lane) {
       ProfScope ps(c, PK_LANE);
-      if ((rc = launch_lane<0>(c, a))) return rc;
+      if ((rc = launch_lane<0>(c, a, false))) return rc;
     }
     if (any_split) {
       ProfScope ps(c, PK_NARROW);
@@ -1016,7 +1032,19 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
-  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order);
+  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons);
+  {
+    // Batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled scan
+    // (K in the thousands) otherwise launches tens of thousands of workgroups of a few hundred electrons each.
+    const int n_chunks_l = (W + kLaneThreads - 1) / kLaneThreads;
+    int kb = (int)(((long long)K * n_chunks_l) / 2048);
+    kb = std::min(std::max(kb, 1), kPrepBatchMax);
+    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), kPrepBatchMax);
+    s.kb = kb;
+    // thin: the expected electrons of the fullest chunk in the longest sub-sample fit the flush list with room to spare
+    s.thin = s.max_chunk_electrons <= 0.4 * kLaneListCap;
+    if (const char* e = std::getenv("WAYNE_THIN")) s.thin = std::atoi(e) != 0;
+  }
   s.use_box = accumulator_boxes(c, d, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
   {
     const size_t seg_bytes = ((SS + 63) / 64) * sizeof(uint32_t);
@@ -1133,7 +1161,9 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
     ca.seg = s.seg.as<uint32_t>();
     ProfScope ps(c, PK_PREP_SUB);
-    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
+    a.kb = s.kb;
+    if (s.kb > 1) hipLaunchKernelGGL(k_prep_sub<true>, dim3((K + s.kb - 1) / s.kb, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
+    else hipLaunchKernelGGL(k_prep_sub<false>, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
     HIP_TRY(c, hipGetLastError());
     if (!a.fix_inline) {
       hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
@@ -1143,6 +1173,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   {
     ThrowArgs a{};
     a.W = W; a.K = K; a.N = N; a.S = S;
+    a.kb = s.kb;
     // grid: one unit (128 electrons; 1 in replay mode) per lane of the workgroups of a sub-sample, from
     // the host's estimate of the electrons + 8 %, but at least ~4 workgroups per CU over the launch
     // (WAYNE_THROW_WGS / desc.thrower_splits override); k_throw shares out what it actually finds
@@ -1216,7 +1247,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       if (rc) return rc;
       if (d.rng_mode == WAYNE_RNG_SPLIT) {
         ProfScope ps(c, PK_LANE);
-        if ((rc = launch_lane<1>(c, a))) return rc;
+        if ((rc = launch_lane<1>(c, a, s.thin))) return rc;
       }
       if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join[si_], 0));
     }
