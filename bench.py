@@ -37,7 +37,6 @@ import argparse
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -170,17 +169,9 @@ def cpu_baseline(visit, budget_s=20.0):
 def launch_ranks(n, argv):
     """Start n fresh rank processes (nothing in THIS process has touched torch or HIP), wait for them, relay
     rank 0's JSON line.  Returns the exit code."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), WAYNE_BENCH_CHILD="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    from wayne_amd import launch
+    codes, out0 = launch.launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + argv,
+                                      extra_env={"WAYNE_BENCH_CHILD": "1"}, capture_rank0=True)
     if any(codes):
         sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
         sys.stdout.write(out0 or "")
@@ -198,6 +189,26 @@ def launch_ranks(n, argv):
     return 0
 
 
+def dry_run(rank, world):
+    """`--dry-run`: the rendezvous of the N-rank path without any GPU work (gloo barrier, max-reduce, gather), so
+    that the launcher and the ranks' meeting can be rehearsed at any N on a CPU.  Prints a line that cannot be
+    mistaken for a measurement."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    got = [None] * world
+    dist.all_gather_object(got, rank)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_reported": len(set(got)), "max_rank": t.item(),
+                          "value": None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +223,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="HIP streams in the timed region (1: kernels of different exposures never co-run, so "
                          "per-kernel event times are clean; the 2-stream rate is reported separately as two_streams)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extra-pass", action="store_true",
                     help="skip the passes after the timed region (use under rocprofv3 so that the kernel statistics "
                          "cover the timed region only)")
@@ -227,6 +239,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     n_gpus = world
+    if args.dry_run:
+        if world < 2:
+            raise SystemExit("--dry-run rehearses the multi-rank rendezvous: use --gpus N with N > 1")
+        return dry_run(rank, world)
 
     import torch
     if not torch.cuda.is_available():
@@ -239,6 +255,8 @@ def main():
         raise SystemExit("rank %d: no GPU %d on this node (set WAYNE_BENCH_SHARE_GPU=1 to share device 0)" % (
             rank, device))
     torch.cuda.set_device(device)
+    from wayne_amd import launch
+    launch.pin_to_gpu_numa(device)           # the rank's host threads on its GPU's NUMA node (best effort)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -54,6 +54,18 @@ def test_launcher_refuses_a_rank_count_mismatch():
     assert out.returncode != 0 and "WORLD_SIZE (2) != --gpus (4)" in (out.stderr + out.stdout)
 
 
+def test_launcher_rendezvous_at_eight_ranks():
+    # CPU: `bench.py --gpus 8 --dry-run` -- the self-launching path at the rank count of the driver's scaling run: the
+    # parent starts 8 fresh rank processes, they meet over gloo (barrier, max-reduce, gather) and rank 0's line is
+    # relayed; no GPU work is rehearsed by this (a one-GPU box admits at most 6 processes on its card)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip())
+    assert d == {"dry_run": True, "n_gpus": 8, "ranks_reported": 8, "max_rank": 7.0, "value": None}
+
+
 def test_launcher_starts_n_ranks_and_fails_loudly_without_gpus():
     # CPU: `--gpus 2` without WORLD_SIZE starts two rank processes; without a GPU both refuse, and the parent
     # reports the failure instead of printing a one-GPU line

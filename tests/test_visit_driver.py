@@ -10,6 +10,7 @@ import yaml
 from wayne_amd import detector, fitsio, observation, run_visit, tools, visit_planner
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MINI = os.path.join(HERE, "fixtures", "mini_visit")
 
 
@@ -260,6 +261,63 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
     np.testing.assert_array_equal(np.asarray(frame.reads[3][0], dtype=np.float64), sci[0].data)
     di = fitsio.read(os.path.join(obs.outdir, "0000_flt.fits"))
     assert abs(di[1].data.max() - 10000.0) < 700                           # the 2-D gaussian direct image
+
+
+@pytest.mark.gpu
+def test_cli_starts_its_own_ranks(tmp_path):
+    # `python -m wayne_amd.run_visit --gpus 2`: the parent starts two rank processes before anything touches a GPU
+    # (here both on device 0: WAYNE_SHARE_GPU=1); each writes its round-robin share; every file equals the one a
+    # single process writes
+    import shutil
+    import subprocess
+    import sys
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    shutil.copytree(MINI, one)
+    shutil.copytree(MINI, two)
+    obs = run_visit.run(["-p", os.path.join(one, "params.yml"), "--max-exposures", "4"])
+    env = dict(os.environ, WAYNE_SHARE_GPU="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(two, "params.yml"),
+                          "--max-exposures", "4", "--gpus", "2"], capture_output=True, text=True, timeout=900, env=env,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "2 ranks done" in out.stdout
+    outdir2 = os.path.join(two, os.path.relpath(obs.outdir, one))
+    names = sorted(f for f in os.listdir(obs.outdir) if f.endswith("_raw.fits"))
+    assert names == ["%04d_raw.fits" % i for i in range(1, 5)]
+    for n in names:
+        a, b = fitsio.read(os.path.join(obs.outdir, n)), fitsio.read(os.path.join(outdir2, n))
+        for ha, hb in zip(a, b):
+            if ha.data is not None:
+                np.testing.assert_array_equal(ha.data, hb.data)
+
+
+def test_cli_launcher_fails_loudly_without_gpus(tmp_path):
+    # CPU: --gpus 2 starts two ranks; without a GPU both refuse (no CPU fallback) and the parent says so
+    import shutil
+    import subprocess
+    import sys
+    from wayne_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    work = str(tmp_path / "v")
+    shutil.copytree(MINI, work)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(work, "params.yml"),
+                          "--max-exposures", "2", "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "rank exit codes" in (out.stderr + out.stdout)
+
+
+def test_gpu_numa_pinning_is_best_effort():
+    from wayne_amd import launch
+    assert launch._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    # no such device / no sysfs entry: nothing happens, nothing raises
+    assert launch.gpu_local_cpus(10 ** 6) is None
+    before = os.sched_getaffinity(0)
+    launch.pin_to_gpu_numa(10 ** 6)
+    assert os.sched_getaffinity(0) == before
 
 
 @pytest.mark.gpu

@@ -1,0 +1,96 @@
+"""One process per GPU without an external launcher, and CPU affinity of a rank.
+
+`launch_ranks` is what `bench.py --gpus N` and `python -m wayne_amd.run_visit --gpus N` do when they are not
+already a rank (no WORLD_SIZE in the environment): the parent -- which has not touched HIP or torch -- starts N
+fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set and waits for them.
+(A process that has initialised the GPU must never exec another program; starting children from a clean parent
+is the safe form.)  Exposures are independent, so the ranks share nothing but the output directory.
+
+`pin_to_gpu_numa` binds the calling process to the CPUs of the NUMA node its GPU hangs off (sysfs, best effort):
+the host side of a rank is descriptor building and copies out of pinned memory, both of which want local memory.
+"""
+import glob
+import os
+import re
+import socket
+import subprocess
+import sys
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world, port, extra=None):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    env.update(extra or {})
+    return env
+
+
+def launch_ranks(n, cmd, extra_env=None, capture_rank0=False):
+    """Start `cmd` (a list, e.g. [sys.executable, script, args...]) n times, one per rank; wait for all.
+    Returns (exit codes, rank 0's stdout or None)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        out = subprocess.PIPE if (capture_rank0 and r == 0) else (subprocess.DEVNULL if capture_rank0 else None)
+        procs.append(subprocess.Popen(cmd, env=rank_env(r, n, port, extra_env), stdout=out, text=True))
+    out0 = None
+    if capture_rank0:
+        out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    return codes, out0
+
+
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(device):
+    """CPUs local to HIP device `device` from the KFD topology (GPU nodes in node order, the order HIP enumerates
+    them in when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES do not re-map), or None when sysfs does not say."""
+    if any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return None                       # the ordinal no longer names a KFD node: do not guess
+    gpus = []
+    for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(os.path.basename(p))):
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(node, "properties")) if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(int(props.get("drm_render_minor", "-1")))
+    if device < 0 or device >= len(gpus) or gpus[device] < 0:
+        return None
+    try:
+        text = open("/sys/class/drm/renderD%d/device/local_cpulist" % gpus[device]).read()
+    except OSError:
+        return None
+    cpus = _cpulist(text)
+    return cpus or None
+
+
+def pin_to_gpu_numa(device):
+    """sched_setaffinity to the GPU's local CPUs (intersected with what the process may use).  Returns the CPU set
+    applied, or None when nothing was done."""
+    if os.environ.get("WAYNE_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = gpu_local_cpus(device)
+    if not cpus:
+        return None
+    allowed = os.sched_getaffinity(0) & cpus
+    if not allowed or allowed == os.sched_getaffinity(0):
+        return None
+    try:
+        os.sched_setaffinity(0, allowed)
+    except OSError:
+        return None
+    return allowed

@@ -1,6 +1,6 @@
 """Command line: generate a visit from a YAML parameter file.
 
-    python -m wayne_amd.run_visit -p <parameter_file> [--calibration DIR] [--device N] [--max-exposures M]
+    python -m wayne_amd.run_visit -p <parameter_file> [--calibration DIR] [--device N] [--max-exposures M] [--gpus G]
 
 Accepts the reference's parameter files (wayne/run_visit.py:1-9, example
 examples/hd209458b_12181_simulation_parameters.yml): sections `general`
@@ -13,18 +13,21 @@ examples/hd209458b_12181_simulation_parameters.yml): sections `general`
     the Open Exoplanet Catalogue lookup (oec.py) is not provided;
   * a missing stellar spectrum file falls back to a black body of
     `target: star_temperature` (default 6100 K);
-  * with WORLD_SIZE / RANK set (one process per GPU) each rank generates its
-    round-robin share of the exposures.
+  * `--gpus G`: the process starts G rank processes itself (one per GPU of this node, before anything touches a
+    GPU) and waits for them; under an external launcher (WORLD_SIZE / RANK set, one process per GPU) it is one
+    rank.  Each rank generates its round-robin share of the exposures (observation.py:403-405 is the axis) on the
+    CPUs of its GPU's NUMA node.
 """
 import argparse
 import os
 import shutil
+import sys
 
 import numpy as np
 import yaml
 
 from . import calibration as _cal
-from . import detector, grism, observation, tools
+from . import detector, grism, launch, observation, tools
 from .trend_generators import scan_speed_varations
 
 
@@ -133,7 +136,25 @@ def run(argv=None):
     ap.add_argument("--calibration", default=None, help="directory holding the WFC3 calibration FITS files")
     ap.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     ap.add_argument("--max-exposures", type=int, default=None, help="only the first M exposures")
+    ap.add_argument("--gpus", type=int, default=1, help="start this many rank processes, one per GPU of this node")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the launcher: nothing in this process has touched a GPU; the children are ranks of a fresh interpreter each
+        child = [a for a in (sys.argv[1:] if argv is None else list(argv))]
+        cmd = [sys.executable, "-m", "wayne_amd.run_visit"] + child
+        extra = {"PYTHONPATH": os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                               [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])}
+        codes, _ = launch.launch_ranks(args.gpus, cmd, extra_env=extra)
+        if any(codes):
+            raise SystemExit("run_visit: rank exit codes %s" % codes)
+        print("run_visit: %d ranks done" % args.gpus)
+        return None
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and args.gpus not in (1, world_env):
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world_env, args.gpus))
+    if os.environ.get("WAYNE_SHARE_GPU") == "1":       # rehearsal on a one-GPU box: every rank on device 0
+        args.device = 0
+    launch.pin_to_gpu_numa(args.device)
     with open(args.parameter_file) as f:
         cfg = yaml.safe_load(f)
     base_dir = os.path.dirname(os.path.abspath(args.parameter_file))
