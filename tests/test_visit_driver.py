@@ -310,6 +310,22 @@ def test_cli_launcher_fails_loudly_without_gpus(tmp_path):
     assert out.returncode != 0 and "rank exit codes" in (out.stderr + out.stdout)
 
 
+def test_cosmic_ray_generators_keep_the_reference_api():
+    # wayne.trend_generators.cosmic_rays' public classes (cosmic_rays.py:10-139); same draws as the oracle's
+    # restatement of MinMaxPossionCosmicGenerator.cosmic_frame over the same legacy stream
+    from oracle import wayne_oracle as wo
+    from wayne_amd.trend_generators.cosmic_rays import BaseCosmicGenerator, MinMaxPossionCosmicGenerator
+    g = MinMaxPossionCosmicGenerator(11., rng=np.random.RandomState(5))
+    frame = g.cosmic_frame(100.0, 256)
+    want = wo.LegacyDraws(5).cosmic_frame(11., 100.0, 256, 0)
+    np.testing.assert_array_equal(frame, want)
+    hits = frame[frame > 0]
+    assert frame.shape == (256, 256) and 30 < hits.size < 110 and hits.min() >= 10000
+    assert g._rate_full_frame_to_size(11., 256) == pytest.approx(11. / 16) and g._rate_full_frame_to_size(11., (512, 1024)) == 5.5
+    b = BaseCosmicGenerator(rng=np.random.RandomState(1)).cosmic_frame(2.0, (32, 64))
+    assert b.shape == (32, 64) and b.sum() == 22 * 25000
+
+
 def test_gpu_numa_pinning_is_best_effort():
     from wayne_amd import launch
     assert launch._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}

@@ -134,7 +134,10 @@ class CalibrationSet(object):
                 hdus[1:1] = [np.float32(0.05 * t) * pat, err, None, None, None]
         else:
             name = det.dark_file(subarray, sampseq)              # raises WFC3SimNoDarkFileError
-            hdus = [h.data for h in fitsio.read(os.path.join(self._dir, name))]
+            # 1 + 5 x 16 HDUs (SCI, ERR, DQ, SAMP, TIME per read, last read first): only SCI and ERR are ever used
+            # (detector.py:185-190), so the other three of every read are dropped as they come in
+            hdus = [h.data if (i == 0 or (i - 1) % 5 < 2) else None
+                    for i, h in enumerate(fitsio.read(os.path.join(self._dir, name)))]
         self.dark[key] = hdus
         return hdus
 

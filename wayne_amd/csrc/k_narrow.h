@@ -102,10 +102,7 @@ __device__ __forceinline__ int wave_maxi(int v) {
              max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// BATCH: the workgroup takes a.kb consecutive sub-samples (k_lane, "BATCHES"); false: one -- the loop below then has
-// one trip and the compiler keeps nothing alive around it (the batched form of this kernel needs 99 registers, the
-// single form 62)
-template <int FLUSH, bool FAST, bool BATCH>
+template <int FLUSH, bool FAST>
 __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   __shared__ int tile[kNarrowTile];
@@ -117,10 +114,9 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   __shared__ int s_box[4];
   __shared__ float s_fc[10];                            // stirling_tail(0..9), indexed per lane in the rejection sampler
   if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
+  const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
   const int w = (int)a.chunk_order[blockIdx.y] * kNarrowThreads + tid;
-  // the workgroup's batch of consecutive sub-samples (k_lane, "BATCHES"; sub-sample fastest: see ThrowArgs::chunk_order)
-  auto sub_sample = [&](const int k) {
   const SubInfo si = a.sub[k];
   const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // narrow electrons of the bin's multinomial
   if (!__syncthreads_or(n0 > 0)) return;
@@ -345,12 +341,6 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       deposit_global<FLUSH>(a, si, tx0 + lx, ty0 + ly, n);
     }
   }
-  };   // sub_sample
-  if (BATCH) {
-    for (int k = (int)blockIdx.x * a.kb, k_end = min(k + a.kb, a.K); k < k_end; ++k) sub_sample(k);
-  } else {
-    sub_sample((int)blockIdx.x);
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -381,14 +371,17 @@ constexpr int kLaneReachMax = 48;       // largest margin of a test-free tile (s
 constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~20 px of the trace, + 2 x margin, by 2 x margin + a few rows
 
 // BATCHES.  A finely sampled scan (the reference's default 10 ms sampling: K = 2233 sub-samples of ~2.5 electrons
-// per bin) would launch K x chunks workgroups of ~1300 electrons each and spend its time in their prologues and
-// in flushes of nearly empty tiles.  A workgroup therefore takes `kb` consecutive sub-samples of its chunk (the
-// host's choice, 1 on a coarsely sampled exposure): one tile geometry for the batch (the union of its sub-samples'
-// bins), the tile flushed -- with that sub-sample's flat -- and left clean after every sub-sample.  THIN (the host
-// expects few electrons per workgroup and sub-sample): an electron that is the first on its tile cell (the LDS
-// atomic returns 0) puts the cell on a list, and the flush then visits the list's ~1000 cells instead of scanning
-// the tile's 9216 with a tenth of the lanes finding anything.  Same electrons, same streams, same sums (integer
-// accumulation commutes): frames do not depend on kb or THIN.
+// per bin) launches K x chunks workgroups of ~1300 electrons each.  A workgroup can take `kb` consecutive sub-samples
+// of its chunk (the host's choice, 1 on a coarsely sampled exposure): one tile geometry for the batch (the union of
+// its sub-samples' bins), the tile flushed -- with that sub-sample's flat -- and left clean after every sub-sample.
+// THIN (the host expects few electrons per workgroup and sub-sample): an electron that is the first on its tile cell
+// (the LDS atomic returns 0) puts the cell on a list, and the flush then visits the list's ~1000 cells instead of
+// scanning the tile's 9216 with a tenth of the lanes finding anything.  Same electrons, same streams, same sums
+// (integer accumulation commutes): frames do not depend on kb or THIN.  Measured on cfg1 (K = 2233): kb = 9 + THIN
+// takes k_lane from 0.279 to 0.230 ms; the same batching of k_prep_sub and k_narrow was built and measured SLOWER
+// (0.259 -> 0.286, 0.039 -> 0.057 ms: more registers, a barrier per sub-sample) and is not kept -- those kernels'
+// time on such an exposure is arithmetic per (bin, sub-sample): ~2.2 Philox blocks and an fp64 product-of-uniforms
+// search per stellar Poisson draw, not prologues (profiles/r03/cfg1_batches.txt).
 constexpr int kLaneListCap = 4096;      // cells on a THIN flush list (beyond it the flush falls back to the scan)
 
 template <int FLUSH, bool THIN, bool BATCH>

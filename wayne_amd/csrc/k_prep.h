@@ -88,11 +88,9 @@ struct PrepArgs {
   uint32_t* chunk_total;     // [K * n_chunks] electrons (for k_throw) per chunk of kPrepThreads bins
   double* chunk_box;         // [K * n_chunks * 4] xmin, xmax, ymin, ymax of the chunk's populated bins
   int fix_inline;            // split mode without a k_throw launch: chunk 0 writes SubInfo, k_prep_fix is not launched
-  int kb;                    // consecutive sub-samples a workgroup takes (1 .. kPrepBatchMax; k_lane, "BATCHES")
 };
 
 constexpr int kPrepThreads = 512;
-constexpr int kPrepBatchMax = 32;       // most sub-samples per workgroup (their trace coefficients sit in LDS)
 constexpr int kMaxPrepChunks = 128;     // chunks of kPrepThreads bins per sub-sample (32768 bins)
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
@@ -271,15 +269,14 @@ __device__ __forceinline__ SubInfo make_sub_info(const PrepArgs& a, int k, doubl
 // sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the chunk
 // offsets (when anything is left for k_throw: see the end of the kernel).
 // K * ceil(W / 512) workgroups instead of K: the whole chip works.
-template <bool BATCH>
 __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArgs ca) {
-  const int k0 = BATCH ? (int)blockIdx.x * a.kb : (int)blockIdx.x, k1 = BATCH ? min(k0 + a.kb, a.K) : k0 + 1;
+  const int k = blockIdx.x;
   const int ch = blockIdx.y;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int W = a.W;
   constexpr int NW = kPrepThreads / 64;
-  __shared__ double s_trb[kPrepBatchMax][6];   // per sub-sample of the batch: m_t, c_t, m_w, c_w, m_wl, c_wl
+  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
   __shared__ uint32_t s_wsum[NW];   // per-wave totals
   __shared__ double s_red[4][NW];
   __shared__ uint32_t s_hits;
@@ -288,26 +285,21 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     const int n_wg = gridDim.x * gridDim.y;
     for (int r = blockIdx.y * gridDim.x + blockIdx.x; r < ca.R; r += n_wg) { cosmic_hits(ca, r, &s_hits); __syncthreads(); }
   }
-  // the trace of each sub-sample of the batch: lane i computes sub-sample k0 + i's coefficients
-  if (tid < k1 - k0) trace_coeffs(a.g, a.x_ref[k0 + tid], a.y_ref[k0 + tid], s_trb[tid]);
-  __syncthreads();
-  const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE
-  unsigned long long n_split_total = 0;   // per thread, over the batch
-  bool overflow = false;
-  const int w = ch * kPrepThreads + tid;
-  // what depends on the wavelength alone: loaded once for the batch
-  double wl = 0., flux_w = 0., sens_w = 0., dlam_w = 0., ratio_w = 0., sigl_w = 0.;
-  if (w < W) { wl = a.wl[w]; flux_w = a.flux[w]; sens_w = a.wa.sens[w]; dlam_w = a.wa.dlam[w]; ratio_w = a.wa.ratio[w]; sigl_w = a.wa.sigl[w]; }
-
-  for (int k = k0; k < k1; ++k) {
-  const double* s_tr = s_trb[k - k0];
   const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
+  if (tid == 0) trace_coeffs(a.g, x_ref, y_ref, s_tr);
+  __syncthreads();
   const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
   const double dur = a.dur_ms[k];
+  const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE
 
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  bool overflow = false;
+  unsigned long long n_split_total = 0;   // per thread
+
+  const int w = ch * kPrepThreads + tid;
   uint32_t c = 0;
   if (w < W) {
+      const double wl = a.wl[w];
     // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
     // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
     const double x = (wl - c_wl) / m_wl;
@@ -318,10 +310,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     a.ypos[(size_t)k * W + w] = ys;
     // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
     //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
-    double f = flux_w;
+    double f = a.flux[w];
     if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
-    double lam = f * sens_w;
-    lam = lam * dlam_w;
+    double lam = f * a.wa.sens[w];
+    lam = lam * a.wa.dlam[w];
     lam = lam * 1e4;
     lam = lam * dur;
     lam = lam * 1e-3;
@@ -338,7 +330,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     c = (uint32_t)cnt;
     a.counts[(size_t)k * W + w] = (int32_t)c;
     // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
-    double nw = (double)(int32_t)c * ratio_w;
+    double nw = (double)(int32_t)c * a.wa.ratio[w];
     int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
     a.nwide[(size_t)k * W + w] = nwi;
     if (c > 0) {
@@ -352,7 +344,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     if (a.nsplit) {
       const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
       const uint32_t narrow = c - wide;
-      const double sl = sigl_w;
+      const double sl = a.wa.sigl[w];
       const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sl > 0.05 &&
                          sl * 6.5 <= (double)kNarrowR;
       const uint32_t ind = split ? wide : c;                 // electrons thrown one by one
@@ -366,6 +358,12 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
       if (a.fix_inline && c > 0u) atomicOr(a.status, 2);
     }
   }
+  if (overflow) atomicOr(a.status, 1);
+  // electrons handed to k_lane / k_narrow: one atomic per workgroup (wave shuffle, then LDS)
+  for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
+  __shared__ unsigned long long s_split[NW];
+  if (lane == 0) s_split[wave] = n_split_total;
+
   if (!a.fix_inline) {
     // what k_throw needs: exclusive scan of c inside the chunk (shuffle scan per wave, wave totals through LDS) ...
     uint32_t incl = c;
@@ -406,7 +404,12 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
       a.chunk_box[4 * ci + 0] = xmin; a.chunk_box[4 * ci + 1] = xmax;
       a.chunk_box[4 * ci + 2] = ymin; a.chunk_box[4 * ci + 3] = ymax;
     }
-    __syncthreads();                      // (s_wsum / s_red are written again by the batch's next sub-sample)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < NW; ++i) tot += s_split[i];
+    if (tot) atomicAdd(a.total_electrons, tot);
   }
 
   // Split mode with no k_throw launch (the default: every bin's one-by-one electrons fit its lane): nothing of the
@@ -415,19 +418,6 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
   // counter electing the last workgroup would serve every mode, but what the others wrote is only visible across
   // XCDs after an L2 write-back per workgroup: measured 0.17 ms per launch.)
   if (a.fix_inline && ch == 0 && tid == 0) a.sub[k] = make_sub_info(a, k, x_ref, y_ref, s_tr, 0u, 1e300, -1e300, 1e300, -1e300);
-  }   // sub-samples of the batch
-
-  if (overflow) atomicOr(a.status, 1);
-  // electrons handed to k_lane / k_narrow: one atomic per workgroup (wave shuffle, then LDS)
-  for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
-  __shared__ unsigned long long s_split[NW];
-  if (lane == 0) s_split[wave] = n_split_total;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long tot = 0;
-    for (int i = 0; i < NW; ++i) tot += s_split[i];
-    if (tot) atomicAdd(a.total_electrons, tot);
-  }
 }
 
 // One workgroup per sub-sample (modes that launch k_throw): chunk offsets -> global exclusive prefix, E_k,

@@ -291,9 +291,7 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
 // NOISE: the optional gaussian noise stage (noise_mean / noise_std; off in every shipped configuration) is
 // compiled in or out: its stream would otherwise hold four registers of a kernel that lives at the 64-VGPR limit
 template <class OutT, bool FAST, int SKY, bool NOISE>
-__global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ramp(RampArgs a) {
-  // (8 waves per SIMD = 64 VGPRs: the kernel hides its plane loads behind other waves' arithmetic; at 66 VGPRs
-  // and 7 waves it measured 0.116 ms instead of 0.108)
+__device__ __forceinline__ void ramp_body(const RampArgs& a) {
   constexpr bool ALIAS = SKY != 0;
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
   static_assert(kSkyAlias <= kRampThreads, "the sky tables and the per-thread sky counts share one LDS array");
@@ -564,6 +562,19 @@ __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8,
     if (rdn) v = v + kReadNoise * (double)zr;   // add_read_noise (detector.py:193-198)
     st_out(r + 1, (OutT)v);
   }
+}
+
+// The production-math variants with a table-driven sky fit 64 registers -- 8 waves per SIMD, which is what hides the
+// plane loads behind other waves' arithmetic (at 66 registers and 7 waves the kernel measured 7 % slower) -- and are
+// pinned there.  The exact-math, direct-sky (SKY = 0) and gaussian-noise variants would spill under that pin
+// (24-64 bytes of scratch each); they are parity / fallback paths and take the registers they need.
+template <class OutT, bool FAST, int SKY, bool NOISE>
+__global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ramp(RampArgs a) {
+  ramp_body<OutT, FAST, SKY, NOISE>(a);
+}
+template <class OutT, bool FAST, int SKY, bool NOISE>
+__global__ __launch_bounds__(kRampThreads) void k_ramp_wide(RampArgs a) {
+  ramp_body<OutT, FAST, SKY, NOISE>(a);
 }
 
 }  // namespace wayne

@@ -43,7 +43,7 @@ constexpr int kThrowPCache = 256;       // bins of a workgroup's slice whose pre
 
 struct ThrowArgs {
   int W, K, N, S;          // bins, sub-samples, frame side, bordered side
-  int kb;                  // k_lane / k_narrow: consecutive sub-samples a workgroup takes (>= 1; see k_lane, "BATCHES")
+  int kb;                  // k_lane: consecutive sub-samples a workgroup takes (>= 1; see k_lane, "BATCHES")
   int splits;              // workgroups launched per sub-sample (an upper bound: see k_throw)
   int min_wgs;             // spread the electrons over at least this many workgroups per launch
   int threads_compat;      // replay: emulated OpenMP team size

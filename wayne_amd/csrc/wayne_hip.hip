@@ -69,7 +69,7 @@ struct Slot {
   DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   DevBuf seg;             // cosmic-ray segments (CosmicArgs::seg): zeroed when allocated, k_ramp clears what it reads
-  int kb = 1;             // sub-samples a workgroup of k_prep_sub / k_lane / k_narrow takes (k_lane, "BATCHES")
+  int kb = 1;             // sub-samples a workgroup of k_lane takes (k_lane, "BATCHES")
   bool thin = false;      // few electrons per (workgroup, sub-sample): k_lane flushes from its first-touch list
   bool use_box = false;   // acc_box is valid: k_ramp loads the accumulators of a read only inside it (and where `seg` says)
   int acc_box[16][4] = {{0}};
@@ -548,20 +548,21 @@ static_assert(kSplitMin == kSplitMinHost, "split threshold");
 
 template <int FLUSH>
 int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
-  const dim3 grid((unsigned)((a.K + a.kb - 1) / a.kb), (unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads));
-  if (a.kb > 1) {
-    if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_narrow<FLUSH, true, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
-  } else {
-    if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_narrow<FLUSH, true, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
-  }
+  const dim3 grid((unsigned)a.K, (unsigned)((a.W + kNarrowThreads - 1) / kNarrowThreads));
+  if (exact) hipLaunchKernelGGL((k_narrow<FLUSH, false>), grid, dim3(kNarrowThreads), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_narrow<FLUSH, true>), grid, dim3(kNarrowThreads), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
 }
 
+template <class OutT, bool FAST, int SKY, bool NOISE>
+void (*ramp_kernel())(RampArgs) {
+  // (pinned to 8 waves per SIMD where that does not spill: see k_ramp / k_ramp_wide)
+  if constexpr (FAST && SKY != 0 && !NOISE) return k_ramp<OutT, FAST, SKY, NOISE>;
+  else return k_ramp_wide<OutT, FAST, SKY, NOISE>;
+}
 template <class OutT, bool FAST, int SKY>
-void (*ramp_noise(bool noise))(RampArgs) { return noise ? k_ramp<OutT, FAST, SKY, true> : k_ramp<OutT, FAST, SKY, false>; }
+void (*ramp_noise(bool noise))(RampArgs) { return noise ? ramp_kernel<OutT, FAST, SKY, true>() : ramp_kernel<OutT, FAST, SKY, false>(); }
 template <class OutT, bool FAST>
 void (*ramp_sky(int sky, bool noise))(RampArgs) {
   return sky == 1 ? ramp_noise<OutT, FAST, 1>(noise) : sky == 2 ? ramp_noise<OutT, FAST, 2>(noise) : ramp_noise<OutT, FAST, 0>(noise);
@@ -1034,12 +1035,12 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons);
   {
-    // Batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled scan
-    // (K in the thousands) otherwise launches tens of thousands of workgroups of a few hundred electrons each.
+    // k_lane's batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled
+    // scan (K in the thousands) otherwise launches tens of thousands of workgroups of ~1000 electrons each
     const int n_chunks_l = (W + kLaneThreads - 1) / kLaneThreads;
     int kb = (int)(((long long)K * n_chunks_l) / 2048);
-    kb = std::min(std::max(kb, 1), kPrepBatchMax);
-    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), kPrepBatchMax);
+    kb = std::min(std::max(kb, 1), 32);
+    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), 32);
     s.kb = kb;
     // thin: the expected electrons of the fullest chunk in the longest sub-sample fit the flush list with room to spare
     s.thin = s.max_chunk_electrons <= 0.4 * kLaneListCap;
@@ -1161,9 +1162,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
     ca.seg = s.seg.as<uint32_t>();
     ProfScope ps(c, PK_PREP_SUB);
-    a.kb = s.kb;
-    if (s.kb > 1) hipLaunchKernelGGL(k_prep_sub<true>, dim3((K + s.kb - 1) / s.kb, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
-    else hipLaunchKernelGGL(k_prep_sub<false>, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
+    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
     HIP_TRY(c, hipGetLastError());
     if (!a.fix_inline) {
       hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
