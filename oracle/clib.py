@@ -57,6 +57,9 @@ def lib():
         L.wayne_oracle_poisson_f64.restype = None
         L.wayne_oracle_poisson_f64.argtypes = [_f64p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, _f64p]
+        L.wayne_oracle_poisson_counts_f64.restype = None
+        L.wayne_oracle_poisson_counts_f64.argtypes = [_f64p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.c_uint32, C.c_uint32, _f64p]
         L.wayne_oracle_seed_streams.restype = None
         L.wayne_oracle_seed_streams.argtypes = [_u32p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
         L.wayne_oracle_poisson_sky_step.restype = None

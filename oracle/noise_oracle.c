@@ -168,6 +168,34 @@ static float wo_poisson_f(float lam, wo_stream *rng) {
   return floorf(lam + 0.5f);
 }
 
+/* The stellar counts of a bin (stage COUNTS, exposure_generator.py:626): PTRS as above from a mean of 10; below it
+ * ONE uniform and a sequential search of the cdf from 0 (inversion) instead of the product of uniforms -- a finely
+ * sampled scan draws millions of such counts per exposure, and the product of uniforms takes lam + 1 words (a
+ * second and a third Philox block for a fifth and a ninth word) where inversion takes one.  The distribution is
+ * Poisson(lam) either way; the draw is this project's own (the reference's comes from numpy's global stream). */
+static double wo_poisson_counts(double lam, wo_stream *rng) {
+  if (!(lam > 0.0)) return 0.0;
+  if (!(lam < 10.0)) return wo_poisson_d(lam, rng);
+  const double u = wo_u01d(wo_next(rng));
+  double p = exp(-lam), c = p, k = 0.0;
+  for (int it = 1; it < 256; ++it) {
+    if (u <= c) break;
+    p = p * lam / (double)it;
+    c = c + p;
+    k = (double)it;
+  }
+  return k;
+}
+
+void wayne_oracle_poisson_counts_f64(const double *lam, int64_t n, uint32_t seed, uint32_t stage,
+                                     uint32_t c0_base, uint32_t c2, uint32_t c3, double *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    wo_stream s;
+    wo_stream_init(&s, seed, stage, c0_base + (uint32_t)i, c2, c3);
+    out[i] = wo_poisson_counts(lam[i], &s);
+  }
+}
+
 /* Vector entry points used by oracle/wayne_oracle.py.  Element i draws from
  * the stream (c0[i] or c0_base + i, c2, c3) of stage `stage`. */
 void wayne_oracle_poisson_f64(const double *lam, int64_t n, uint32_t seed, uint32_t stage,

@@ -452,7 +452,7 @@ class PhiloxDraws(object):
     def stellar_poisson(self, lam, k):
         lam = np.ascontiguousarray(lam, dtype=np.float64)
         out = np.empty(lam.size)
-        clib.lib().wayne_oracle_poisson_f64(lam, lam.size, self.seed, STAGE_COUNTS, 0, int(k), self.exposure, out)
+        clib.lib().wayne_oracle_poisson_counts_f64(lam, lam.size, self.seed, STAGE_COUNTS, 0, int(k), self.exposure, out)
         return out
 
     def _stream(self, name, idx, stage):

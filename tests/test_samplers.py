@@ -67,6 +67,27 @@ def test_poisson_f64_counter_streams(lam):
     assert abs(out2.mean() - lam) < 5 * np.sqrt(lam / M)
 
 
+@pytest.mark.parametrize("lam", [0.004, 0.02, 0.7, 2.5, 6.0, 9.99, 10.0, 37.5, 1.0e4])
+def test_stellar_counts_sampler(lam):
+    # the stellar counts (stage COUNTS): inversion from one uniform below a mean of 10, PTRS from 10
+    L = clib.lib()
+    out = np.empty(M)
+    L.wayne_oracle_poisson_counts_f64(np.full(M, lam), M, 11, 1, 0, 3, 5, out)
+    assert np.all(out == np.floor(out)) and out.min() >= 0
+    lo, hi = support(lam, np.sqrt(lam))
+    assert chi2_pvalue(out, lambda k: stats.poisson.pmf(k, lam), lo, hi) > P_MIN
+    assert abs(out.mean() - lam) < 5 * np.sqrt(lam / M) and abs(out.var() - lam) < 6 * lam * np.sqrt(2.0 / M) + 6 * np.sqrt(lam / M)
+    if lam >= 10.0:                                            # the PTRS branch is the generic sampler's
+        ref = np.empty(M)
+        L.wayne_oracle_poisson_f64(np.full(M, lam), M, 11, 1, 0, 3, 5, ref)
+        np.testing.assert_array_equal(out, ref)
+    else:                                                      # one word per draw: inversion is monotone in it
+        blocks = np.empty((M, 4), dtype=np.uint32)
+        L.wayne_oracle_philox_blocks(np.arange(M, dtype=np.uint32), M, 0, 3, 5, 11, 1, blocks)
+        order = np.argsort(blocks[:, 0], kind="stable")
+        assert np.all(np.diff(out[order]) >= 0)
+
+
 @pytest.mark.parametrize("lam", [0.3, 9.5, 10.5, 80.0, 255.9, 256.0, 3000.0])
 def test_sky_poisson_step_fp32_and_fp64_branches(lam):
     # per-pixel seeded streams, float32 sampler below 256, float64 above (k_ramp's sky draw)

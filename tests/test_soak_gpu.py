@@ -79,3 +79,35 @@ def test_frames_do_not_depend_on_batches_or_the_thin_flush(name, monkeypatch):
         b = np.stack([r[0] for r in pg.scanning_frame(rng_mode=mode, **kw).reads])
         monkeypatch.delenv("WAYNE_BATCH")
         np.testing.assert_array_equal(a, b)
+
+
+def test_thin_exposure_without_k_narrow_and_its_rerun(monkeypatch):
+    # a few electrons per bin and sub-sample: the host leaves k_narrow out of the launch sequence (no bin is expected
+    # to reach the multinomial's 32 narrow electrons); same frame as with the kernel launched and finding nothing
+    v = helpers.make_visit("tiny")
+    kw = v.frame_kwargs(0, scale_factor=0.4)
+    pg = helpers.product_generator(v, 0)
+    rec = {}
+    a = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw).reads])
+    assert rec["counts"].max() < 32 and rec["counts"].mean() > 1
+    monkeypatch.setenv("WAYNE_KEEP_NARROW", "1")
+    b = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    monkeypatch.delenv("WAYNE_KEEP_NARROW")
+    np.testing.assert_array_equal(a, b)
+    # ... and a bin that defies the estimate (the host's estimate does not know the transit-depth matrix: a depth of
+    # -30 makes one bin 31 times brighter): the run flags itself and is repeated with k_narrow -- same frame as when
+    # the kernel is launched from the start
+    sig = np.array(kw["planet_signal"], dtype=float)
+    i0 = int(np.searchsorted(v.wl, 1.3))
+    sig[:, i0] = -30.0
+    kw2 = dict(kw, planet_signal=sig)
+    rec = {}
+    c = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw2).reads])
+    assert rec["counts"].max() > 60                                   # that bin went to the multinomial
+    c2 = np.stack([r[0] for r in pg.scanning_frame(**kw2).reads])
+    monkeypatch.setenv("WAYNE_KEEP_NARROW", "1")
+    d = np.stack([r[0] for r in pg.scanning_frame(**kw2).reads])
+    monkeypatch.delenv("WAYNE_KEEP_NARROW")
+    np.testing.assert_array_equal(c, d)
+    np.testing.assert_array_equal(c2, d)
+    assert rec["acc"].sum() > 0.9 * rec["counts"].sum()

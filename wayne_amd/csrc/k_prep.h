@@ -88,6 +88,7 @@ struct PrepArgs {
   uint32_t* chunk_total;     // [K * n_chunks] electrons (for k_throw) per chunk of kPrepThreads bins
   double* chunk_box;         // [K * n_chunks * 4] xmin, xmax, ymin, ymax of the chunk's populated bins
   int fix_inline;            // split mode without a k_throw launch: chunk 0 writes SubInfo, k_prep_fix is not launched
+  int no_narrow;             // k_narrow is not launched either (the host expects no bin with split_min narrow electrons)
 };
 
 constexpr int kPrepThreads = 512;
@@ -202,10 +203,44 @@ __device__ __forceinline__ int ptrs_squeeze(double lam, double k, double lhs_arg
   return (D <= -eps) ? 1 : ((D >= eps) ? -1 : 0);
 }
 
+// ... and below a mean of 10: ONE uniform and a sequential search of the cdf from 0 (the oracle's wo_poisson_counts),
+// in fp32 with a guard band and in fp64 only when the uniform falls within it (a few draws in ten thousand): the
+// decision is the fp64 one either way.  (numpy's product of uniforms takes lam + 1 words -- a second Philox block for
+// a fifth word, a third for a ninth, each paid by the whole wave -- an fp64 exp and an fp64 product per word; on a
+// finely sampled scan, millions of such draws per exposure, that was most of k_prep_sub.)
+template <class RNG>
+__device__ __forceinline__ double poisson_small(double lam, RNG& rng) {
+  const double u = u01d(rng.next());
+  const float lf = (float)lam, uf = (float)u;
+  float p = FastMath::exp_(-lf), c = p;
+  int k = 0;
+  bool unsure = true;
+  for (int it = 1; it < 64; ++it) {
+    const float tol = fmaf(c, 2e-5f, 2e-7f);              // fp32 exp, product and sum: < 3e-6 c; uf: 6e-8
+    if (uf <= c - tol) { unsure = false; break; }
+    if (!(uf > c + tol)) break;
+    p = p * (lf * (1.0f / (float)it));
+    c = c + p;
+    k = it;
+  }
+  if (unsure) {
+    double pd = exp(-lam), cd = pd;
+    k = 0;
+    for (int it = 1; it < 256; ++it) {
+      if (u <= cd) break;
+      pd = pd * lam / (double)it;
+      cd = cd + pd;
+      k = it;
+    }
+  }
+  return (double)k;
+}
+
 template <class RNG>
 __device__ double poisson_counts(double lam, RNG& rng) {
   typedef ExactMath<double> M;
-  if (!(lam >= 10.)) return poisson<M>(lam, rng);              // (also lam <= 0 and NaN)
+  if (!(lam > 0.)) return 0.;                                  // (also NaN)
+  if (!(lam >= 10.)) return poisson_small(lam, rng);
   // PtrsSetup<M>::init without ln(lam), which only the fp64 comparison needs
   const double slam = sqrt(lam);
   const double b = 0.931 + 2.53 * slam;
@@ -356,6 +391,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
       // launched without k_throw (the host expected no bin beyond a lane's reach) and here is one after all:
       // tell the host, which runs the exposure again with k_throw (wayne_hip.hip, check_status)
       if (a.fix_inline && c > 0u) atomicOr(a.status, 2);
+      if (a.no_narrow && split) atomicOr(a.status, 2);     // ... or without k_narrow, and here is a bin for it
     }
   }
   if (overflow) atomicOr(a.status, 1);

@@ -91,6 +91,7 @@ struct Slot {
   unsigned char sky_tab0[16] = {0};
   std::vector<double> read_dt_host;
   double lc_p_lo = 0., lc_p_hi = 0.;   // range of lc_rp
+  double max_narrow = 0.;   // host estimate: most narrow electrons expected in a bin of the longest sub-sample
   double max_chunk_electrons = 0.;   // host estimate: electrons of the fullest k_lane chunk in the longest sub-sample
   double est_thrown = 0.;   // host estimate of the electrons k_throw handles in the longest sub-sample
   unsigned char chunk_order[kMaxChunks] = {0};   // chunks of kNarrowThreads bins, most electrons first (ThrowArgs::chunk_order)
@@ -337,7 +338,7 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
 // (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
 // the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
 double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
-                       unsigned char* lane_order, double* max_chunk_electrons) {
+                       unsigned char* lane_order, double* max_chunk_electrons, double* max_narrow) {
   const int W = d->n_wl, K = d->n_samples;
   const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
   const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
@@ -348,6 +349,7 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
   const std::vector<double>&sw = c->sens_wl_host, &sv = c->sens_val_host;
   auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
   double total = 0.;
+  *max_narrow = 0.;
   for (int i = 0; i < W; ++i) {
     const double x = d->wl_um[i];
     double sens = 1.0;
@@ -368,6 +370,7 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
     lane_e[(size_t)(i / kLaneThreads)] += cnt;
     if (d->rng_mode == WAYNE_RNG_SPLIT) {
       const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
+      *max_narrow = std::max(*max_narrow, cnt - wide);
       const double sl = poly3(g.p_sigl, x);
       if (cnt - wide >= (double)kSplitMinHost && cnt - wide <= (double)kSplitMaxNarrow && sl > 0.05 &&
           sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
@@ -1033,7 +1036,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
-  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons);
+  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons, &s.max_narrow);
   {
     // k_lane's batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled
     // scan (K in the thousands) otherwise launches tens of thousands of workgroups of ~1000 electrons each
@@ -1117,6 +1120,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   }
   // margin of a thrower workgroup's tile around its slice of the trace: 5 sigma_h, so that practically no electron
   // takes the in-loop global-atomic path (see k_lane)
+  bool skip_narrow = false;
   bool lane_unlimited = false;   // split mode without a k_throw launch: the lanes take every bin (up to kLaneReach)
   const int margin = d.thrower_margin > 0 ? d.thrower_margin : 30;
   {
@@ -1156,6 +1160,12 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.chunk_total = s.chunk_total.as<uint32_t>();
     a.chunk_box = s.chunk_box.as<double>();
     a.fix_inline = lane_unlimited ? 1 : 0;
+    // a finely sampled scan holds a few electrons per bin and sub-sample: no bin is expected to reach the
+    // multinomial's threshold (mean <= 6 against kSplitMin = 32: 1e-13 per draw), k_narrow's launch would only find
+    // that out workgroup by workgroup (0.04 ms at K = 2233) -- it is left out, and a bin that qualifies after all
+    // flags the run, which is then repeated with every kernel (check_status)
+    skip_narrow = lane_unlimited && s.max_narrow <= 6. && !std::getenv("WAYNE_KEEP_NARROW");
+    a.no_narrow = skip_narrow ? 1 : 0;
     CosmicArgs ca{};
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
     ca.rate = (d.cosmic_rate >= 0.) ? d.cosmic_rate : -1.;
@@ -1222,7 +1232,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.frame = nullptr;
     if ((d.flags & WAYNE_F_ADD_FLAT) && !c->has_flat) return fail(c, WAYNE_E_STATE, "run: add_flat without a flat cube");
     const int si_ = slot % c->n_streams;
-    const bool fork = d.rng_mode == WAYNE_RNG_SPLIT && c->fork_narrow;
+    const bool fork = d.rng_mode == WAYNE_RNG_SPLIT && c->fork_narrow && !skip_narrow;
     hipStream_t main_stream = c->stream;
     {
       // (with the fork, the PK_THROW interval spans all thrower kernels; PK_NARROW / PK_LANE are those kernels' own)
@@ -1250,7 +1260,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       }
       if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join[si_], 0));
     }
-    if (!fork && d.rng_mode == WAYNE_RNG_SPLIT) {
+    if (!fork && d.rng_mode == WAYNE_RNG_SPLIT && !skip_narrow) {
       ProfScope ps(c, PK_NARROW);
       int rc = launch_narrow<1>(c, a, (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0);
       if (rc) return rc;
