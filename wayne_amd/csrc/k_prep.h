@@ -7,11 +7,18 @@ namespace wayne {
 // ---------------------------------------------------------------------------
 // k_prep_wl : A8 + the wavelength-only part of A9
 // ---------------------------------------------------------------------------
-__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o, uint32_t* misc) {
+WAYNE_HD void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o);
+
+// (also: thread k computes the trace coefficients of sub-sample k -- six numbers that every workgroup of k_prep_sub
+// needs before it can start; computed there by one thread with the other 511 waiting at a barrier they were ~2 us of
+// serial fp64 latency per workgroup)
+__global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlArrays o, uint32_t* misc, int K,
+                          const double* __restrict__ x_ref, const double* __restrict__ y_ref, double* __restrict__ tr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the exposure's status words (total electrons, overflow flag) start from zero: cleared here, by the
   // first kernel of the exposure, instead of by a separate fill in front of it
   if (i < 16) misc[i] = 0u;
+  if (i < K) trace_coeffs(g, x_ref[i], y_ref[i], tr + 6 * (size_t)i);
   if (i >= W) return;
   const double x = wl[i];
   o.ratio[i] = poly3(g.p_ratio, x);
@@ -73,6 +80,7 @@ struct PrepArgs {
   const double* dur_ms;      // [K]
   const int32_t* replay_seed;  // [K]
   const int32_t* sample_read;  // [K]
+  const double* tr;          // [K*6] trace coefficients per sub-sample (k_prep_wl): m_t, c_t, m_w, c_w, m_wl, c_wl
   WlArrays wa;
   // outputs
   int32_t* counts;           // [K*W]
@@ -311,7 +319,6 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
   const int lane = tid & 63, wave = tid >> 6;
   const int W = a.W;
   constexpr int NW = kPrepThreads / 64;
-  __shared__ double s_tr[8];        // m_t, c_t, m_w, c_w, m_wl, c_wl
   __shared__ uint32_t s_wsum[NW];   // per-wave totals
   __shared__ double s_red[4][NW];
   __shared__ uint32_t s_hits;
@@ -321,8 +328,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     for (int r = blockIdx.y * gridDim.x + blockIdx.x; r < ca.R; r += n_wg) { cosmic_hits(ca, r, &s_hits); __syncthreads(); }
   }
   const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
-  if (tid == 0) trace_coeffs(a.g, x_ref, y_ref, s_tr);
-  __syncthreads();
+  const double* s_tr = a.tr + 6 * (size_t)k;      // (wave-uniform: scalar loads)
   const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
   const double dur = a.dur_ms[k];
   const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE

@@ -66,7 +66,7 @@ struct Slot {
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
   DevBuf wl, flux, depth, xref, yref, dur, rseed, sread, read_dt, lc_z, lc_hidden, lc_rp;   // views into in_dev (depth: owned when computed by k_lightcurve)
   DevBuf ratio, sigl, sigh, sens, dlam;
-  DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box;
+  DevBuf counts, nwide, nsplit, nlane, prefix, xpos, ypos, sub, chunk_total, chunk_box, tr;
   DevBuf acc, out, misc;  // misc: [0] total electrons (u64), [1] status (int)
   DevBuf seg;             // cosmic-ray segments (CosmicArgs::seg): zeroed when allocated, k_ramp clears what it reads
   int kb = 1;             // sub-samples a workgroup of k_lane takes (k_lane, "BATCHES")
@@ -104,7 +104,7 @@ struct Slot {
   bool stage_pending = false;
   void release() {
     for (DevBuf* b : {&wl, &flux, &depth, &xref, &yref, &dur, &rseed, &sread, &read_dt, &lc_z, &lc_hidden, &lc_rp, &ratio, &sigl,
-                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &nlane, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &acc, &out,
+                      &sigh, &sens, &dlam, &counts, &nwide, &nsplit, &nlane, &prefix, &xpos, &ypos, &sub, &chunk_total, &chunk_box, &tr, &acc, &out,
                       &misc, &seg, &sky_tab, &in_dev})
       b->release();
     if (sky_tab_host) (void)hipHostFree(sky_tab_host);
@@ -1011,6 +1011,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.sub.reserve((size_t)K * sizeof(SubInfo)));
+  HIP_TRY(c, s.tr.reserve((size_t)K * 6 * sizeof(double)));
   {
     const size_t n_chunks = (size_t)(W + kPrepThreads - 1) / kPrepThreads;
     if (n_chunks > (size_t)kMaxPrepChunks || W > 32768) return fail(c, WAYNE_E_INVALID, "upload: more than 32768 wavelength bins");
@@ -1046,7 +1047,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), 32);
     s.kb = kb;
     // thin: the expected electrons of the fullest chunk in the longest sub-sample fit the flush list with room to spare
-    s.thin = s.max_chunk_electrons <= 0.4 * kLaneListCap;
+    s.thin = s.max_chunk_electrons <= 0.9 * kLaneListCap;
     if (const char* e = std::getenv("WAYNE_THIN")) s.thin = std::atoi(e) != 0;
   }
   s.use_box = accumulator_boxes(c, d, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
@@ -1114,8 +1115,9 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
               s.dlam.as<double>()};
   {
     ProfScope ps(c, PK_PREP_WL);
-    hipLaunchKernelGGL(k_prep_wl, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->g, W,
-                       s.wl.as<double>(), wa, s.misc.as<uint32_t>());
+    hipLaunchKernelGGL(k_prep_wl, dim3((std::max(W, K) + 255) / 256), dim3(256), 0, c->stream, c->g, W,
+                       s.wl.as<double>(), wa, s.misc.as<uint32_t>(), K, s.xref.as<double>(), s.yref.as<double>(),
+                       s.tr.as<double>());
     HIP_TRY(c, hipGetLastError());
   }
   // margin of a thrower workgroup's tile around its slice of the trace: 5 sigma_h, so that practically no electron
@@ -1137,6 +1139,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.x_ref = s.xref.as<double>(); a.y_ref = s.yref.as<double>(); a.dur_ms = s.dur.as<double>();
     a.replay_seed = s.has_replay_seed ? s.rseed.as<int32_t>() : nullptr;
     a.sample_read = s.sread.as<int32_t>();
+    a.tr = s.tr.as<double>();
     a.wa = wa;
     a.counts = s.counts.as<int32_t>(); a.nwide = s.nwide.as<int32_t>();
     a.nsplit = s.nsplit.as<int32_t>();
