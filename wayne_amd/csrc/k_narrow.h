@@ -550,35 +550,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     uint32_t wa, wb;
     if (sure) {
       if (one_sigma) {
-        for (int j = 0; j < cmin2; j += 2) {
-          // two electrons per pair of words, their (independent) dependent chains written side by side
-          rng.next2(wa, wb);
-          int xa, ya, xb, yb;
-#ifdef WAYNE_LANE_PAIRED
-          const float reva = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wa, 9)), revb = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9));
-          const uint32_t ha = wa & 0xFFFFu, hb = wb & 0xFFFFu;
-          float la = __builtin_amdgcn_logf((float)ha + 0.5f), lb = __builtin_amdgcn_logf((float)hb + 0.5f);
-          float ra = fmaf(ch, la, ch16), rb = fmaf(ch, lb, ch16);
-          if (__builtin_expect((ha == 0u) | (hb == 0u), 0)) {
-            if (ha == 0u) { refine = refine * 1664525u + 1013904223u; ra = fmaf(ch, __builtin_amdgcn_logf((float)(refine >> 15) + 0.5f), -33.f * ch); }
-            if (hb == 0u) { refine = refine * 1664525u + 1013904223u; rb = fmaf(ch, __builtin_amdgcn_logf((float)(refine >> 15) + 0.5f), -33.f * ch); }
-          }
-          const float sa = __builtin_amdgcn_sqrtf(ra), sb = __builtin_amdgcn_sqrtf(rb);
-          const float ca = __builtin_amdgcn_cosf(reva), cb = __builtin_amdgcn_cosf(revb);
-          const float na = __builtin_amdgcn_sinf(reva), nb = __builtin_amdgcn_sinf(revb);
-          xa = (int)fmaf(ca, sa, x); xb = (int)fmaf(cb, sb, x);
-          ya = (int)fmaf(na, sa, y); yb = (int)fmaf(nb, sb, y);
-          int aa, ab;
-          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aa) : "v"(ya), "s"(tw4), "v"((xa << 2) + origin));
-          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ab) : "v"(yb), "s"(tw4), "v"((xb << 2) + origin));
-          tile_add(aa);
-          tile_add(ab);
-#else
-          (void)xa; (void)ya; (void)xb; (void)yb;
-          throw_sure(rng, wa, ch, ch16, true);
-          throw_sure(rng, wb, ch, ch16, true);
-#endif
-        }
+        for (int j = 0; j < cmin2; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, true); throw_sure(rng, wb, ch, ch16, true); }
         for (int j = cmin2; j < cmax; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, j < n); throw_sure(rng, wb, ch, ch16, j + 1 < n); }
       } else {
         for (int j = 0; j < cmax; j += 2) {
