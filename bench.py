@@ -523,11 +523,10 @@ def main():
             if v.get("csrc_hash") == here:
                 # counted and un-clamped (scripts/make_profile_stamps.py): quad-cycles of vector execution over SIMD cycles
                 line["thrower"]["valu_issue"] = {k: {"valu_busy_frac": x["valu_busy_frac"],
-                                                     "valu_busy_frac_sq_busy": x.get("valu_busy_frac_sq_busy"),
-                                                     "cycles_source": x.get("cycles_source"),
-                                                     "eff_clock_ghz": x.get("eff_clock_ghz"),
+                                                     "valu_busy_frac_gui": x.get("valu_busy_frac_gui"),
                                                      "lane_utilisation": x["lane_utilisation"]}
                                                  for k, x in v["kernels"].items()}
+                line["thrower"]["valu_issue_note"] = "valu_busy_frac: vector quad-cycles per SIMD / (kernel duration x 2.4 GHz): a lower bound, un-clamped"
                 line["thrower"]["valu_issue_source"] = v.get("source", "profiles/valu_issue.json")
             else:
                 line["thrower"]["valu_issue"] = None

@@ -57,11 +57,17 @@ def main():
     issue["note"] = (
         "valu_busy_frac = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): SQ_ACTIVE_INST_VALU counts the QUAD-cycles a "
         "SIMD spends executing vector instructions (MI355X_MICROARCH.md: 'SQ_ACTIVE_INST_* count quad-cycles'; it equals "
-        "SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32 on these kernels: 4 cycles per wave64 instruction, 8 per transcendental); "
-        "cycles = GRBM_GUI_ACTIVE / 8 XCDs of the same dispatch (the shader clock really run, DVFS included) when that "
-        "counter was collected, else SQ_BUSY_CYCLES / 32 shader engines.  Counted, not modelled, and NOT clamped: a value "
-        "above 1 would say the normalisation is wrong.  valu_busy_frac_sq_busy is the same over SQ_BUSY_CYCLES / 32; "
-        "eff_clock_ghz = cycles / kernel_avg_ns; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)")
+        "SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32 on these kernels: one quad-cycle per wave64 instruction, two per "
+        "transcendental); cycles = the kernel's average duration (rocprofv3 --kernel-trace --stats of the same "
+        "collection) x 2.4 GHz, the chip's maximum clock -- the clock under load is at most that, so the figure is a "
+        "LOWER bound of the fraction of SIMD cycles with a vector instruction executing.  Counted, not modelled, not "
+        "clamped.  valu_busy_frac_gui is the same over GRBM_GUI_ACTIVE / 8 XCDs of the dispatch, which on dispatches "
+        "this short includes cycles around the kernel (the guide: 'reads high on dispatches shorter than about 0.3 ms'; "
+        "gui_clock_ghz = those cycles / the duration comes out above 2.4) and so reads lower still.  (The SQ's own "
+        "busy counters are not wall-time denominators: SQ_BUSY_CYCLES / 32 shader engines and SQ_BUSY_CU_CYCLES / 256 "
+        "CUs count 0.88-0.93 of duration x 2.4 GHz on the big kernels -- idle stretches of an engine or CU are not in "
+        "them -- and the vector quad-cycles per SIMD come to 0.99-1.04 of them.)  lane_utilisation = "
+        "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)")
     issue["kernels"] = {}
     for k, c in sq.items():
         if "wayne::" not in k or not all(n in c for n in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_THREAD_CYCLES_VALU",
@@ -69,21 +75,19 @@ def main():
             continue
         valu, trans = c["SQ_INSTS_VALU"]["mean"], c["SQ_INSTS_VALU_TRANS_F32"]["mean"]
         active = c["SQ_ACTIVE_INST_VALU"]["mean"]
-        busy_sq = c["SQ_BUSY_CYCLES"]["mean"] / 32.0
-        if busy_sq < 20000:          # tiny kernels say nothing
-            continue
-        gui = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0 if "GRBM_GUI_ACTIVE" in c else None
-        cycles = gui if gui else busy_sq
         ns = avg.get(k, {}).get("avg_ns")
+        if c["SQ_BUSY_CYCLES"]["mean"] / 32.0 < 20000 or not ns:          # tiny kernels say nothing
+            continue
+        cycles = ns * 2.4
+        gui = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0 if "GRBM_GUI_ACTIVE" in c else None
         issue["kernels"][k.replace("wayne::", "")] = {
             "valu_wave_instructions": round(valu), "transcendental_wave_instructions": round(trans),
             "valu_active_quad_cycles": round(active),
-            "cycles": round(cycles), "cycles_source": "GRBM_GUI_ACTIVE/8" if gui else "SQ_BUSY_CYCLES/32",
+            "kernel_avg_ns": ns, "cycles_at_2p4_ghz": round(cycles),
             "valu_busy_frac": round(4.0 * active / 1024.0 / cycles, 3),
-            "valu_busy_frac_sq_busy": round(4.0 * active / 1024.0 / busy_sq, 3),
-            "eff_clock_ghz": round(cycles / ns, 3) if ns else None,
-            "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / (64.0 * active), 3),
-            "kernel_avg_ns": ns}
+            "valu_busy_frac_gui": round(4.0 * active / 1024.0 / gui, 3) if gui else None,
+            "gui_clock_ghz": round(gui / ns, 3) if gui else None,
+            "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / (64.0 * active), 3)}
     json.dump(issue, open(os.path.join(prof_dir, "valu_issue.json"), "w"), indent=1)
     print("stamped", prof_dir, stamp)
 

@@ -111,3 +111,28 @@ def test_thin_exposure_without_k_narrow_and_its_rerun(monkeypatch):
     np.testing.assert_array_equal(c, d)
     np.testing.assert_array_equal(c2, d)
     assert rec["acc"].sum() > 0.4 * rec["counts"].sum()            # (a 64-px frame: much of the scan falls off it)
+
+
+@pytest.mark.parametrize("name,kw_over", [("small256", {}), ("tiny_g102", {}), ("cfg5", {"E": 2e6, "K": 16}),
+                                          ("stare256", {})])
+def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):
+    # k_ramp loads a read's accumulators only inside the host's bound on where that read's electrons can land and
+    # where a cosmic-ray segment bit is set; with the boxes off (every accumulator loaded, as in rounds 1-2) the
+    # reads must be the same bit for bit -- cosmic rays, jitter, SSV, scan and stare, every rng mode
+    from wayne_amd import _lib
+    v = helpers.make_visit(name, **kw_over)
+    pg = helpers.product_generator(v, 0)
+    kw = v.frame_kwargs(0)
+    staring = v.scan_speed == 0
+    if staring:
+        kw = {k: kw[k] for k in kw if k not in ("scan_speed", "sample_rate", "ssv_generator")}
+    gen = pg.staring_frame if staring else pg.scanning_frame
+    for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX, _lib.RNG_REPLAY):
+        a = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
+        monkeypatch.setenv("WAYNE_NO_ACC_BOX", "1")
+        b = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
+        monkeypatch.delenv("WAYNE_NO_ACC_BOX")
+        np.testing.assert_array_equal(a, b, err_msg="%s rng_mode %d" % (name, mode))
+        # and a second exposure in the same slot starts from clean accumulators and segment bits
+        c = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
+        np.testing.assert_array_equal(a, c)
