@@ -113,6 +113,28 @@ def test_thin_exposure_without_k_narrow_and_its_rerun(monkeypatch):
     assert rec["acc"].sum() > 0.4 * rec["counts"].sum()            # (a 64-px frame: much of the scan falls off it)
 
 
+@pytest.mark.parametrize("name,scale", [("tiny", 0.4), ("small256", 0.02), ("cfg1", 1.0)])
+def test_fused_thin_path_equals_the_three_kernel_path(name, scale, monkeypatch):
+    # thin exposures (a few electrons per bin and sub-sample, nothing expected for k_narrow or k_throw) run without
+    # k_prep_sub: k_lane<.., FUSED> plans each bin itself (plan_bin, k_prep.h) and throws at once.  Same counts, same
+    # positions (worked out afterwards by k_prep_sub for the record), same cosmic rays, same reads as the
+    # k_prep_sub -> k_lane sequence, bit for bit; cfg1 (K = 2233 sub-samples of ~2.5 e- per bin) is the case it is for
+    v = helpers.make_visit(name)
+    kw = v.frame_kwargs(0, scale_factor=scale)
+    pg = helpers.product_generator(v, 0)
+    rec_f, rec_u = {}, {}
+    a = np.stack([r[0] for r in pg.scanning_frame(record=rec_f, **kw).reads])
+    a2 = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
+    monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+    b = np.stack([r[0] for r in pg.scanning_frame(record=rec_u, **kw).reads])
+    monkeypatch.delenv("WAYNE_NO_FUSE")
+    assert rec_u["counts"].max() < 32 and rec_u["counts"].sum() > 1000
+    for key in ("counts", "x", "y", "acc"):
+        np.testing.assert_array_equal(rec_f[key], rec_u[key], err_msg=key)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a2, b)
+
+
 @pytest.mark.parametrize("name,kw_over", [("small256", {}), ("tiny_g102", {}), ("cfg5", {"E": 2e6, "K": 16}),
                                           ("stare256", {})])
 def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):

@@ -31,6 +31,8 @@ struct GrismDev {
 };
 
 // Per sub-sample record written by k_prep_sub and read by k_throw.
+constexpr int kTrStride = 8;   // doubles per sub-sample in the trace-coefficient array (k_prep_wl): 6 coefficients, 1 / m_wl, pad
+
 struct SubInfo {
   uint32_t electrons;      // E_k
   int tx0, ty0, tw, th;    // LDS tile rectangle, frame coordinates

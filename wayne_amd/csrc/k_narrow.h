@@ -383,10 +383,19 @@ constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~2
 // time on such an exposure is arithmetic per (bin, sub-sample): ~2.2 Philox blocks and an fp64 product-of-uniforms
 // search per stellar Poisson draw, not prologues (profiles/r03/cfg1_batches.txt).
 constexpr int kLaneListCap = 4096;      // cells on a THIN flush list (beyond it the flush falls back to the scan)
+constexpr int kLaneBatchMax = 32;       // most sub-samples per workgroup
 
-template <int FLUSH, bool THIN, bool BATCH>
-__global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
+// FUSED (thin exposures, split mode, no k_throw and no k_narrow launched): there is no k_prep_sub launch either -- the
+// lane works out its bin's position, count and routing itself, per sub-sample, with k_prep_sub's own code (plan_bin),
+// and throws at once.  A finely sampled scan is 10^7 (bin, sub-sample) pairs of ~2.5 electrons: written by k_prep_sub
+// and read back here, the six K x W arrays of intermediates were ~900 MB of traffic per exposure and the two kernels
+// spent two thirds of their wave-cycles waiting on them.  Only the counts are still stored (for
+// wayne_exposure_debug_fetch); positions are worked out again by a k_prep_sub launch if a caller asks for them.
+template <int FLUSH, bool THIN, bool BATCH, bool FUSED>
+__device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p, const CosmicArgs& ca) {
   __shared__ int tile[kLaneTile];
+  __shared__ SubInfo s_sub[FUSED ? kLaneBatchMax : 1];
+  __shared__ uint32_t s_hits;
   __shared__ unsigned short s_list[THIN ? kLaneListCap : 1];
   __shared__ int s_cnt;
   __shared__ int s_box[4];
@@ -402,22 +411,48 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
     ch = (-1.3862943611198906f * sh) * sh;
     cl = (-1.3862943611198906f * sl) * sl;
   }
+  // FUSED: the bin's per-wavelength inputs of the counts chain, the batch's SubInfo records, and the cosmic-ray hits
+  // that k_prep_sub's workgroups add on their way in
+  double f_wl = 0., f_flux = 0., f_sens = 0., f_dlam = 0., f_ratio = 0., f_sigl = 0.;
+  unsigned long long f_electrons = 0ull;
+  if (FUSED) {
+    if (ca.rate >= 0.) {
+      const int n_wg = gridDim.x * gridDim.y;
+      for (int r = blockIdx.y * gridDim.x + blockIdx.x; r < ca.R; r += n_wg) { cosmic_hits(ca, r, &s_hits); __syncthreads(); }
+    }
+    if (inw) { f_wl = p.wl[w]; f_flux = p.flux[w]; f_sens = p.wa.sens[w]; f_dlam = p.wa.dlam[w]; f_ratio = p.wa.ratio[w]; f_sigl = p.wa.sigl[w]; }
+    if (tid < k1 - k0) {
+      const int k = k0 + tid;
+      s_sub[tid] = make_sub_info(p, k, p.x_ref[k], p.y_ref[k], p.tr + kTrStride * (size_t)k, 0u, 1e300, -1e300, 1e300, -1e300);
+    }
+  }
   // the batch's populated bins: bounding box and reach
   int x_lo = 0x7FFFFFFF, x_hi = -0x7FFFFFFF, y_lo = 0x7FFFFFFF, y_hi = -0x7FFFFFFF;
   float reach = 0.f;
   bool any = false;
   for (int k = k0; k < k1; ++k) {
     const size_t kw = (size_t)k * a.W + (inw ? w : 0);
-    const int n = inw ? a.nlane[kw] : 0;
+    int n = 0, nw = 0;
+    float x = 0.f, y = 0.f;
+    if (FUSED) {
+      // every bin of the chunk, populated or not, and both sigmas (the counts are not drawn twice for a box); the
+      // positions without their division, good to 1e-10 px, and the box a pixel larger all round
+      if (inw) {
+        bin_position_bound(p, f_wl, p.tr + kTrStride * (size_t)k, p.x_ref[k], p.y_ref[k], &x, &y);
+        n = 2; nw = 1;
+      }
+    } else if (inw) {
+      n = a.nlane[kw];
+      if (n > 0) { x = (float)a.xpos[kw]; y = (float)a.ypos[kw]; nw = min(max(a.nwide[kw], 0), n); }
+    }
     if (n > 0) {
       any = true;
-      const float x = (float)a.xpos[kw], y = (float)a.ypos[kw];
-      const int nw = min(max(a.nwide[kw], 0), n);
       const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
       float r = (smax >= 0.f && smax < 1e6f) ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
       if (fabsf(x) < 1e6f && fabsf(y) < 1e6f) {
         const int ic = (int)floorf(x), jc = (int)floorf(y);
-        x_lo = min(x_lo, ic); x_hi = max(x_hi, ic); y_lo = min(y_lo, jc); y_hi = max(y_hi, jc);
+        constexpr int spare = FUSED ? 1 : 0;
+        x_lo = min(x_lo, ic - spare); x_hi = max(x_hi, ic + spare); y_lo = min(y_lo, jc - spare); y_hi = max(y_hi, jc + spare);
       } else {
         r = __int_as_float(0x7F800000);
       }
@@ -470,12 +505,25 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
 
   for (int k = k0; k < k1; ++k) {
   const size_t kw = (size_t)k * a.W + (inw ? w : 0);
-  const int n = inw ? a.nlane[kw] : 0;
-  if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and s_cnt is 0 again)
-  const SubInfo si = a.sub[k];
+  int n = 0, nw = 0;
   float x = -1e30f, y = -1e30f;
-  int nw = 0;
-  if (n > 0) {
+  if (FUSED) {
+    if (inw) {
+      const BinPlan b = plan_bin(p, k, w, f_wl, f_flux, f_sens, f_dlam, f_ratio, f_sigl, p.tr + kTrStride * (size_t)k, p.x_ref[k],
+                                 p.y_ref[k], p.dur_ms[k], p.depth ? p.depth[kw] : 0.);
+      p.counts[kw] = (int32_t)b.count;
+      if (b.overflow) atomicOr(p.status, 1);
+      if (b.narrow > 0u || b.rest > 0u) atomicOr(p.status, 2);   // a bin for k_narrow / k_throw after all: the host runs the exposure again
+      n = (int)b.lane;
+      f_electrons += b.lane;
+      if (n > 0) { x = (float)b.xs; y = (float)b.ys; nw = min(max(b.nwide, 0), n); }
+    }
+  } else if (inw) {
+    n = a.nlane[kw];
+  }
+  if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and s_cnt is 0 again)
+  const SubInfo si = FUSED ? s_sub[k - k0] : a.sub[k];
+  if (!FUSED && n > 0) {
     x = (float)a.xpos[kw];
     y = (float)a.ypos[kw];
     nw = min(max(a.nwide[kw], 0), n);
@@ -599,6 +647,29 @@ __global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
   }
   if (THIN && tid == 0) s_cnt = 0;
   }   // sub-samples of the batch
+  if (FUSED) {
+    // electrons handed to the lanes: ONE atomic per workgroup (the counter is a single address for the whole chip:
+    // 8 ns apiece, measured -- one per wave was 1.4 ms of a finely sampled exposure)
+    for (int off = 32; off > 0; off >>= 1) f_electrons += __shfl_down(f_electrons, off);
+    __shared__ unsigned long long s_tot[kLaneThreads / 64];
+    if ((tid & 63) == 0) s_tot[tid >> 6] = f_electrons;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long t = 0;
+      for (int i = 0; i < kLaneThreads / 64; ++i) t += s_tot[i];
+      if (t) atomicAdd(p.total_electrons, t);
+    }
+  }
+}
+
+template <int FLUSH, bool THIN, bool BATCH>
+__global__ __launch_bounds__(kLaneThreads) void k_lane(ThrowArgs a) {
+  lane_body<FLUSH, THIN, BATCH, false>(a, PrepArgs{}, CosmicArgs{});
+}
+// (two workgroups per CU: 128 VGPRs)
+template <int FLUSH>
+__global__ __launch_bounds__(kLaneThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lane_fused(ThrowArgs a, PrepArgs p, CosmicArgs ca) {
+  lane_body<FLUSH, true, true, true>(a, p, ca);
 }
 
 }  // namespace wayne

@@ -18,7 +18,12 @@ __global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlAr
   // the exposure's status words (total electrons, overflow flag) start from zero: cleared here, by the
   // first kernel of the exposure, instead of by a separate fill in front of it
   if (i < 16) misc[i] = 0u;
-  if (i < K) trace_coeffs(g, x_ref[i], y_ref[i], tr + 6 * (size_t)i);
+  if (i < K) {
+    double* t = tr + kTrStride * (size_t)i;
+    trace_coeffs(g, x_ref[i], y_ref[i], t);
+    t[6] = 1. / t[4];     // (for bin_position_bound)
+    t[7] = 0.;
+  }
   if (i >= W) return;
   const double x = wl[i];
   o.ratio[i] = poly3(g.p_ratio, x);
@@ -308,6 +313,88 @@ __device__ __forceinline__ SubInfo make_sub_info(const PrepArgs& a, int k, doubl
   return si;
 }
 
+// What k_prep_sub works out for bin w of sub-sample k (A7, A9, A10 and the routing of the bin) -- also evaluated on the
+// fly, from the same inputs by the same code, by the fused form of k_lane (thin exposures), which is why it is a
+// function: position in the frame, electron count, the sigma split and who throws what.
+struct BinPlan {
+  double xs, ys;            // frame position (x_sub, y_sub)
+  uint32_t count;           // electrons of the bin (A9)
+  int32_t nwide;            // N = (int)(counts * psf_ratio) (pyparallel_menu.c:89), not yet clamped to the count
+  uint32_t narrow;          // electrons handed to k_narrow's multinomial (0: none)
+  uint32_t lane;            // electrons the bin's own lane throws one by one (0: none)
+  uint32_t rest;            // electrons left for k_throw
+  bool overflow;
+};
+// wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift x_sub = x_pos - sub_scale
+// (exposure_generator.py:630-632).  The fma is written out: the fused k_lane sizes its LDS tile from this function
+// before it plans its bins with it, and the two evaluations have to agree to the bit.
+__device__ __forceinline__ void bin_position(const PrepArgs& a, double wl, const double* tr, double x_ref, double y_ref,
+                                             double* xs, double* ys) {
+  const double m_t = tr[0], c_t = tr[1], m_wl = tr[4], c_wl = tr[5];
+  const double x = (wl - c_wl) / m_wl;
+  const double y = fma(m_t, x - x_ref, c_t) + y_ref;
+  *xs = x - (double)a.sub_scale;
+  *ys = y - (double)a.sub_scale;
+}
+// The same position to ~1e-10 px without the division (tr[6] = 1 / m_wl): for bounding boxes, with a pixel to spare
+__device__ __forceinline__ void bin_position_bound(const PrepArgs& a, double wl, const double* tr, double x_ref, double y_ref,
+                                                   float* xs, float* ys) {
+  const double x = (wl - tr[5]) * tr[6];
+  const double y = fma(tr[0], x - x_ref, tr[1]) + y_ref;
+  *xs = (float)(x - (double)a.sub_scale);
+  *ys = (float)(y - (double)a.sub_scale);
+}
+// wl .. sigl_w: the bin's per-wavelength inputs; tr: the sub-sample's trace coefficients (k_prep_wl); depth: the
+// transit depth of (k, w) or 0
+__device__ __forceinline__ BinPlan plan_bin(const PrepArgs& a, int k, int w, double wl, double flux_w, double sens_w,
+                                            double dlam_w, double ratio_w, double sigl_w, const double* tr,
+                                            double x_ref, double y_ref, double dur, double depth) {
+  BinPlan o;
+  bin_position(a, wl, tr, x_ref, y_ref, &o.xs, &o.ys);
+  // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
+  //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
+  double f = flux_w;
+  if (a.depth) f = f * (1. - depth);
+  double lam = f * sens_w;
+  lam = lam * dlam_w;
+  lam = lam * 1e4;
+  lam = lam * dur;
+  lam = lam * 1e-3;
+  lam = lam * a.scale_factor;
+  double cnt;
+  if ((a.flags & (1u << 5)) != 0) {         // WAYNE_F_ADD_STELLAR_NOISE
+    PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
+    cnt = poisson_counts(lam, rng);         // np.random.poisson (:626)
+  } else {
+    cnt = rint(lam);                        // np.round, half to even (:628)
+  }
+  o.overflow = false;
+  if (!(cnt >= 0.)) cnt = 0.;               // negative / NaN flux throws no electrons
+  if (cnt > 2147483647.) { cnt = 2147483647.; o.overflow = true; }
+  const uint32_t c = (uint32_t)cnt;
+  o.count = c;
+  // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
+  const double nw = (double)(int32_t)c * ratio_w;
+  o.nwide = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
+  // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one multinomial by k_narrow;
+  // what is left to throw one by one -- its wide electrons, or the whole of a bin that does not qualify --
+  // is thrown by the bin's own lane in k_lane (no prefix search, no bin changes inside a lane's loop);
+  // only a bin with more than kLaneMax such electrons is shared out by k_throw
+  o.narrow = 0u; o.lane = 0u; o.rest = c;
+  if (a.nsplit) {
+    const uint32_t wide = (uint32_t)min(max(o.nwide, 0), (int32_t)min(c, 0x7FFFFFFFu));
+    const uint32_t narrow = c - wide;
+    const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sigl_w > 0.05 &&
+                       sigl_w * 6.5 <= (double)kNarrowR;
+    const uint32_t ind = split ? wide : c;                 // electrons thrown one by one
+    const bool lane = a.split_min > 0 && ind <= (uint32_t)a.lane_max;
+    o.narrow = split ? narrow : 0u;
+    o.lane = lane ? ind : 0u;
+    o.rest = lane ? 0u : ind;
+  }
+  return o;
+}
+
 // One workgroup per (sub-sample, chunk of kPrepThreads bins): positions, counts,
 // sigma split, and the chunk-local exclusive prefix; k_prep_fix then adds the chunk
 // offsets (when anything is left for k_throw: see the end of the kernel).
@@ -328,10 +415,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     for (int r = blockIdx.y * gridDim.x + blockIdx.x; r < ca.R; r += n_wg) { cosmic_hits(ca, r, &s_hits); __syncthreads(); }
   }
   const double x_ref = a.x_ref[k], y_ref = a.y_ref[k];
-  const double* s_tr = a.tr + 6 * (size_t)k;      // (wave-uniform: scalar loads)
-  const double m_t = s_tr[0], c_t = s_tr[1], m_wl = s_tr[4], c_wl = s_tr[5];
+  const double* s_tr = a.tr + kTrStride * (size_t)k;      // (wave-uniform: scalar loads)
   const double dur = a.dur_ms[k];
-  const bool noisy = (a.flags & (1u << 5)) != 0;  // WAYNE_F_ADD_STELLAR_NOISE
 
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
   bool overflow = false;
@@ -340,64 +425,28 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
   const int w = ch * kPrepThreads + tid;
   uint32_t c = 0;
   if (w < W) {
-      const double wl = a.wl[w];
-    // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift
-    // x_sub = x_pos - sub_scale (exposure_generator.py:630-632)
-    const double x = (wl - c_wl) / m_wl;
-    const double y = m_t * (x - x_ref) + c_t + y_ref;
-    const double xs = x - (double)a.sub_scale;
-    const double ys = y - (double)a.sub_scale;
-    a.xpos[(size_t)k * W + w] = xs;
-    a.ypos[(size_t)k * W + w] = ys;
-    // counts chain (exposure_generator.py:344-348, 602-628, 649-687):
-    //   F (1 - depth) * Sens * dlam[um] * 1e4 [A/um] * dur[ms] * 1e-3 [s/ms] * scale
-    double f = a.flux[w];
-    if (a.depth) f = f * (1. - a.depth[(size_t)k * W + w]);
-    double lam = f * a.wa.sens[w];
-    lam = lam * a.wa.dlam[w];
-    lam = lam * 1e4;
-    lam = lam * dur;
-    lam = lam * 1e-3;
-    lam = lam * a.scale_factor;
-    double cnt;
-    if (noisy) {
-      PhiloxStream rng(a.seed, STAGE_COUNTS, (uint32_t)w, (uint32_t)k, a.exposure);
-      cnt = poisson_counts(lam, rng);       // np.random.poisson (:626)
-    } else {
-      cnt = rint(lam);                      // np.round, half to even (:628)
-    }
-    if (!(cnt >= 0.)) cnt = 0.;             // negative / NaN flux throws no electrons
-    if (cnt > 2147483647.) { cnt = 2147483647.; overflow = true; }
-    c = (uint32_t)cnt;
-    a.counts[(size_t)k * W + w] = (int32_t)c;
-    // N = counts*psf_ratio truncated (pyparallel_menu.c:89), in fp64
-    double nw = (double)(int32_t)c * a.wa.ratio[w];
-    int32_t nwi = (nw >= 2147483647.) ? 2147483647 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1) : (int32_t)nw;
-    a.nwide[(size_t)k * W + w] = nwi;
+    const size_t kw = (size_t)k * W + w;
+    const BinPlan b = plan_bin(a, k, w, a.wl[w], a.flux[w], a.wa.sens[w], a.wa.dlam[w], a.wa.ratio[w], a.wa.sigl[w], s_tr,
+                               x_ref, y_ref, dur, a.depth ? a.depth[kw] : 0.);
+    a.xpos[kw] = b.xs;
+    a.ypos[kw] = b.ys;
+    a.counts[kw] = (int32_t)b.count;
+    a.nwide[kw] = b.nwide;
+    overflow = b.overflow;
+    c = b.count;
     if (c > 0) {
-      xmin = fmin(xmin, xs); xmax = fmax(xmax, xs);
-      ymin = fmin(ymin, ys); ymax = fmax(ymax, ys);
+      xmin = fmin(xmin, b.xs); xmax = fmax(xmax, b.xs);
+      ymin = fmin(ymin, b.ys); ymax = fmax(ymax, b.ys);
     }
-    // WAYNE_RNG_SPLIT: the narrow component of a well-populated bin is drawn as one multinomial by k_narrow;
-    // what is left to throw one by one -- its wide electrons, or the whole of a bin that does not qualify --
-    // is thrown by the bin's own lane in k_lane (no prefix search, no bin changes inside a lane's loop);
-    // only a bin with more than kLaneMax such electrons is shared out by k_throw
     if (a.nsplit) {
-      const uint32_t wide = (uint32_t)min(max(nwi, 0), (int32_t)min(c, 0x7FFFFFFFu));
-      const uint32_t narrow = c - wide;
-      const double sl = a.wa.sigl[w];
-      const bool split = a.split_min > 0 && narrow >= (uint32_t)a.split_min && narrow <= kSplitMaxNarrow && sl > 0.05 &&
-                         sl * 6.5 <= (double)kNarrowR;
-      const uint32_t ind = split ? wide : c;                 // electrons thrown one by one
-      const bool lane = a.split_min > 0 && ind <= (uint32_t)a.lane_max;
-      a.nsplit[(size_t)k * W + w] = split ? (int32_t)narrow : 0;
-      a.nlane[(size_t)k * W + w] = lane ? (int32_t)ind : 0;
-      n_split_total += (split ? narrow : 0u) + (lane ? ind : 0u);
-      c = lane ? 0u : ind;                                   // c: electrons left for k_throw
+      a.nsplit[kw] = (int32_t)b.narrow;
+      a.nlane[kw] = (int32_t)b.lane;
+      n_split_total += b.narrow + b.lane;
+      c = b.rest;                                            // c: electrons left for k_throw
       // launched without k_throw (the host expected no bin beyond a lane's reach) and here is one after all:
       // tell the host, which runs the exposure again with k_throw (wayne_hip.hip, check_status)
       if (a.fix_inline && c > 0u) atomicOr(a.status, 2);
-      if (a.no_narrow && split) atomicOr(a.status, 2);     // ... or without k_narrow, and here is a bin for it
+      if (a.no_narrow && b.narrow > 0u) atomicOr(a.status, 2);     // ... or without k_narrow, and here is a bin for it
     }
   }
   if (overflow) atomicOr(a.status, 1);

@@ -60,6 +60,9 @@ struct Slot {
   bool front_done = false;
   bool acc_dirty = false;
   bool acc_init = false;
+  bool fused_last = false;    // the last front half ran fused: positions / routing arrays were not written (debug_fetch)
+  PrepArgs last_prep{};       // ... and k_prep_sub's arguments of that run
+  int last_chunks = 0;
   bool force_throw = false;   // the last run met a bin beyond a lane's reach: run with k_throw (set by check_status)
   wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
   int W = 0, K = 0, R = 0;
@@ -577,9 +580,11 @@ void (*pick_ramp(bool f64, bool exact, int sky, bool noise))(RampArgs) {
 }
 
 template <int FLUSH>
-int launch_lane(wayne_ctx* c, const ThrowArgs& a, bool thin) {
+int launch_lane(wayne_ctx* c, const ThrowArgs& a, bool thin, const PrepArgs* fused_prep = nullptr, const CosmicArgs* fused_cosmic = nullptr) {
   const dim3 grid((unsigned)((a.K + a.kb - 1) / a.kb), (unsigned)((a.W + kLaneThreads - 1) / kLaneThreads));
-  if (a.kb > 1) {
+  if (fused_prep) {
+    hipLaunchKernelGGL((k_lane_fused<FLUSH>), grid, dim3(kLaneThreads), 0, c->stream, a, *fused_prep, *fused_cosmic);
+  } else if (a.kb > 1) {
     if (thin) hipLaunchKernelGGL((k_lane<FLUSH, true, true>), grid, dim3(kLaneThreads), 0, c->stream, a);
     else hipLaunchKernelGGL((k_lane<FLUSH, false, true>), grid, dim3(kLaneThreads), 0, c->stream, a);
   } else {
@@ -1011,7 +1016,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   HIP_TRY(c, s.xpos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.ypos.reserve(KW * sizeof(double)));
   HIP_TRY(c, s.sub.reserve((size_t)K * sizeof(SubInfo)));
-  HIP_TRY(c, s.tr.reserve((size_t)K * 6 * sizeof(double)));
+  HIP_TRY(c, s.tr.reserve((size_t)K * kTrStride * sizeof(double)));
   {
     const size_t n_chunks = (size_t)(W + kPrepThreads - 1) / kPrepThreads;
     if (n_chunks > (size_t)kMaxPrepChunks || W > 32768) return fail(c, WAYNE_E_INVALID, "upload: more than 32768 wavelength bins");
@@ -1043,8 +1048,8 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     // scan (K in the thousands) otherwise launches tens of thousands of workgroups of ~1000 electrons each
     const int n_chunks_l = (W + kLaneThreads - 1) / kLaneThreads;
     int kb = (int)(((long long)K * n_chunks_l) / 2048);
-    kb = std::min(std::max(kb, 1), 32);
-    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), 32);
+    kb = std::min(std::max(kb, 1), kLaneBatchMax);
+    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), kLaneBatchMax);
     s.kb = kb;
     // thin: the expected electrons of the fullest chunk in the longest sub-sample fit the flush list with room to spare
     s.thin = s.max_chunk_electrons <= 0.9 * kLaneListCap;
@@ -1124,9 +1129,12 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
   // takes the in-loop global-atomic path (see k_lane)
   bool skip_narrow = false;
   bool lane_unlimited = false;   // split mode without a k_throw launch: the lanes take every bin (up to kLaneReach)
+  bool fused = false;            // ... and no k_prep_sub either: k_lane<.., FUSED> plans its bins itself
   const int margin = d.thrower_margin > 0 ? d.thrower_margin : 30;
+  PrepArgs prep_args{};
+  CosmicArgs cosmic_args{};
   {
-    PrepArgs a{};
+    PrepArgs& a = prep_args;
     a.g = c->g;
     a.W = W; a.K = K; a.N = N;
     a.sub_scale = d.sub_scale;
@@ -1169,17 +1177,24 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     // flags the run, which is then repeated with every kernel (check_status)
     skip_narrow = lane_unlimited && s.max_narrow <= 6. && !std::getenv("WAYNE_KEEP_NARROW");
     a.no_narrow = skip_narrow ? 1 : 0;
-    CosmicArgs ca{};
+    CosmicArgs& ca = cosmic_args;
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
     ca.rate = (d.cosmic_rate >= 0.) ? d.cosmic_rate : -1.;
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
     ca.seg = s.seg.as<uint32_t>();
-    ProfScope ps(c, PK_PREP_SUB);
-    hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
-    HIP_TRY(c, hipGetLastError());
-    if (!a.fix_inline) {
-      hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
+    // thin exposure, nothing for k_throw or k_narrow expected: the lanes plan their bins themselves (k_lane, FUSED)
+    fused = lane_unlimited && skip_narrow && s.thin && !std::getenv("WAYNE_NO_FUSE");
+    s.fused_last = fused;
+    s.last_prep = a;
+    s.last_chunks = n_chunks;
+    if (!fused) {
+      ProfScope ps(c, PK_PREP_SUB);
+      hipLaunchKernelGGL(k_prep_sub, dim3(K, n_chunks), dim3(kPrepThreads), 0, c->stream, a, ca);
       HIP_TRY(c, hipGetLastError());
+      if (!a.fix_inline) {
+        hipLaunchKernelGGL(k_prep_fix, dim3(K), dim3(kPrepThreads), 0, c->stream, a, n_chunks);
+        HIP_TRY(c, hipGetLastError());
+      }
     }
   }
   {
@@ -1259,7 +1274,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
       if (rc) return rc;
       if (d.rng_mode == WAYNE_RNG_SPLIT) {
         ProfScope ps(c, PK_LANE);
-        if ((rc = launch_lane<1>(c, a, s.thin))) return rc;
+        if ((rc = fused ? launch_lane<1>(c, a, true, &prep_args, &cosmic_args) : launch_lane<1>(c, a, s.thin))) return rc;
       }
       if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join[si_], 0));
     }
@@ -1438,6 +1453,16 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
   use_slot_stream(c, slot);
   const size_t KW = (size_t)s.K * s.W;
   if (counts) HIP_TRY(c, hipMemcpyAsync(counts, s.counts.p, KW * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (s.fused_last && (x_pos || y_pos)) {
+    // a fused front half kept no positions: k_prep_sub works them out now (same code, same inputs; its cosmic-ray
+    // stage off and its electron count into a spare counter)
+    PrepArgs a = s.last_prep;
+    a.total_electrons = c->counters.as<unsigned long long>() + 1;
+    CosmicArgs off{};
+    off.rate = -1.;
+    hipLaunchKernelGGL(k_prep_sub, dim3(s.K, s.last_chunks), dim3(kPrepThreads), 0, c->stream, a, off);
+    HIP_TRY(c, hipGetLastError());
+  }
   if (x_pos) HIP_TRY(c, hipMemcpyAsync(x_pos, s.xpos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (y_pos) HIP_TRY(c, hipMemcpyAsync(y_pos, s.ypos.p, KW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   {
