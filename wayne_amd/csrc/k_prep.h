@@ -326,13 +326,14 @@ struct BinPlan {
   bool overflow;
 };
 // wl_to_x / wl_to_y (grism.py:651, 667-669), then the sub-array shift x_sub = x_pos - sub_scale
-// (exposure_generator.py:630-632).  The fma is written out: the fused k_lane sizes its LDS tile from this function
-// before it plans its bins with it, and the two evaluations have to agree to the bit.
+// (exposure_generator.py:630-632).  Product and sum are rounded separately, as numpy rounds them (never contracted
+// into an fma, whatever the compiler's flags): k_prep_sub and the fused k_lane both evaluate this function and have to
+// agree with each other, and with the oracle, to the bit.
 __device__ __forceinline__ void bin_position(const PrepArgs& a, double wl, const double* tr, double x_ref, double y_ref,
                                              double* xs, double* ys) {
   const double m_t = tr[0], c_t = tr[1], m_wl = tr[4], c_wl = tr[5];
   const double x = (wl - c_wl) / m_wl;
-  const double y = fma(m_t, x - x_ref, c_t) + y_ref;
+  const double y = __dadd_rn(__dmul_rn(m_t, x - x_ref), c_t) + y_ref;
   *xs = x - (double)a.sub_scale;
   *ys = y - (double)a.sub_scale;
 }
