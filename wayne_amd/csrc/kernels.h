@@ -9,6 +9,7 @@
 //                                  flushed x flat into the read-interval accumulator                     (A1-A4, A11, A12)
 //   k_narrow.h      k_narrow       narrow PSF component as one multinomial per bin
 //                   k_lane         a bin's one-by-one electrons (wide component, thin bins) thrown by its own lane
+//                   k_lane_fused   thin exposures: k_lane planning its bins itself (plan_bin of k_prep.h), no k_prep_sub
 //   k_ramp.h        k_ramp         fused up-the-ramp kernel: sky, gain, cumulative, dark, non-linearity,
 //                                  clip, reference pixels, zero read, read noise                          (A13-A15)
 //
