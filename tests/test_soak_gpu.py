@@ -135,6 +135,44 @@ def test_fused_thin_path_equals_the_three_kernel_path(name, scale, monkeypatch):
     np.testing.assert_array_equal(a2, b)
 
 
+@pytest.mark.parametrize("case", ["nan_and_negative_flux", "off_the_frame", "one_bright_bin"])
+def test_fused_thin_path_on_hostile_inputs(case, monkeypatch):
+    # the fused kernel sizes its LDS tile before it knows the counts: inputs that leave the sane range -- NaN and
+    # negative flux (no electrons), a reference position far off the frame (no tile at all: every electron takes the
+    # bounds-checked path and is dropped), one bin a thousand times brighter than the host's estimate can know
+    # (status bit 1: the exposure is run again with k_prep_sub, k_narrow and k_throw) -- must come out as from
+    # the three-kernel sequence, bit for bit
+    v = helpers.make_visit("tiny")
+    kw = v.frame_kwargs(0, scale_factor=0.4)
+    if case == "nan_and_negative_flux":
+        flux = np.array(kw["stellar_flux"], dtype=float)
+        flux[::7] = np.nan
+        flux[3::11] = -flux[3::11]
+        kw = dict(kw, stellar_flux=flux)
+    elif case == "off_the_frame":
+        kw = dict(kw, x_ref=kw["x_ref"] + 3000.0, y_ref=kw["y_ref"] - 2500.0)
+    else:
+        sig = np.array(kw["planet_signal"], dtype=float)
+        sig[:, sig.shape[1] // 2] = -2000.0
+        kw = dict(kw, planet_signal=sig)
+    pg = helpers.product_generator(v, 0)
+    rec_f, rec_u = {}, {}
+    a = np.stack([r[0] for r in pg.scanning_frame(record=rec_f, **kw).reads])
+    monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+    b = np.stack([r[0] for r in pg.scanning_frame(record=rec_u, **kw).reads])
+    monkeypatch.delenv("WAYNE_NO_FUSE")
+    for key in ("counts", "acc"):
+        np.testing.assert_array_equal(rec_f[key], rec_u[key], err_msg=key)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all()
+    if case == "off_the_frame":
+        assert rec_f["acc"].sum() == 0 and rec_f["counts"].sum() > 1000
+    if case == "one_bright_bin":
+        assert rec_f["counts"].max() > 1000
+    if case == "nan_and_negative_flux":
+        assert (rec_f["counts"][:, ::7] == 0).all() and rec_f["counts"].sum() > 1000
+
+
 @pytest.mark.parametrize("name,kw_over", [("small256", {}), ("tiny_g102", {}), ("cfg5", {"E": 2e6, "K": 16}),
                                           ("stare256", {})])
 def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):
