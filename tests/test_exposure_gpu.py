@@ -77,6 +77,39 @@ def test_prep_counts_with_stellar_poisson_over_six_decades():
     assert (a != b).mean() < 1e-5
 
 
+@pytest.mark.parametrize("table", ["gaps", "two_points", "dense", "off_band"])
+def test_sensitivity_tables_of_any_spacing(table):
+    # k_prep_wl finds a bin's interval of the sensitivity table (np.interp, grism.py:116-118) by a proportional guess
+    # and bisects only where that fails: tables that are far from uniform -- clustered points with a wide gap, the
+    # minimum of two points, one denser than the bins, one that covers only part of the band (clamped outside) -- must
+    # give the oracle's counts exactly
+    import copy
+    from wayne_amd import calibration as calmod, detector, grism, synthetic
+    rng = np.random.default_rng(5)
+    cal = copy.copy(helpers.calibration_set())
+    wl0, val0 = cal.sens["G141"]
+    if table == "gaps":
+        wl = np.sort(np.concatenate([rng.uniform(1.0, 1.18, 150), rng.uniform(1.52, 1.8, 7), [1.0, 1.8]]))
+    elif table == "two_points":
+        wl = np.array([1.05, 1.72])
+    elif table == "dense":
+        wl = np.sort(rng.uniform(0.9, 1.9, 20000)) ** 1.0
+    else:
+        wl = np.linspace(1.25, 1.45, 37) + rng.uniform(0, 2e-3, 37)
+    cal.sens = dict(cal.sens, G141=(wl, np.interp(wl, wl0, val0) * (1 + 0.2 * np.sin(40 * wl))))
+    gr = grism.G141(cal)
+    v = synthetic.Visit("tiny", detector.WFC3_IR(), gr, cal, n_exposures=1, seed=3)
+    kw = v.frame_kwargs(0, **DET_OFF)
+    pg = helpers.product_generator(v, 0)
+    rec = {}
+    pg.scanning_frame(rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64, record=rec, threads=2, **kw)
+    eo = helpers.oracle_generator(v)
+    orec = {}
+    eo.scanning_frame(threads=2, draws=wo.PhiloxDraws(v.seed, 0, 64), thrower="oracle", record=orec, **helpers.oracle_kwargs(kw))
+    np.testing.assert_array_equal(rec["counts"], np.stack(orec["counts"]))
+    assert rec["counts"].sum() > 1000
+
+
 @pytest.mark.parametrize("name,flat", [("tiny", True), ("tiny", False), ("small256", True)])
 def test_accumulated_electrons_replay_thrower_and_flat(name, flat):
     v, got, want, rec, orec = run_both(name, **dict(DET_OFF, add_flat=flat))
