@@ -4,7 +4,7 @@ one gpurun call (boxes differ by a few per cent, runs on one box by ~0.5 %):
 
     cp ab/A.so wayne_amd/libwayne_hip.so && python scripts/ab_kernels.py cfg5 && cp ab/B.so wayne_amd/libwayne_hip.so && ...
 
-    python scripts/ab_kernels.py [config=cfg5] [exposures=40]
+    python scripts/ab_kernels.py [config=cfg5] [exposures=40] [rng_mode=2 (0 replay, 1 every electron, 2 split)]
 """
 import os
 import sys
@@ -17,6 +17,7 @@ from wayne_amd.exposure_generator import ExposureGenerator  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 cal = calibration.CalibrationSet.synthetic(11)
 det = detector.WFC3_IR()
 gr = grism.G141(cal) if synthetic.CONFIGS[name]["grism"] == "G141" else grism.G102(cal)
@@ -26,7 +27,7 @@ ctx = eng.ctx
 slots = 10
 for j in range(slots):
     eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
-    ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=2, **v.frame_kwargs(j)))
+    ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, threads=2, **v.frame_kwargs(j)))
 for j in range(slots):
     ctx.run(2 * j)
 ctx.synchronize()

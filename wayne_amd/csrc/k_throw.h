@@ -352,28 +352,73 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
       uint32_t lcg = lcg_jump((uint32_t)(25234 + 17 * part + si.replay_seed), 6ull * (uint64_t)(e - part_start_of(part)));
       double x = XP[b], y = YP[b];
       double sl = a.sigl[b], sh = a.sigh[b];
+      // The fp64 Box-Muller below is what the reference computes (pyparallel_menu.c:57-61, 87-93) and ~400 fp64
+      // instructions per electron.  Its outcome is two integers, and a float32 evaluation on the hardware's sin / cos /
+      // log2 / sqrt units (~30 instructions) gives the same two integers unless the position falls within the float32
+      // path's error of a pixel boundary: THEN, and only then, the fp64 code runs (one electron in ~5000; a wave takes
+      // the branch for ~1 % of its iterations).  The error bound is measured, not estimated -- exhaustively over the
+      // 2^31 values of a rand_r call (scripts/ubench/replay_fast_error.hip, profiles/r03/replay_fast_error.txt):
+      // |cos32 - cos64|, |sin32 - sin64| <= 2.7e-7; |R32 - R64| <= 3.0e-6 for R >= 0.01 (<= 5.8e-7 for R >= 0.1) -- so
+      // the offset R sigma (cos, sin) is good to sigma (3.0e-6 + 6.56 x 2.7e-7) = 4.8e-6 sigma plus three float32
+      // roundings of numbers below 64 (1.2e-5): `band` below is twice that.  R < 0.01 (5e-5 of the electrons), a
+      // zero rand_r, positions or sigmas out of the sane range: fp64.  The frames stay the reference's bit for bit
+      // (tests/test_psf_gpu.py: the 13 golden frames and random inputs; tests/test_fullsize_oracle_gpu.py: 10^9
+      // electrons against the compiled reference C, no accumulator differs).
+      struct Fast { int ix, iy; float fx, fy, sl, sh; bool ok; };
+      auto fast_of = [](double x_, double y_, double sl_, double sh_) {
+        Fast f;
+        f.ok = fabs(x_) < 1e6 && fabs(y_) < 1e6 && sl_ > 0. && sl_ < 1e3 && sh_ > 0. && sh_ < 1e3;
+        const double flx = floor(x_), fly = floor(y_);
+        f.ix = f.ok ? (int)flx : 0; f.iy = f.ok ? (int)fly : 0;
+        f.fx = (float)(x_ - flx); f.fy = (float)(y_ - fly);
+        f.sl = (float)sl_; f.sh = (float)sh_;
+        return f;
+      };
+      Fast fb = fast_of(x, y, sl, sh);
       for (; e < e_end; ++e) {
         if (e >= bin_end) {
           do { ++b; bin_start = bin_end; bin_end = P[b + 1]; } while (bin_end <= e && b + 1 < W);
           wide_end = bin_start + (uint32_t)max(NW[b], 0);
           x = XP[b]; y = YP[b]; sl = a.sigl[b]; sh = a.sigh[b];
+          fb = fast_of(x, y, sl, sh);
         }
         while (e >= part_end && part + 1 < T) {   // next emulated thread: fresh stream
           ++part;
           part_end = (part == T - 1) ? E : part_start_of(part + 1);
           lcg = (uint32_t)(25234 + 17 * part + si.replay_seed);
         }
-        // pyparallel_menu.c:57-61
-        const double theta = 2. * kPi * rand_r_step(lcg) / ((double)2147483647);
-        const double R = sqrt(-2. * log(rand_r_step(lcg) / ((double)2147483647)));
-        const double zx = R * cos(theta);
-        const double zy = R * sin(theta);
-        const double sig = (e < wide_end) ? sh : sl;
-        const double px = zx * sig + x, py = zy * sig + y;
-        // (int) of a non-finite / out-of-range double: reject (x86 gives INT_MIN)
-        const bool okx = (px > -2147483649.0 && px < 2147483648.0);
-        const bool oky = (py > -2147483649.0 && py < 2147483648.0);
-        const int xi = okx ? (int)px : -1, yi = oky ? (int)py : -1;
+        const int k1 = rand_r_step(lcg), k2 = rand_r_step(lcg);
+        const bool wide = e < wide_end;
+        int xi, yi;
+        {
+          const float sg = wide ? fb.sh : fb.sl;
+          const float rev = (float)k1 * 4.656612873077393e-10f;          // k1 2^-31 revolutions
+          const float kf = (float)k2;
+          // log2(k2 2^-31) = (e - 31) + log2 m, (float)k2 = m 2^e, m in [0.5, 1)
+          const float t = (float)(__builtin_amdgcn_frexp_expf(kf) - 31) + __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(kf));
+          const float r2 = t * -1.3862943611198906f;                     // R^2 = -2 ln u
+          const float Rs = __builtin_amdgcn_sqrtf(r2) * sg;
+          const float sx = fmaf(__builtin_amdgcn_cosf(rev), Rs, fb.fx);  // position - floor(bin position)
+          const float sy = fmaf(__builtin_amdgcn_sinf(rev), Rs, fb.fy);
+          const float flx = floorf(sx), fly = floorf(sy);
+          const float band = fmaf(sg, 1e-5f, 2.5e-5f) + (fabsf(sx) + fabsf(sy)) * 2.4e-7f;
+          const float gx = sx - flx, gy = sy - fly;
+          const bool sure = fb.ok && r2 >= 1e-4f && gx > band && gx < 1.f - band && gy > band && gy < 1.f - band;
+          xi = fb.ix + (int)flx; yi = fb.iy + (int)fly;
+          if (!sure) {
+            // pyparallel_menu.c:57-61
+            const double theta = 2. * kPi * k1 / ((double)2147483647);
+            const double R = sqrt(-2. * log(k2 / ((double)2147483647)));
+            const double zx = R * cos(theta);
+            const double zy = R * sin(theta);
+            const double sig = wide ? sh : sl;
+            const double px = zx * sig + x, py = zy * sig + y;
+            // (int) of a non-finite / out-of-range double: reject (x86 gives INT_MIN)
+            const bool okx = (px > -2147483649.0 && px < 2147483648.0);
+            const bool oky = (py > -2147483649.0 && py < 2147483648.0);
+            xi = okx ? (int)px : -1; yi = oky ? (int)py : -1;
+          }
+        }
         const int lx = xi - tx0, ly = yi - ty0;
         if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
           atomicAdd(&tile[ly * tw + lx], 1);
