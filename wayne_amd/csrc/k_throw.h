@@ -153,9 +153,17 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
   // XCD-aware block -> (sub-sample, split): blocks b and b+8 share an XCD
   // (and its L2); keep all splits of a sub-sample, which read the same
   // prefix / bin arrays and flush to the same frame region, on one XCD.
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int k = (local / a.splits) * 8 + xcd;
-  const int s = local % a.splits;
+  // Fewer than 8 sub-samples (wayne_psf_apply: one): that rule would leave XCDs idle -- the one sub-sample of a
+  // psf_apply call ran on an eighth of the chip -- so the splits go round the XCDs instead (grid = K * splits).
+  int k, s;
+  if (a.K < 8) {
+    k = (int)(blockIdx.x % (unsigned)a.K);
+    s = (int)(blockIdx.x / (unsigned)a.K);
+  } else {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    k = (local / a.splits) * 8 + xcd;
+    s = local % a.splits;
+  }
   if (k >= a.K) return;
   const SubInfo si = a.sub[k];
   const uint32_t E = si.electrons;

@@ -543,7 +543,7 @@ int thrower_lds_ints(const wayne_ctx*, int splits, int margin) {
 template <int RNG, int FLUSH>
 int launch_throw(wayne_ctx* c, const ThrowArgs& a, int lds_ints) {
   const int groups = (a.K + 7) / 8;
-  const dim3 grid((unsigned)(groups * 8 * a.splits));
+  const dim3 grid((unsigned)(a.K < 8 ? a.K * a.splits : groups * 8 * a.splits));   // (k_throw: block -> (sub-sample, split))
   const size_t lds = (size_t)lds_ints * sizeof(int);
   HIP_TRY(c, hipFuncSetAttribute((const void*)k_throw<RNG, FLUSH>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
