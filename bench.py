@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
   roofline      the fused up-the-ramp kernel k_ramp against the HBM roof
   cpu_baseline  the reference's C thrower + the numpy restatement of the host
                 loop, timed on this box's host cores on a bounded sample
-  per_electron / replay_bit_exact / out_f64 / two_streams / delivered / end_to_end
+  per_electron / replay_bit_exact / out_f64 / two_streams / delivered / end_to_end / psf_apply_replay
                 the same workload measured like-for-like with the reference
                 (every electron thrown; float64 reads) and through the host
                 pipeline (PCIe-inclusive) -- never `value`
@@ -439,6 +439,28 @@ def main():
                                 "note": "per exposure: host descriptor (K-vectors) -> upload -> k_lightcurve + all kernels -> "
                                         "reads in pinned host memory; VisitRunner, device light curves (no K x W upload), "
                                         "median of 3 passes of %d" % n_d}
+
+        # (6) the inner drop-in boundary by itself: wayne_psf_apply (= pyparallel.apply_psf, pyparallel.pyx:14-38) for one
+        # sub-sample of this workload -- host arrays in, the frame out, replay mode (the reference's frame bit for bit)
+        if rank == 0:
+            rng = np.random.default_rng(3)
+            shape = visit.stellar_flux / visit.stellar_flux.sum()
+            counts = rng.poisson(shape * visit.E / visit.K).astype(np.int32)
+            xs = np.linspace(560.0, 700.0, counts.size)
+            ys = 300.0 + 0.01 * (xs - 560.0)
+            polys = [np.polyval(getattr(visit.grism, n_), visit.wl) for n_ in ("psf_ratio_poly", "psf_sigmal_poly", "psf_sigmah_poly")]
+            side = eng.N
+            for j in range(3):
+                ctx.psf_apply(counts, xs, ys, polys[0], polys[1], polys[2], side, side, 7 + j, 4, _lib.RNG_REPLAY)
+            n_calls = 30
+            t = time.perf_counter()
+            for j in range(n_calls):
+                ctx.psf_apply(counts, xs, ys, polys[0], polys[1], polys[2], side, side, 7 + j, 4, _lib.RNG_REPLAY)
+            dt = (time.perf_counter() - t) / n_calls
+            extras["psf_apply_replay"] = {"ms_per_call": dt * 1e3, "electrons_per_s": float(counts.sum()) / dt,
+                                          "electrons_per_call": int(counts.sum()),
+                                          "note": "wayne_psf_apply through the C ABI, rng_mode REPLAY, threads 4: one sub-sample "
+                                                  "of the workload, host arrays in and the %d x %d frame out (PCIe-inclusive)" % (side, side)}
 
     if rank == 0:
         N, S, R, K = eng.N, eng.S, eng.R, visit.K

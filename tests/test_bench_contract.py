@@ -36,6 +36,8 @@ def test_bench_line_has_the_contract_keys():
     for key in ("per_electron", "per_electron_f64", "replay_bit_exact", "out_f64", "two_streams", "delivered", "end_to_end"):
         assert d[key]["unit"] == "exposures/s" and d[key]["value"] > 10, key
     assert d["replay_bit_exact"]["value"] < d["per_electron"]["value"] < d["value"]
+    pa = d["psf_apply_replay"]          # the inner drop-in boundary, PCIe-inclusive
+    assert 0.01 < pa["ms_per_call"] < 50 and pa["electrons_per_call"] > 1e6 and pa["electrons_per_s"] > 1e9
     # the sustained pass: seconds of back-to-back exposures, reported beside `value`
     sus = d["sustained"]
     assert sus["unit"] == "exposures/s" and sus["seconds"] >= 2.0 and sus["steps"] >= 1000
