@@ -41,6 +41,57 @@ def test_replay_mode_random_inputs_against_oracle(gpu_ctx, threads):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["on_the_grid", "tiny_sigma", "huge_sigma", "many_electrons", "with_reference_c"])
+def test_replay_mode_where_the_float32_path_must_hand_over(gpu_ctx, case):
+    # the replay thrower evaluates a position in float32 and keeps the result only outside a band around the pixel
+    # boundaries (k_throw.h); these inputs sit on the band's edges: bin positions exactly on pixel corners and centres
+    # (a symmetric PSF then puts half of the electrons within rounding of a boundary... of a coordinate), sigmas from
+    # 1e-4 px (every electron inside the band of its bin's pixel: all fp64) to 300 px (most electrons off the frame,
+    # float32 spacing of the offsets ~1e-5 px), and 2e7 electrons in a few bins (long rand_r streams, the partition of
+    # 7 emulated threads).  Frames must equal the oracle's -- and the compiled reference C's -- bit for bit
+    rng = np.random.RandomState(11)
+    N, threads = 128, 7
+    if case == "on_the_grid":
+        W = 400
+        x = rng.randint(2, N - 2, W).astype(float) + rng.choice([0.0, 0.5, 1.0 - 2 ** -40, 2 ** -40], W)
+        y = rng.randint(2, N - 2, W).astype(float) + rng.choice([0.0, 0.5], W)
+        sl, sh = rng.uniform(0.3, 1.0, W), rng.uniform(3, 8, W)
+        counts = rng.poisson(300, W)
+    elif case == "tiny_sigma":
+        W = 300
+        x, y = rng.uniform(1, N - 1, W), rng.uniform(1, N - 1, W)
+        x[::3] = np.round(x[::3])                       # on a boundary with a PSF of 1e-4 px: both sides get electrons
+        sl, sh = np.full(W, 1e-4), rng.choice([1e-4, 1e-3, 0.02], W)
+        counts = rng.poisson(500, W)
+    elif case == "huge_sigma":
+        W = 200
+        x, y = rng.uniform(-50, N + 50, W), rng.uniform(-50, N + 50, W)
+        sl, sh = rng.uniform(20, 60, W), rng.uniform(100, 300, W)
+        counts = rng.poisson(2000, W)
+    elif case == "many_electrons":
+        W = 5
+        x, y = rng.uniform(40, 90, W), rng.uniform(40, 90, W)
+        sl, sh = rng.uniform(0.4, 0.9, W), rng.uniform(4, 7, W)
+        counts = np.array([4_000_000, 1, 9_000_000, 0, 7_000_000])
+    else:
+        if not clib.have_ref():
+            pytest.skip("oracle/_ref not built")
+        W = 1500
+        x = np.sort(rng.uniform(5, N - 5, W))
+        y = 0.5 * N + 0.01 * x
+        sl, sh = rng.uniform(0.4, 0.9, W), rng.uniform(4, 7, W)
+        counts = rng.poisson(900, W)
+    ratio = rng.uniform(0, 1, W)
+    counts = counts.astype(np.int32)
+    got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 4242, threads, rng_mode=0)
+    if case == "with_reference_c":
+        want = clib.psf_reference(counts, x, y, ratio, sl, sh, N, N, 4242, threads)
+    else:
+        want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, 4242, threads)
+    np.testing.assert_array_equal(got, want)
+    assert got.sum() > 0
+
+
 def test_apply_psf_dropin_signature_and_dtype(gpu_ctx):
     from wayne_amd import pyparallel
     k = load_golden_psf("s64_t3")
