@@ -157,9 +157,7 @@ class Exposure(object):
             hdus.append(fitsio.HDU(fitsio.Header(cards), np.asarray(data, dtype=np.float64), name="SCI"))
             for ext in ("ERR", "DQ", "SAMP", "TIME"):
                 hdus.append(fitsio.HDU(fitsio.Header([("EXTVER", i + 1, "")]), None, name=ext))
-        if os.path.exists(path):
-            os.remove(path)
-        fitsio.write(path, hdus)
+        fitsio.write(path, hdus)        # (replaces an existing file, as the reference's remove + writeto does: exposure.py:211-213)
         return path
 
 

@@ -234,11 +234,13 @@ def _header_bytes(cards):
     return (text + " " * pad).encode("ascii")
 
 
-def _image_hdu_bytes(data, extra_cards, primary, name=None):
+def _image_hdu_parts(data, extra_cards, primary, name=None):
+    """[header bytes, payload (a big-endian array's buffer, or b""), zero padding] of one image HDU."""
     cards = [("SIMPLE", True, "conforms to FITS standard")] if primary else [("XTENSION", "IMAGE", "Image extension")]
     if data is None:
         cards += [("BITPIX", 8, ""), ("NAXIS", 0, "")]
         payload = b""
+        nbytes = 0
     else:
         a = np.asarray(data)
         code = a.dtype.kind + str(a.dtype.itemsize)
@@ -248,7 +250,11 @@ def _image_hdu_bytes(data, extra_cards, primary, name=None):
         cards += [("BITPIX", _DTYPE_BITPIX[code], ""), ("NAXIS", a.ndim, "")]
         for i, n in enumerate(a.shape[::-1], 1):
             cards.append(("NAXIS%d" % i, n, ""))
-        payload = np.ascontiguousarray(a, dtype=a.dtype.newbyteorder(">")).tobytes()
+        # (the byte-swapped copy is written from its own buffer: no second copy into a bytes object, no third into
+        # header + payload + padding)
+        swapped = np.ascontiguousarray(a, dtype=a.dtype.newbyteorder(">"))
+        payload = memoryview(swapped.reshape(-1)).cast("B") if swapped.size else b""
+        nbytes = swapped.nbytes
     if primary:
         cards.append(("EXTEND", True, ""))
     else:
@@ -260,13 +266,22 @@ def _image_hdu_bytes(data, extra_cards, primary, name=None):
         if k in reserved or k.startswith("NAXIS") or (k == "EXTNAME" and name):
             continue
         cards.append((k, v, c))
-    pad = (-len(payload)) % BLOCK
-    return _header_bytes(cards) + payload + b"\x00" * pad
+    return [_header_bytes(cards), payload, b"\x00" * ((-nbytes) % BLOCK)]
 
 
 def write(path, hdus):
-    """Write [HDU, ...]; the first becomes the primary HDU."""
-    with open(path, "wb") as f:
+    """Write [HDU, ...]; the first becomes the primary HDU.  An existing file is replaced."""
+    with open(path, "wb", buffering=0) as f:
+        small = []                      # consecutive header / padding pieces go out in one write
         for i, h in enumerate(hdus):
             cards = h.header.cards if isinstance(h.header, Header) else list(h.header or [])
-            f.write(_image_hdu_bytes(h.data, cards, primary=(i == 0), name=h.name or None))
+            head, payload, pad = _image_hdu_parts(h.data, cards, primary=(i == 0), name=h.name or None)
+            small.append(head)
+            if len(payload):
+                f.write(b"".join(small))
+                small = []
+                f.write(payload)
+            if pad:
+                small.append(pad)
+        if small:
+            f.write(b"".join(small))
