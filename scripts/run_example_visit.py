@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """End-to-end timing of an example-shaped visit through the CLI entry point (GPU only).
 
-    python scripts/run_example_visit.py [n_exposures=121] [outdir]
+    python scripts/run_example_visit.py [n_exposures=121] [outdir] [ranks]
+
+`ranks` > 1: `python -m wayne_amd.run_visit -p ... --gpus ranks` as a child process, its rank processes sharing device 0
+(WAYNE_SHARE_GPU=1) -- on a small sub-array the visit is bound by one interpreter's lock (descriptor building + FITS
+headers), not by the GPU, and several ranks on one GPU are the way past it.
 
 Writes a parameter file with the settings of the reference's example visit
 (examples/hd209458b_12181_simulation_parameters.yml: G141 spatial scan, SUBARRAY 256,
@@ -115,6 +119,21 @@ def main():
             make(self, *a, **k)
             self.ctx.profile_enable(True)
         engine.Engine.__init__ = make_and_profile
+    ranks = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if ranks > 1:
+        import subprocess
+        env = dict(os.environ, WAYNE_SHARE_GPU="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        t0 = time.perf_counter()
+        subprocess.check_call([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(work, "params.yml"),
+                               "--gpus", str(ranks)], env=env)
+        dt = time.perf_counter() - t0
+        out = os.path.join(work, "simulated")
+        files = [f for f in os.listdir(out) if f.endswith("_raw.fits")]
+        size = sum(os.path.getsize(os.path.join(out, f)) for f in files)
+        print("example-shaped visit, %d rank processes on one GPU: %d exposures in %.2f s = %.1f exposures/s end to end "
+              "(interpreter start-up of the ranks included), %d FITS files, %.1f MB"
+              % (ranks, len(files), dt, len(files) / dt, len(files), size / 1e6))
+        return
     t0 = time.perf_counter()
     obs = run_visit.run(["-p", os.path.join(work, "params.yml")])
     dt = time.perf_counter() - t0

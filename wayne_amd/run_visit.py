@@ -152,7 +152,7 @@ def run(argv=None):
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" in os.environ and args.gpus not in (1, world_env):
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world_env, args.gpus))
-    if os.environ.get("WAYNE_SHARE_GPU") == "1":       # rehearsal on a one-GPU box: every rank on device 0
+    if os.environ.get("WAYNE_SHARE_GPU") == "1":       # every rank on device 0: a one-GPU box, or several ranks per GPU on small sub-arrays
         args.device = 0
     launch.pin_to_gpu_numa(args.device)
     with open(args.parameter_file) as f:
