@@ -3,8 +3,8 @@
 
     python scripts/run_example_visit.py [n_exposures=121] [outdir] [ranks]
 
-`ranks` > 1: `python -m wayne_amd.run_visit -p ... --gpus ranks` as a child process, its rank processes sharing device 0
-(WAYNE_SHARE_GPU=1) -- on a small sub-array the visit is bound by one interpreter's lock (descriptor building + FITS
+`ranks` > 1: `python -m wayne_amd.run_visit -p ... --gpus 1 --ranks-per-gpu ranks` as a child process, its rank
+processes sharing device 0 -- on a small sub-array the visit is bound by one interpreter's lock (descriptor building + FITS
 headers), not by the GPU, and several ranks on one GPU are the way past it.
 
 Writes a parameter file with the settings of the reference's example visit
@@ -122,10 +122,10 @@ def main():
     ranks = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     if ranks > 1:
         import subprocess
-        env = dict(os.environ, WAYNE_SHARE_GPU="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         t0 = time.perf_counter()
         subprocess.check_call([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(work, "params.yml"),
-                               "--gpus", str(ranks)], env=env)
+                               "--gpus", "1", "--ranks-per-gpu", str(ranks)], env=env)
         dt = time.perf_counter() - t0
         out = os.path.join(work, "simulated")
         files = [f for f in os.listdir(out) if f.endswith("_raw.fits")]

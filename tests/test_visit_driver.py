@@ -264,10 +264,11 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_starts_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("how", ["gpus_2_sharing_device_0", "ranks_per_gpu_2"])
+def test_cli_starts_its_own_ranks(tmp_path, how):
     # `python -m wayne_amd.run_visit --gpus 2`: the parent starts two rank processes before anything touches a GPU
-    # (here both on device 0: WAYNE_SHARE_GPU=1); each writes its round-robin share; every file equals the one a
-    # single process writes
+    # (here both on device 0: WAYNE_SHARE_GPU=1) -- or `--gpus 1 --ranks-per-gpu 2`, two ranks to the one GPU, the
+    # form for small sub-arrays; each writes its round-robin share; every file equals the one a single process writes
     import shutil
     import subprocess
     import sys
@@ -275,11 +276,16 @@ def test_cli_starts_its_own_ranks(tmp_path):
     shutil.copytree(MINI, one)
     shutil.copytree(MINI, two)
     obs = run_visit.run(["-p", os.path.join(one, "params.yml"), "--max-exposures", "4"])
-    env = dict(os.environ, WAYNE_SHARE_GPU="1", PYTHONPATH=ROOT)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "WAYNE_SHARE_GPU"):
         env.pop(k, None)
+    if how == "gpus_2_sharing_device_0":
+        env["WAYNE_SHARE_GPU"] = "1"
+        ranks = ["--gpus", "2"]
+    else:
+        ranks = ["--gpus", "1", "--ranks-per-gpu", "2"]
     out = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(two, "params.yml"),
-                          "--max-exposures", "4", "--gpus", "2"], capture_output=True, text=True, timeout=900, env=env,
+                          "--max-exposures", "4"] + ranks, capture_output=True, text=True, timeout=900, env=env,
                          cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "2 ranks done" in out.stdout

@@ -16,7 +16,8 @@ examples/hd209458b_12181_simulation_parameters.yml): sections `general`
   * `--gpus G`: the process starts G rank processes itself (one per GPU of this node, before anything touches a
     GPU) and waits for them; under an external launcher (WORLD_SIZE / RANK set, one process per GPU) it is one
     rank.  Each rank generates its round-robin share of the exposures (observation.py:403-405 is the axis) on the
-    CPUs of its GPU's NUMA node.
+    CPUs of its GPU's NUMA node.  `--ranks-per-gpu R` starts G x R ranks, R to a GPU (rank r on device r // R):
+    on small sub-arrays a visit is bound by one interpreter's lock, not by the GPU.
 """
 import argparse
 import os
@@ -136,22 +137,28 @@ def run(argv=None):
     ap.add_argument("--calibration", default=None, help="directory holding the WFC3 calibration FITS files")
     ap.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     ap.add_argument("--max-exposures", type=int, default=None, help="only the first M exposures")
-    ap.add_argument("--gpus", type=int, default=1, help="start this many rank processes, one per GPU of this node")
+    ap.add_argument("--gpus", type=int, default=1, help="start rank processes, one per GPU of this node")
+    ap.add_argument("--ranks-per-gpu", type=int, default=1, help="... and this many to a GPU (small sub-arrays)")
     args = ap.parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus < 1 or args.ranks_per_gpu < 1:
+        raise SystemExit("--gpus and --ranks-per-gpu must be at least 1")
+    n_ranks = args.gpus * args.ranks_per_gpu
+    if n_ranks > 1 and "WORLD_SIZE" not in os.environ:
         # the launcher: nothing in this process has touched a GPU; the children are ranks of a fresh interpreter each
         child = [a for a in (sys.argv[1:] if argv is None else list(argv))]
         cmd = [sys.executable, "-m", "wayne_amd.run_visit"] + child
         extra = {"PYTHONPATH": os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
                                                [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])}
-        codes, _ = launch.launch_ranks(args.gpus, cmd, extra_env=extra)
+        codes, _ = launch.launch_ranks(n_ranks, cmd, extra_env=extra)
         if any(codes):
             raise SystemExit("run_visit: rank exit codes %s" % codes)
-        print("run_visit: %d ranks done" % args.gpus)
+        print("run_visit: %d ranks done" % n_ranks)
         return None
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" in os.environ and args.gpus not in (1, world_env):
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world_env, args.gpus))
+    if "WORLD_SIZE" in os.environ and n_ranks not in (1, world_env):
+        raise SystemExit("WORLD_SIZE (%d) != --gpus x --ranks-per-gpu (%d)" % (world_env, n_ranks))
+    if args.ranks_per_gpu > 1 and "LOCAL_RANK" in os.environ:
+        args.device = int(os.environ["LOCAL_RANK"]) // args.ranks_per_gpu
     if os.environ.get("WAYNE_SHARE_GPU") == "1":       # every rank on device 0: a one-GPU box, or several ranks per GPU on small sub-arrays
         args.device = 0
     launch.pin_to_gpu_numa(args.device)
