@@ -15,12 +15,8 @@ sys.path.insert(0, ROOT)
 from oracle import clib  # noqa: E402  (the checker: test infrastructure)
 from wayne_amd import _lib  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-ctx = _lib.default_context(0)
-bad = 0
-electrons = 0
-for case in range(n_cases):
+def case(rng):
+    """One random input of PSF() inside the reference's valid domain."""
     W = int(rng.integers(1, 4000))
     N = int(rng.choice([16, 33, 64, 100, 256, 512, 1014]))
     threads = int(rng.integers(1, 17))
@@ -40,16 +36,33 @@ for case in range(n_cases):
     # normals for -- pyparallel_menu.c:89-106 reads past its array -- and the restatement clamps instead)
     ratio = np.clip(rng.uniform(-0.1, 1.1, W), 0.0, 1.0)
     test = int(rng.integers(0, 2 ** 31 - 1 - 25234 - 17 * 16))
-    if int(counts.sum()) * threads >= 2 ** 31:
-        continue
-    want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, test, threads)
-    got = ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, test, threads, rng_mode=0)
-    ok = np.array_equal(got, want)
-    if ok and clib.have_ref() and case % 5 == 0:
-        ok = np.array_equal(got, clib.psf_reference(counts, x, y, ratio, sl, sh, N, N, test, threads))
-    electrons += int(counts.sum())
-    if not ok:
-        bad += 1
-        print("case %d DIFFERS: W=%d N=%d threads=%d electrons=%d off=%d" % (case, W, N, threads, counts.sum(), np.abs(got.astype(np.int64) - want).sum() // 2), flush=True)
-print("soak_replay %s: %d cases, %.3g electrons, %d frames differ" % ("ok" if bad == 0 else "FAILED", n_cases, electrons, bad))
-sys.exit(1 if bad else 0)
+    return counts, x, y, ratio, sl, sh, N, test, threads
+
+
+def run(ctx, n_cases, seed, verbose=True):
+    """-> (frames that differ, electrons thrown)"""
+    rng = np.random.default_rng(seed)
+    bad = electrons = 0
+    for i in range(n_cases):
+        counts, x, y, ratio, sl, sh, N, test, threads = case(rng)
+        if int(counts.sum()) * threads >= 2 ** 31:
+            continue
+        want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, test, threads)
+        got = ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, test, threads, rng_mode=0)
+        ok = np.array_equal(got, want)
+        if ok and clib.have_ref() and i % 5 == 0:
+            ok = np.array_equal(got, clib.psf_reference(counts, x, y, ratio, sl, sh, N, N, test, threads))
+        electrons += int(counts.sum())
+        if not ok:
+            bad += 1
+            if verbose:
+                print("case %d DIFFERS: W=%d N=%d threads=%d electrons=%d" % (i, counts.size, N, threads, counts.sum()), flush=True)
+    return bad, electrons
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad, electrons = run(_lib.default_context(0), n_cases, seed)
+    print("soak_replay %s: %d cases, %.3g electrons, %d frames differ" % ("ok" if bad == 0 else "FAILED", n_cases, electrons, bad))
+    sys.exit(1 if bad else 0)

@@ -92,6 +92,18 @@ def test_replay_mode_where_the_float32_path_must_hand_over(gpu_ctx, case):
     assert got.sum() > 0
 
 
+def test_replay_soak_against_the_restatement_and_the_reference_c(gpu_ctx):
+    # a fixed-seed stretch of scripts/soak_replay.py: random bins, frames from 16 to 1014 pixels, PSF widths from 1e-3 to
+    # 200 px, 1-16 emulated threads, positions on and off the frame and on pixel boundaries, a bin of 10^5-10^6 electrons
+    # now and then -- every frame equal to the CPU restatement's, every fifth also to the compiled reference C's
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_replay
+    bad, electrons = soak_replay.run(gpu_ctx, 60, 4)
+    assert bad == 0 and electrons > 1e6
+
+
 def test_apply_psf_dropin_signature_and_dtype(gpu_ctx):
     from wayne_amd import pyparallel
     k = load_golden_psf("s64_t3")
