@@ -985,6 +985,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   // the slot is unusable until this call has succeeded: a failure half way leaves re-pointed views behind
   s.uploaded = false;
   s.front_done = false;
+  s.fused_last = false;      // (last_prep points into buffers this call may re-allocate)
   int rc;
   const size_t KW = (size_t)K * W;
   {
