@@ -1,0 +1,241 @@
+"""GPU: the PRODUCTION thrower modes (WAYNE_RNG_SPLIT in production math -- flags = 0 -- and WAYNE_RNG_PHILOX) against
+the reference's compiled C thrower IN DISTRIBUTION.
+
+The replay mode reproduces the reference's frames bit for bit (tests/test_psf_gpu.py); the modes `bench.py` times
+cannot -- the reference's frame is one sample of a law, theirs another sample of (what must be) the same law.  So:
+ensembles.  For each input, M frames of `oracle/_ref` (wayne/pyparallel_menu.c compiled unmodified; different `test`
+seeds, `threads` 1 and 4 alternating) beside M' frames of each device mode through the C ABI (wayne_psf_apply), and both
+beside the exact per-pixel moments of the reference's algorithm (tests/ensemble_stats.py: sums of binomials, closed
+form).  Every approximation of the production path -- float32 Box-Muller on the hardware's log2 / sqrt / sin / cos,
+one 32-bit word per electron (16-bit radius with a refined far cell, 23-bit angle), the Chebyshev fit of erfc, the
+6.5 sigma cut and +-6 px window of the multinomial chains, float32 cell masses, pooled rows of 16 bins -- is inside
+these frames; the tests see their SUM.
+
+Inputs (all from the reference's own golden vectors, tests/golden/psf_*.npz):
+  bright   s256_t4 counts x 60: 9.7e6 electrons, 2165 per bin -> nearly every bin's narrow component is a multinomial
+           draw (k_narrow, pooled rows), its wide component lane-thrown (k_lane)
+  thin     s256_t4 counts clipped below 32 and thinned: every electron is thrown one by one by its bin's lane
+  edge     edge_low counts x 20: a trace along pixel row 1 that runs off the frame's left edge (x from -6): 38 % of
+           the electrons are lost, row 0 / column 0 must stay empty
+
+Bands are 5 standard errors of each figure's known sampling distribution (ensemble_stats.check / check_moments), plus
+the small stated floors for the non-gaussianity of counts.  The measured values of every figure are written to
+gpurun_out/ensemble_parity.json by the tests themselves (committed copy: profiles/r04/ensemble_parity.json).
+
+Then the same at exposure level (small256: SUBARRAY 256, NSAMP 4, 9 sub-samples, 3e6 electrons): production
+exposures (split thrower, float32 reads, hardware-math samplers, Philox streams) beside exposures of the oracle driven
+by the reference's C thrower and numpy's legacy generator in the reference's call order
+(`ExposureOracle(thrower="ref", draws=LegacyDraws)`): per-pixel mean and variance of the last read inside the
+trace (stellar Poisson + scatter + flat + gain + non-linearity + dark + read noise), outside it (sky + dark + read
+noise: exposure_generator.py:488-495, detector.py:185-198) and in the reference pixels (zero read + read noise).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ensemble_stats as es
+import helpers
+from conftest import load_golden_psf
+from oracle import clib
+from oracle import wayne_oracle as wo
+from wayne_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    #          golden      scale  clip  M_ref  M_dev
+    "bright": ("s256_t4",  60,    None, 48,    256),
+    "thin":   ("s256_t4",  1,     31,   400,   1200),
+    "edge":   ("edge_low", 20,    None, 64,    400),
+}
+_cache = {}
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "ensemble_parity.json")
+
+
+def report(key, **figures):
+    """Keep the measured figures next to the bands (gpurun_out/ensemble_parity.json -> profiles/rNN/)."""
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        d = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        d[key] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in figures.items()}
+        json.dump(d, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def case_inputs(name):
+    golden, scale, clip, m_ref, m_dev = CASES[name]
+    k = load_golden_psf(golden)
+    counts = k["counts"].astype(np.int64) * scale
+    if clip is not None:
+        counts = np.minimum(counts, clip)
+        counts[::3] //= 4
+    return k, counts.astype(np.int32), m_ref, m_dev
+
+
+def reference_ensemble(name):
+    """M frames of the reference's compiled C thrower, with the exact moments of its law (cached per session)."""
+    if name not in _cache:
+        if not clib.have_ref():
+            pytest.skip("oracle/_ref not built")
+        k, counts, m_ref, _ = case_inputs(name)
+        n = k["nr"]
+        tests = np.random.RandomState(5).randint(0, 100000, m_ref)        # exposure_generator.py:327
+        A = np.stack([clib.psf_reference(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, int(tests[m]),
+                                         1 if m % 2 == 0 else 4).reshape(n, n) for m in range(m_ref)])
+        _cache[name] = (A, es.analytic_moments(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n))
+    return _cache[name]
+
+
+def device_ensemble(ctx, name, mode):
+    k, counts, _, m_dev = case_inputs(name)
+    n = k["nr"]
+    return np.stack([ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, 1963 + m // 64,
+                                   rng_mode=mode, exposure=m, subsample=m % 5).reshape(n, n) for m in range(m_dev)])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_reference_ensemble_follows_the_exact_moments(name):
+    # pins tests/ensemble_stats.analytic_moments (truncation, row / column 0, the deterministic sigma split) to the
+    # reference itself before anything is compared with it
+    A, (mean, var, var_other, _) = reference_ensemble(name)
+    s = es.compare_with_moments(A, mean, var, var_other)
+    report("psf/%s/reference_vs_exact_moments" % name, **s)
+    bad = es.check_moments(s)
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.parametrize("mode", [_lib.RNG_SPLIT, _lib.RNG_PHILOX], ids=["split", "philox"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_production_thrower_against_reference_ensemble(gpu_ctx, name, mode):
+    k, counts, _, _ = case_inputs(name)
+    A, (mean, var, var_other, _) = reference_ensemble(name)
+    B = device_ensemble(gpu_ctx, name, mode)
+    assert B.min() >= 0
+    # two-sample: device ensemble beside the reference's
+    two = es.compare(B, A, k["x"], k["y"])
+    bad = es.check(two, require_subpoisson=0.95 if name != "thin" else None)
+    # one-sample: device ensemble against the exact moments of the reference's law (the sharper test: M' >> M)
+    one = es.compare_with_moments(B, mean, var, var_other)
+    bad += es.check_moments(one)
+    tag = "split" if mode == _lib.RNG_SPLIT else "philox"
+    report("psf/%s/%s_vs_reference" % (name, tag), **two)
+    report("psf/%s/%s_vs_exact_moments" % (name, tag), **one)
+    if name == "bright":
+        # the variance law is the reference's deterministic split N = (int)(counts * ratio) (pyparallel_menu.c:89),
+        # not a per-electron (or per-pixel Poisson) one: in the core of the trace the two differ by > 4 %
+        assert one["n_split"] >= 200 and one["other_over_exact"] > 1.03
+        off = (1.0 - one["split_ratio_other"]) / one["split_se"]
+        if off < 5.0:
+            bad.append("core variance does not exclude the random-split law: %.1f sigma" % off)
+    assert not bad, "%s / mode %d: %s\n%r\n%r" % (name, mode, "; ".join(bad), two, one)
+
+
+def test_split_and_philox_ensembles_agree_with_each_other(gpu_ctx):
+    # product against product on a fourth input (the full-array golden, x 2): two large ensembles, tight bands
+    k = load_golden_psf("s1014_t4")
+    counts = (k["counts"].astype(np.int64) * 2).astype(np.int32)
+    n = k["nr"]
+    x0, x1 = int(k["x"].min()) - 40, int(k["x"].max()) + 40
+    y0, y1 = int(k["y"].min()) - 40, int(k["y"].max()) + 40
+    ens = {}
+    for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX):
+        fr = []
+        for m in range(96):
+            f = gpu_ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, 77, rng_mode=mode,
+                                  exposure=m, subsample=3).reshape(n, n)
+            assert f.sum() == f[y0:y1, x0:x1].sum() == counts.sum()      # reach: nothing beyond 6.9 sigma_h
+            fr.append(f[y0:y1, x0:x1].copy())
+        ens[mode] = np.stack(fr)
+    side = max(ens[_lib.RNG_SPLIT].shape[1:])
+    pad = [np.pad(e, ((0, 0), (0, side - e.shape[1]), (0, side - e.shape[2]))) for e in ens.values()]
+    s = es.compare(pad[0], pad[1], k["x"] - x0, k["y"] - y0)
+    s["row0"] = s["col0"] = 0.0          # cropped window: its first row / column are ordinary pixels
+    report("psf/s1014_t4_x2/split_vs_philox", **s)
+    bad = es.check(s)
+    assert not bad, "; ".join(bad) + "\n%r" % s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# exposure level
+# ---------------------------------------------------------------------------------------------------------------
+def _exposure_ensembles(m_dev=200, m_ref=100):
+    key = ("exposures", m_dev, m_ref)
+    if key not in _cache:
+        if not clib.have_ref():
+            pytest.skip("oracle/_ref not built")
+        v = helpers.make_visit("small256")
+        off = dict(cosmic_rate=None)      # 15 hits of 10-35 ke per exposure would swamp every pixel variance; the
+        #                                   cosmic-ray statistics have their own test (tests/test_configs_gpu.py)
+        kw = v.frame_kwargs(0, **off)
+        dev = []
+        for m in range(m_dev):
+            pg = helpers.product_generator(v, m)                 # exposure index m: independent streams
+            dev.append(np.array(pg.scanning_frame(**kw).reads[-1][0], dtype=np.float64))
+        eo = helpers.oracle_generator(v)
+        okw = helpers.oracle_kwargs(kw)
+        ref = [eo.scanning_frame(threads=2 if m % 2 else 1, draws=wo.LegacyDraws(4000 + m), thrower="ref",
+                                 **okw)[-1] for m in range(m_ref)]
+        # where the star's electrons land, from a run of its own with every noise source off (a mask taken from either
+        # ensemble would select on that ensemble's noise and bias the comparison): last read less the initial bias frame
+        quiet = dict(add_stellar_noise=False, sky_background=0.0, add_dark=False, add_read_noise=False, cosmic_rate=None)
+        star = eo.scanning_frame(threads=1, draws=wo.LegacyDraws(1), thrower="ref",
+                                 **helpers.oracle_kwargs(v.frame_kwargs(0, **quiet)))[-1] - eo._gen_zero_read(True)
+        _cache[key] = (v, np.stack(dev), np.stack(ref), star)
+    return _cache[key]
+
+
+def _region_stats(D, R, sel):
+    """Two-sample per-pixel figures of float frames over the pixels `sel`."""
+    Md, Mr = D.shape[0], R.shape[0]
+    md, mr = D.mean(axis=0)[sel], R.mean(axis=0)[sel]
+    vd, vr = D.var(axis=0, ddof=1)[sel], R.var(axis=0, ddof=1)[sel]
+    z = (md - mr) / np.sqrt(vd / Md + vr / Mr)
+    n = int(sel.sum())
+    nu = (1.0 / Md + 1.0 / Mr) ** 2 / (1.0 / (Md * Md * (Md - 1.0)) + 1.0 / (Mr * Mr * (Mr - 1.0)))
+    lr = np.log(vd / vr) + 1.0 / (Md - 1) - 1.0 / (Mr - 1)
+    return dict(n=n, z_mean=float(z.mean()), z_mean_se=1.0 / np.sqrt(n), z_std=float(z.std(ddof=1)),
+                z_std_expect=float(np.sqrt(nu / (nu - 2.0))), z_std_se=float(1.0 / np.sqrt(2.0 * n)),
+                log_var=float(lr.mean()), log_var_se=float(np.sqrt(2.0 / (Md - 1) + 2.0 / (Mr - 1)) / np.sqrt(n)),
+                mean_d=float(md.mean()), mean_r=float(mr.mean()), var_d=float(vd.mean()), var_r=float(vr.mean()))
+
+
+def test_production_exposures_against_reference_driven_oracle_ensemble():
+    v, D, R, star = _exposure_ensembles()
+    S = D.shape[1]
+    interior = np.zeros((S, S), dtype=bool)
+    interior[5:-5, 5:-5] = True
+    inside = interior & (star > 30.0)            # DN of starlight in the last read
+    outside = interior & (star < 0.5)
+    # the read-noise-only pixels: the 5-px reference border
+    border = ~interior
+    assert inside.sum() > 4000 and outside.sum() > 40000
+    bad = []
+    for name, sel, jitter_floor in (("inside", inside, 0.02), ("outside", outside, 0.0), ("border", border, 0.0)):
+        s = _region_stats(D, R, sel)
+        report("exposure/small256/%s" % name, **s)
+        # the per-sub-sample pointing jitter (0.025 px, exposure_generator.py:328-329) moves neighbouring pixels of the
+        # trace together, so their z are correlated: the floor on the mean allows for that inside the trace only
+        if abs(s["z_mean"]) > 5.0 * s["z_mean_se"] + jitter_floor:
+            bad.append("%s: pixel means differ, mean z %.4f (se %.4f)" % (name, s["z_mean"], s["z_mean_se"]))
+        if abs(s["z_std"] - s["z_std_expect"]) > 5.0 * s["z_std_se"] + 0.02:
+            bad.append("%s: spread of z %.4f, expected %.4f" % (name, s["z_std"], s["z_std_expect"]))
+        if abs(s["log_var"]) > 5.0 * s["log_var_se"] + 0.01:
+            bad.append("%s: pixel variances differ, mean log ratio %.4f (se %.4f)" % (name, s["log_var"],
+                                                                                    s["log_var_se"]))
+    # the background's variance is what the reference's stages say it is (e-: sky; DN: / 2.35, dark error, read noise)
+    dt = float(v.read_times[-1])
+    sky_e = float(v.sky[0]) * dt                                       # master sky ~ 1 (synthetic: mean 1)
+    expect = sky_e / 2.35 ** 2 + (14.1 / 2.35) ** 2
+    s_out = _region_stats(D, R, outside)
+    for label, got in (("device", s_out["var_d"]), ("oracle", s_out["var_r"])):
+        if abs(got / expect - 1.0) > 0.05:
+            bad.append("%s background variance %.2f DN^2, expected ~%.2f" % (label, got, expect))
+    # and the border's is the read noise alone: (14.1 / 2.35)^2 (detector.py:33, 193-198)
+    s_b = _region_stats(D, R, border)
+    for label, got in (("device", s_b["var_d"]), ("oracle", s_b["var_r"])):
+        if abs(got / (14.1 / 2.35) ** 2 - 1.0) > 0.03:
+            bad.append("%s border variance %.2f DN^2" % (label, got))
+    assert not bad, "; ".join(bad)
