@@ -281,7 +281,8 @@ void wayne_oracle_sky_alias_table(double lam, uint32_t *out /* 256 */) {
   }
 }
 
-/* One sky draw per pixel from its STAGE_SKY stream, advancing the state.
+/* One sky draw per pixel from the stream whose state is handed in (the pixel's STAGE_READ stream, between the
+ * normals of two reads: wayne_amd/csrc/philox.h), advancing the state.
  * table_of[i] selects the pixel's 256-entry table, lam_level[i] is the rate the
  * table was built for, lam[i] the pixel's own rate (float32 arithmetic). */
 void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const int32_t *table_of,

@@ -521,16 +521,23 @@ class PhiloxDraws(object):
         self._sky_next += 1
         lam32 = np.ascontiguousarray(lam, dtype=np.float32).ravel()
         out = np.empty(lam32.size)
-        state = self._stream("sky", self.interior_idx, STAGE_SKY)
         plan = getattr(self, "_sky_plan", None)
         if plan is None:
+            # the direct sampler (a data-dependent number of words per draw) has a stream of its own
+            state = self._stream("sky", self.interior_idx, STAGE_SKY)
             clib.lib().wayne_oracle_poisson_sky_step(lam32, lam32.size, state, out)
             return out.reshape(lam.shape)
+        # the table-driven draw reads the pixel's STAGE_READ stream, between the normals of read r (0 = zero read) and
+        # those of read r + 1 (philox.h): bring the stream to that point, then step the interior pixels' states
+        self._read_pair(r)
+        st_all = self._stream("read", self.all_idx, STAGE_READ)
+        state = np.ascontiguousarray(st_all[self.interior_idx])
         j = [i for i, d in enumerate(plan["distinct"]) if d.tobytes() == np.float32(bg_count).tobytes()][0]
         lvl = plan["lvl"].ravel()
         lam_level = np.ascontiguousarray((plan["levels"][lvl] * np.float32(bg_count)).astype(np.float32))
         table_of = np.ascontiguousarray((j * plan["L"] + lvl).astype(np.int32))
         clib.lib().wayne_oracle_sky_alias_step(lam32, lam_level, table_of, plan["tables"].ravel(), lam32.size, state, out)
+        st_all[self.interior_idx] = state
         return out.reshape(lam.shape)
 
     def cosmic_frame(self, rate, time, size, r):
@@ -549,7 +556,8 @@ class PhiloxDraws(object):
         return array
 
     def _read_pair(self, r):
-        # words 2i, 2i+1 of every pixel's STAGE_READ stream belong to read i (0 = zero read)
+        # the pair of normals of read i (0 = zero read) from every pixel's STAGE_READ stream; the table-driven sky
+        # draw of read interval i takes its words from the same stream right after them (sky_poisson)
         st = self._stream("read", self.all_idx, STAGE_READ)
         while len(self._pairs) <= r:
             self._pairs.append(self._normal_step(st))

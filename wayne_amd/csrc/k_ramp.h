@@ -150,87 +150,72 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
   return k;
 }
 
-// sky_draw in production math with the pixel's remainder mean m and e^-m handed in: both change only when the read
-// interval does (SPARS sequences repeat theirs), so the read loop keeps them from one read to the next.
-template <class RNG>
-__device__ __forceinline__ float sky_draw_cached(const uint32_t* tab, float m, float em, RNG& rng) {
-  uint32_t w, wr;
-  rng.next2(w, wr);
-  const uint32_t idx = w >> 24;
-  const uint32_t e = tab[idx];
-  const float k = (float)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
-  // count how many of the first cumulative probabilities e^-m (1, 1 + m, 1 + m + m^2/2, ...) lie below u -- four
-  // compares, no loop, no division -- and only when u lies beyond them all (for m = 1: 4e-3 of the draws) continue
-  // the search (m = 0: e^-m = 1 >= u, nothing drawn)
-  const float u = u01f(wr);
-  float t = em, cdf = t, j = 0.f;
-  j += (u > cdf) ? 1.f : 0.f;  t = t * m;                 cdf += t;
-  j += (u > cdf) ? 1.f : 0.f;  t = t * (m * 0.5f);         cdf += t;
-  j += (u > cdf) ? 1.f : 0.f;  t = t * (m * 0.33333334f);  cdf += t;
-  j += (u > cdf) ? 1.f : 0.f;
-  if (u > cdf) {
-    for (int it = 4; it < 512; ++it) {
-      t = t * FastMath::div_(m, (float)it);
-      cdf += t;
-      if (!(u > cdf)) break;
-      j = j + 1.f;
-    }
-  }
-  return k + j;
-}
-
-// sky_draw_cached with the count kept in integers: the same words, the same compares, the same count (the
-// production read loop adds it to the accumulator's fixed-point value before that is converted).
-template <class RNG>
-__device__ __forceinline__ int sky_draw_count(const uint32_t* tab, float m, float em, RNG& rng) {
-  uint32_t w, wr;
-  rng.next2(w, wr);
-  const uint32_t idx = w >> 24;
-  const uint32_t e = tab[idx];
-  const int k = (int)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
-  const float u = u01f(wr);
-  float t = em, cdf = t;
-  int j = (u > cdf) ? 1 : 0;   t = t * m;                 cdf += t;
-  j += (u > cdf) ? 1 : 0;      t = t * (m * 0.5f);         cdf += t;
-  j += (u > cdf) ? 1 : 0;      t = t * (m * 0.33333334f);  cdf += t;
-  j += (u > cdf) ? 1 : 0;
-  if (u > cdf) {
-#pragma nounroll
-    for (int it = 4; it < 512; ++it) {
-      t = t * FastMath::div_(m, (float)it);
-      cdf += t;
-      if (!(u > cdf)) break;
-      j = j + 1;
-    }
-  }
-  return k + j;
-}
-
-// nonlinear_response for the production variant (float32 reads): Newton on the GAP g = px - u, which is what the
-// non-linearity takes off a pixel -- at most ~5 % of it -- so float32 carries it to ~1e-7 of ITS size, i.e. to
-// < 1e-3 DN at full well, where the float32 read itself rounds at 4e-3 DN:
-//     u (1 + c1 + c2 u + c3 u^2 + c4 u^3) = px   <=>   g = u h(u),  h(u) = c1' + c2 u + c3 u^2 + c4 u^3,  u = px - g
-// (c1' = fl(1 + c1) - 1: the reference adds 1 to the float32 plane in float32, detector.py:339).  Same warm start,
-// same stop (|step| < 1e-3), same derivative as nonlinear_response; one fp64 subtraction at the end instead of an
-// fp64 residual per iteration.
-__device__ __forceinline__ double nonlinear_gap(double px, float c1p, float c2, float c3, float c4, NlState& st) {
+// nonlinear_gap with the pixel value itself in float32 (the all-float32 production chain, see ramp_body): the same
+// iteration, the same stop, the same state; returns u = px - g rounded once.
+__device__ __forceinline__ float nonlinear_gap_f32(float px, float c1p, float c2, float c3, float c4, NlState& st) {
   const float d1 = 1.0f + c1p, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
-  const float pxf = (float)px;
-  float g = fmaf(pxf - st.v_prev, st.bend, st.gap);
+  float g = fmaf(px - st.v_prev, st.bend, st.gap);
   float rinv = 1.0f;
   for (int it = 0; it < 64; ++it) {
-    const float u = pxf - g;
+    const float u = px - g;
     const float h = fmaf(u, fmaf(u, fmaf(u, c4, c3), c2), c1p);
     const float fp_ = fmaf(u, fmaf(u, fmaf(u, d4, d3), d2), d1);
     rinv = __builtin_amdgcn_rcpf(fp_);
-    const float step = fmaf(u, h, -g) * rinv;          // Newton on phi(g) = u h(u) - g,  phi' = -f'(u)
+    const float step = fmaf(u, h, -g) * rinv;
     g = g + step;
     if (fabsf(step) < 1e-3f) break;
   }
-  st.v_prev = pxf;
+  st.v_prev = px;
   st.gap = g;
   st.bend = 1.0f - rinv;
-  return px - (double)g;
+  return px - g;
+}
+
+// The remainder's first four cumulative probabilities e^-m (1, 1 + m, 1 + m + m^2/2, 1 + ... + m^3/6) as 32-bit integer
+// thresholds of the random WORD: u01f(w) > c  <=>  w > c 2^32 up to the float32 rounding of u01f (6e-8 of the draws
+// decide differently from the float compare -- the hardware e^-m is itself only good to 1e-6).  They change only
+// when the read interval does, so the read loop keeps them in registers: the search is then four integer compares
+// feeding v_addc, with no conversion of the word.  (v_cvt_u32_f32 saturates: c >= 1 -> 0xFFFFFFFF, never exceeded.)
+struct SkyRem {
+  float m;                   // the pixel's remainder mean (sky_px - level) * bg_count
+  uint32_t t0, t1, t2, t3;
+  float c3, term3;           // the float cdf and its last term, for the rare continuation beyond four
+  __device__ __forceinline__ void set(float m_) {
+    m = m_;
+    float em;
+    asm volatile("v_exp_f32 %0, %1" : "=v"(em) : "v"(-1.4426950408889634f * m_));   // (volatile: not to be speculated into every read)
+    float t = em, cdf = t;
+    t0 = (uint32_t)(cdf * 4294967296.f);  t = t * m_;                  cdf += t;
+    t1 = (uint32_t)(cdf * 4294967296.f);  t = t * (m_ * 0.5f);         cdf += t;
+    t2 = (uint32_t)(cdf * 4294967296.f);  t = t * (m_ * 0.33333334f);  cdf += t;
+    t3 = (uint32_t)(cdf * 4294967296.f);
+    c3 = cdf; term3 = t;
+  }
+};
+
+template <class RNG>
+__device__ __forceinline__ int sky_draw_count_int(const uint32_t* tab, const SkyRem& sr, RNG& rng) {
+  uint32_t w, wr;
+  rng.next2(w, wr);
+  const uint32_t idx = w >> 24;
+  const uint32_t e = tab[idx];
+  int k = (int)(((w & 0xFFFFFFu) < (e & 0xFFFFFFu)) ? idx : (e >> 24));
+  k += (wr > sr.t0) ? 1 : 0;
+  k += (wr > sr.t1) ? 1 : 0;
+  k += (wr > sr.t2) ? 1 : 0;
+  if (wr > sr.t3) {
+    k += 1;
+    const float u = u01f(wr);
+    float t = sr.term3, cdf = sr.c3;
+#pragma nounroll
+    for (int it = 4; it < 512; ++it) {
+      t = t * FastMath::div_(sr.m, (float)it);
+      cdf += t;
+      if (!(u > cdf)) break;
+      k = k + 1;
+    }
+  }
+  return k;
 }
 
 // Phase 1 of k_ramp: the sky Poisson draws of one pixel for all reads
@@ -290,7 +275,7 @@ __device__ __forceinline__ void sky_counts(const RampArgs& a, uint32_t p, int ti
 // remainder in pieces (a master sky with hot pixels)
 // NOISE: the optional gaussian noise stage (noise_mean / noise_std; off in every shipped configuration) is
 // compiled in or out: its stream would otherwise hold four registers of a kernel that lives at the 64-VGPR limit
-template <class OutT, bool FAST, int SKY, bool NOISE>
+template <class OutT, bool FAST, int SKY, bool NOISE, bool ALLON>
 __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   constexpr bool ALIAS = SKY != 0;
   typedef typename std::conditional<FAST, FastMath, ExactMath<float> >::type M;
@@ -337,10 +322,15 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
     for (int l = 1; l < a.sky_levels; ++l) sky_lvl += (a.sky_level[l] <= skyv) ? 1 : 0;
   const float sky_base = a.sky_level[sky_lvl];
 
-  // per-pixel streams, seeded only when the stage is on (one Philox block each)
-  SeededStream rn, rg, rs;
-  if (ALIAS && skyv > 0.f) rs = SeededStream(a.seed, STAGE_SKY, (uint32_t)p, 0u, a.exposure);
-  if (rdn || do_dark) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  // per-pixel streams, seeded only when a stage that reads them is on (one Philox block each).  ONE stream (STAGE_READ)
+  // serves the table-driven sky draw and the two normals of every read, in the order the read loop takes them: pair 0 =
+  // the zero read's normals, then per read interval r the words of its sky draw (a pair; none where the pixel has no
+  // sky) followed by the pair of read r + 1's normals.  A second Philox block per pixel for the sky alone was 6 % of the
+  // kernel's vector instructions.  (The direct sampler, SKY = 0, draws a data-dependent number of words per read and
+  // keeps its own stream, STAGE_SKY: sky_counts.)
+  SeededStream rn, rg;
+  if (rdn || do_dark || (ALIAS && do_sky)) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  SeededStream& rs = rn;
   if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
 
   // Buffer addressing: descriptor (scalar) + the lane's 32-bit byte offset (vector, loop constant) + the plane's
@@ -427,79 +417,87 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
-  float sky_c = -1.f, sky_m = 0.f, sky_em = 1.f;
+  float sky_c = -1.f;
+  SkyRem srem;
+  srem.m = 0.f; srem.t0 = srem.t1 = srem.t2 = srem.t3 = 0xFFFFFFFFu; srem.c3 = 1.f; srem.term3 = 0.f;
   if (std::is_same<OutT, float>::value && FAST && SKY == 1 && !NOISE) {
-    // PRODUCTION VARIANT (float32 reads, hardware math, alias-table sky, no gaussian-noise stage): the same
-    // stages, streams and draws as the generic loop below with the arithmetic cut to what a float32 read needs --
-    // the sky count joins the accumulator as an integer, one fp64 fma takes fixed point -> DN -> cumulative sum,
-    // dark and read noise are float32 fmas, the non-linearity is solved on the gap in float32 (nonlinear_gap), and
-    // the per-read numbers (bg_count, first table) come in scalar registers, so that what depends on them alone is
-    // recomputed only when the read interval changes.  Against the exact / float64 variants: <= 0.02 DN + 2e-7
-    // (tests/test_modes_gpu.py, tests/test_fullsize_oracle_gpu.py).
-    const double inv_gq = inv_g * kInvQ;                   // accumulator unit -> DN
-    const float c1p = (1.0f + c1) - 1.0f;
-    const float zf = (float)z;
-    uint32_t bg_prev = 0xFFFFFFFFu;                        // bits of the previous read's bg (a scalar, like bg)
-#ifndef WAYNE_RAMP_PF
-#define WAYNE_RAMP_PF 1                                    // reads whose planes are in flight ahead of the one in work
-#endif
-    constexpr int PF = WAYNE_RAMP_PF;
-    long long qn[PF];
-    float dsn[PF], den[PF];
-    qn[0] = q_next; dsn[0] = ds_next; den[0] = de_next;
-#pragma unroll
-    for (int i = 1; i < PF; ++i) {
-      qn[i] = 0; dsn[i] = den[i] = 0.f;
-      if (i < a.R) {
-        if (interior && acc_live(i)) qn[i] = ld_acc(i);
-        if (ld_dark) { dsn[i] = ld_f32(rs_ds, i); den[i] = ld_f32(rs_de, i); }
-      }
-    }
-    for (int r = 0; r < a.R; ++r) {
-      const long long q = qn[0];
-      const float ds = dsn[0], de = den[0];
-#pragma unroll
-      for (int i = 0; i + 1 < PF; ++i) { qn[i] = qn[i + 1]; dsn[i] = dsn[i + 1]; den[i] = den[i + 1]; }
-      qn[PF - 1] = 0;
-      if (r + PF < a.R) {
-        if (interior && acc_live(r + PF)) qn[PF - 1] = ld_acc(r + PF);
-        if (ld_dark) { dsn[PF - 1] = ld_f32(rs_ds, r + PF); den[PF - 1] = ld_f32(rs_de, r + PF); }
-      }
-      const float bg = __int_as_float(__builtin_amdgcn_readlane(v_bg, r));   // wave-uniform (see lane_r)
-      const int tab = __builtin_amdgcn_readlane(v_tab0, r);
-      const uint32_t bg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(bg));
-      if (bg_bits != bg_prev) {                            // a new read interval (a scalar branch): the pixel's
-        bg_prev = bg_bits;                                 // remainder mean and its e^-m
-        sky_m = fmaxf(skyv * bg - sky_base * bg, 0.f);
-        asm volatile("v_exp_f32 %0, %1" : "=v"(sky_em) : "v"(-1.4426950408889634f * sky_m));   // (volatile: not to be speculated into every read)
-      }
-      if (interior) {
-        if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);
-        long long qq = q;
-        if (skyv > 0.f) {
-          if (skyv * bg > 0.f)
-            qq += (long long)sky_draw_count(s_tab[tab + sky_lvl], sky_m, sky_em, rs) << kQBits;
+    // PRODUCTION VARIANT (float32 reads, hardware math, alias-table sky, no gaussian-noise stage): the same stages,
+    // streams and draws as the generic loop below with the arithmetic cut to what a float32 read can tell.
+    //  * what a pixel has collected so far is kept EXACTLY, in integers: Q = the sum of its fixed-point accumulators
+    //    (int64; touched only by the waves a read's electrons can reach, ~5 % of them) and ksum = the sum of its sky
+    //    counts (int32).  One conversion per read takes it to float32 electrons -- a single rounding of the exact sum,
+    //    where a float32 running sum would round fifteen times -- and one multiply to DN (the reference's
+    //    sum_r (px_r / gain) is (sum_r px_r) / gain to 1e-16);
+    //  * dark, non-linearity (Newton on the gap, nonlinear_gap_f32), clip, zero read and read noise follow in float32:
+    //    five roundings in all, <= 3 ulp of the float32 read (tests/test_modes_gpu.py: 0.02 DN + 2e-7 against the
+    //    float64 variant; tests/test_fullsize_oracle_gpu.py against the oracle);
+    //  * the sky remainder is four integer compares of the random word against thresholds that change only with the
+    //    read interval (SkyRem); the per-read numbers (bg_count, first table) come in scalar registers;
+    //  * reference pixels run the same instructions as light-sensitive ones (their planes hold the border's fill values,
+    //    their accumulators and their master sky are zero) and are set to zero by one select at the end: no exec-mask
+    //    bracket around each stage;
+    //  * ALLON (a kernel instantiation of its own, chosen by the host): every detector switch of the exposure is on --
+    //    dark, non-linearity, clip, read noise: the rule -- so no stage is selected by a flag at run time.
+    {
+      const bool f_dark = ALLON || do_dark, f_lin = ALLON || do_lin, f_clip = ALLON || clip, f_rdn = ALLON || rdn;
+      const float inv_gf = interior ? (float)inv_g : 0.f;  // DN per electron (reference pixels: nothing collected)
+      const float c1p = (1.0f + c1) - 1.0f;
+      const float zf = (float)z;
+      uint32_t bg_prev = 0xFFFFFFFFu;                      // bits of the previous read's bg (a scalar, like bg)
+      unsigned long long Q = 0ull;
+      int ksum = 0;
+      bool q_any = false;                                  // wave-uniform: has any read of this wave been live?
+      SkyRem sr;
+      sr.m = 0.f; sr.t0 = sr.t1 = sr.t2 = sr.t3 = 0xFFFFFFFFu; sr.c3 = 1.f; sr.term3 = 0.f;
+      // Two register sets for the planes of a read (A, B): a step works on one while the loads of the next read fill
+      // the other, and the loop is written out in pairs of steps so that no register is copied to rotate them.
+      long long qA = q_next, qB = 0;
+      float dsA = ds_next, deA = de_next, dsB = 0.f, deB = 0.f;
+      if (f_dark && !ld_dark) { dsA = ld_f32(rs_ds, 0); deA = ld_f32(rs_de, 0); }   // (reference pixels too)
+      auto step = [&](const int r, const long long q, const float ds, const float de, long long& q_nx, float& ds_nx,
+                      float& de_nx) {
+        const bool live = acc_live(r);                     // scalar
+        if (r + 1 < a.R) {
+          if (acc_live(r + 1)) q_nx = ld_acc(r + 1);
+          if (f_dark) { ds_nx = ld_f32(rs_ds, r + 1); de_nx = ld_f32(rs_de, r + 1); }
         }
-        // fixed point -> double (hi 2^32 + lo, exact), -> DN and onto the cumulative sum in one fma
-        const double d = fma((double)(int)(qq >> 32), 4294967296.0, (double)(unsigned)qq);
-        cum = fma(d, inv_gq, cum);
-      }
-      float zd = 0.f, zr = 0.f;
-      uint32_t w0, w1;
-      rn.next2(w0, w1);
-      if (rdn || ld_dark) bm_pair<true>(w0, w1, zd, zr);
-      double v = 0.;                                       // reference pixels (exposure.py:122-131)
-      if (interior) {
-        v = cum;
-        if (do_dark) v = cum + (double)fmaf((de > 0.f) ? de : 0.00001f, zd, ds);
-        if (do_lin) v = nonlinear_gap(v, c1p, c2, c3, c4, nl);
-        if (clip) {                                        // (plain v_max / v_min: fmax() would canonicalise first)
-          asm volatile("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(v) : "v"(v), "s"(kMinCounts), "s"(kMaxCounts));
+        const float bg = __int_as_float(__builtin_amdgcn_readlane(v_bg, r));   // wave-uniform (see lane_r)
+        const int tab = __builtin_amdgcn_readlane(v_tab0, r);
+        const uint32_t bg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(bg));
+        if (bg_bits != bg_prev) {                          // a new read interval (a scalar branch): the pixel's
+          bg_prev = bg_bits;                               // remainder mean and the thresholds of its search
+          sr.set(fmaxf(skyv * bg - sky_base * bg, 0.f));
         }
+        if (live) {                                        // (scalar branch)
+          if (q != 0) __builtin_amdgcn_raw_buffer_store_b64(v2u{0u, 0u}, rs_acc, off8, (uint32_t)r * acc_plane, 0);
+          Q += (unsigned long long)q;
+          q_any = true;
+        }
+        if (skyv * bg > 0.f) ksum += sky_draw_count_int(s_tab[tab + sky_lvl], sr, rn);   // (skyv = 0 off the sky)
+        float zd = 0.f, zr = 0.f;
+        uint32_t w0, w1;
+        rn.next2(w0, w1);
+        if (f_rdn || f_dark) bm_pair<true>(w0, w1, zd, zr);
+        float e = (float)ksum;                             // electrons so far: sky + accumulators (hi 2^4 + lo 2^-28)
+        if (q_any) {                                       // (scalar branch; the asm keeps it one: 95 % of the waves skip it)
+          asm volatile("" ::: "memory");
+          e = fmaf((float)(int)(Q >> 32), 16.0f, fmaf((float)(uint32_t)Q, 3.725290298461914e-09f, e));
+        }
+        float v = e * inv_gf;
+        if (f_dark) v = v + fmaf((de > 0.f) ? de : 0.00001f, zd, ds);
+        if (f_lin) v = nonlinear_gap_f32(v, c1p, c2, c3, c4, nl);
+        if (f_clip) v = __builtin_amdgcn_fmed3f(v, (float)kMinCounts, (float)kMaxCounts);
+        if (!interior) v = 0.f;                            // reference pixels (exposure.py:122-131)
+        // + zero read + read noise (exposure.py:94-104, detector.py:193-198)
+        const float tail = f_rdn ? fmaf((float)kReadNoise, zr, zf) : zf;
+        st_out(r + 1, (OutT)(v + tail));
+      };
+      int r = 0;
+      for (; r + 1 < a.R; r += 2) {
+        step(r, qA, dsA, deA, qB, dsB, deB);
+        step(r + 1, qB, dsB, deB, qA, dsA, deA);
       }
-      // + zero read + read noise (exposure.py:94-104, detector.py:193-198)
-      const float tail = rdn ? fmaf((float)kReadNoise, zr, zf) : zf;
-      st_out(r + 1, (OutT)(float)(v + (double)tail));
+      if (r < a.R) step(r, qA, dsA, deA, qB, dsB, deB);
     }
     return;
   }
@@ -528,12 +526,11 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
         // master_sky *= bg_count is an in-place float32 multiply (:493)
         const float lam = skyv * s_c[r];
         if (ALIAS && FAST && SKY == 1) {
-          if (s_c[r] != sky_c) {                         // a new read interval: the pixel's remainder mean and its e^-m
+          if (s_c[r] != sky_c) {                         // a new read interval: the pixel's remainder mean and thresholds
             sky_c = s_c[r];
-            sky_m = fmaxf(lam - sky_base * sky_c, 0.f);
-            sky_em = FastMath::exp_(-sky_m);
+            srem.set(fmaxf(lam - sky_base * sky_c, 0.f));
           }
-          if (lam > 0.f) px = px + (double)sky_draw_cached(s_tab[s_tab0[r] + sky_lvl], sky_m, sky_em, rs);
+          if (lam > 0.f) px = px + (double)sky_draw_count_int(s_tab[s_tab0[r] + sky_lvl], srem, rs);
         } else if (ALIAS) {
           if (lam > 0.f) px = px + (double)sky_draw<M, SKY == 2>(s_tab[s_tab0[r] + sky_lvl], sky_base * s_c[r], lam, rs);
         } else {
@@ -568,13 +565,13 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
 // plane loads behind other waves' arithmetic (at 66 registers and 7 waves the kernel measured 7 % slower) -- and are
 // pinned there.  The exact-math, direct-sky (SKY = 0) and gaussian-noise variants would spill under that pin
 // (24-64 bytes of scratch each); they are parity / fallback paths and take the registers they need.
-template <class OutT, bool FAST, int SKY, bool NOISE>
+template <class OutT, bool FAST, int SKY, bool NOISE, bool ALLON = false>
 __global__ __launch_bounds__(kRampThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ramp(RampArgs a) {
-  ramp_body<OutT, FAST, SKY, NOISE>(a);
+  ramp_body<OutT, FAST, SKY, NOISE, ALLON>(a);
 }
 template <class OutT, bool FAST, int SKY, bool NOISE>
 __global__ __launch_bounds__(kRampThreads) void k_ramp_wide(RampArgs a) {
-  ramp_body<OutT, FAST, SKY, NOISE>(a);
+  ramp_body<OutT, FAST, SKY, NOISE, false>(a);
 }
 
 }  // namespace wayne

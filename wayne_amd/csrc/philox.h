@@ -28,10 +28,13 @@ namespace wayne {
 enum Stage : uint32_t {
   STAGE_COUNTS = 1,   // Philox stream (bin w, block, sub-sample k, exposure)     stellar Poisson
   STAGE_THROW = 2,    // seeded stream (electron block e>>7, 0, sub-sample k, exposure): pair j (next2) -> electron j of the block
-  STAGE_SKY = 3,      // seeded stream (pixel, 0, 0, exposure): sky Poisson draws of reads 0..R-1 in order (a pair per draw / trial)
+  STAGE_SKY = 3,      // seeded stream (pixel, 0, 0, exposure): sky Poisson draws of reads 0..R-1 in order (a pair per trial) -- the
+                      //   DIRECT sampler only (k_ramp SKY = 0: rates that fit no alias table); the table-driven draw reads STAGE_READ
   STAGE_CR_COUNT = 4, // Philox stream (0, block, read r, exposure)               number of cosmic hits
   STAGE_CR_HIT = 5,   // Philox block  (hit i, 0, read r, exposure)               energy, y, x of hit i
-  STAGE_READ = 6,     // seeded stream (pixel, 0, 0, exposure): pair i -> (dark, read-noise) normals of read i (0 = zero read)
+  STAGE_READ = 6,     // seeded stream (pixel, 0, 0, exposure): the pair of (dark, read-noise) normals of read 0 (the zero read), then
+                      //   for r = 0..R-1: the words of read interval r's table-driven sky draw (a pair: table word + remainder
+                      //   uniform, further pieces one word each; none where the pixel's sky rate is 0) and the pair of read r+1's normals
   STAGE_NOISE = 7,    // seeded stream (pixel, 0, 0, exposure): pair r -> optional gaussian noise of read interval r
   STAGE_HOST = 8,     // Philox block  (sub-sample k, 0, 0, exposure)             jitter x/y, replay seed
   STAGE_NARROW = 9,   // seeded stream (bin w, 0, sub-sample k, exposure): the binomial chain that splits a bin's

@@ -1360,6 +1360,10 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
     const int sky_mode = a.sky_alias == nullptr ? 0 : (sky_pieces ? 2 : 1);
     const bool noise = d.noise_mean != 0. && d.noise_std != 0.;
     void (*kern)(RampArgs) = pick_ramp(f64, exact, sky_mode, noise);
+    // the production variant with every detector switch on (the rule) has an instantiation of its own (k_ramp.h, ALLON)
+    const uint32_t all_on = WAYNE_F_ADD_DARK | WAYNE_F_ADD_NON_LINEAR | WAYNE_F_CLIP_DET_LIMITS | WAYNE_F_ADD_READ_NOISE;
+    if (!f64 && !exact && sky_mode == 1 && !noise && (d.flags & all_on) == all_on && c->has_dark && c->has_lin)
+      kern = k_ramp<float, true, 1, false, true>;
     if (ps.on) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, ps.rec.a, ps.rec.b, 0, a);
     else hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
