@@ -309,7 +309,10 @@ void wayne_oracle_sky_alias_step(const float *lam, const float *lam_level, const
       float term = expf(-part);
       float j = 0.0f;
       for (int it = 0; it < 512 && u > term; ++it) {
-        u = u - term;
+        /* a term too small to move u: the uniform lies in the rounding residue of the pmf's float32 sum -- stop */
+        const float left = u - term;
+        if (left == u) break;
+        u = left;
         j = j + 1.0f;
         term = term * (part / j);
       }

@@ -43,7 +43,10 @@ struct RampArgs {
 constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
 constexpr float kSkyPiece = 16.f; // largest mean drawn by one sequential search
 
-constexpr int kRampThreads = 1024;
+#ifndef WAYNE_RAMP_THREADS
+#define WAYNE_RAMP_THREADS 1024
+#endif
+constexpr int kRampThreads = WAYNE_RAMP_THREADS;
 constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
 
 // Box-Muller pair from two words.  EXACT mirrors the oracle's libm formula;
@@ -136,7 +139,13 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
       float j = 0.f;
       for (int it = 0; it < 512; ++it) {
         if (u <= pk) break;
-        u = u - pk;
+        // (a term that no longer moves u cannot end the search either: the uniform fell into the rounding residue of
+        // the pmf's float32 sum -- 3e-8 to 9e-8 of the draws, one pixel in an exposure or two.  Without this stop the
+        // search walks on to its cap: ~500 spurious electrons in that pixel and, on the device, a wave that runs tens
+        // of microseconds after every other wave of the launch has finished)
+        const float un = u - pk;
+        if (un == u) break;
+        u = un;
         j = j + 1.f;
         pk = pk * M::div_(piece, j);
       }
@@ -210,7 +219,9 @@ __device__ __forceinline__ int sky_draw_count_int(const uint32_t* tab, const Sky
 #pragma nounroll
     for (int it = 4; it < 512; ++it) {
       t = t * FastMath::div_(sr.m, (float)it);
-      cdf += t;
+      const float cn = cdf + t;
+      if (cn == cdf) break;          // the cdf has stopped growing below u (see sky_draw): stop, not 500 more rounds
+      cdf = cn;
       if (!(u > cdf)) break;
       k = k + 1;
     }
@@ -301,38 +312,6 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   const bool do_noise = NOISE && (a.noise_mean != 0.) && (a.noise_std != 0.);   // `if noise_mean and noise_std` (:477)
   const bool do_sky = a.sky_ct_s > 0. && a.sky;
 
-  if (tid < a.R) {
-    s_c[tid] = (float)(a.sky_ct_s * a.read_dt[tid]);                       // bg_count of read tid (:489-491)
-    s_tab0[tid] = (int)a.sky_tab0[tid];
-  }
-  if (ALIAS && do_sky)
-    for (int i = tid; i < kMaxReads * kSkyAlias; i += kRampThreads) (&s_tab[0][0])[i] = a.sky_alias[i];
-  float skyv = 0.f;
-  if (interior && do_sky) skyv = a.sky[p];
-  __syncthreads();
-  if (!ALIAS) {
-    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c,
-                                 (uint32_t (*)[kRampThreads])&s_tab[0][0]);
-    __syncthreads();
-  }
-  if (!valid) return;
-  // the pixel's sky level (constant over the reads): the highest level not above its sky value
-  int sky_lvl = 0;
-  if (ALIAS && skyv > 0.f)
-    for (int l = 1; l < a.sky_levels; ++l) sky_lvl += (a.sky_level[l] <= skyv) ? 1 : 0;
-  const float sky_base = a.sky_level[sky_lvl];
-
-  // per-pixel streams, seeded only when a stage that reads them is on (one Philox block each).  ONE stream (STAGE_READ)
-  // serves the table-driven sky draw and the two normals of every read, in the order the read loop takes them: pair 0 =
-  // the zero read's normals, then per read interval r the words of its sky draw (a pair; none where the pixel has no
-  // sky) followed by the pair of read r + 1's normals.  A second Philox block per pixel for the sky alone was 6 % of the
-  // kernel's vector instructions.  (The direct sampler, SKY = 0, draws a data-dependent number of words per read and
-  // keeps its own stream, STAGE_SKY: sky_counts.)
-  SeededStream rn, rg;
-  if (rdn || do_dark || (ALIAS && do_sky)) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
-  SeededStream& rs = rn;
-  if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
-
   // Buffer addressing: descriptor (scalar) + the lane's 32-bit byte offset (vector, loop constant) + the plane's
   // byte offset (scalar, advances per read) -- no 64-bit vector address arithmetic per access, which the
   // flat-pointer form spent five v_lshl_add_u64 a read on.  (Planes are < 2^31 bytes: R * S * S * 8 <= 142 MB.)
@@ -364,23 +343,100 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
     }
   };
 
+  // ---- prologue.  Every load whose address is known at entry is ISSUED first -- the once-per-pixel planes, this
+  // wave's per-read numbers (lane l fetches those of read l), its share of the alias tables -- then the stream is
+  // seeded (a Philox block: ~100 vector instructions that need none of them), and only then are the values used.  In
+  // the order the stages are written below -- load, use, load, use -- a wave paid eight memory latencies one after the
+  // other before its first read, twice per launch (two rounds of workgroups): 17 us of a 54 us kernel
+  // (scripts/ramp_vs_reads.py).
+  const int lane_r = min(tid & 63, kMaxReads);
+  const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
+  const float t_sky = (interior && do_sky) ? a.sky[p] : 0.f;
+  const float t_pfl = (interior && gainvar) ? a.pfl[p] : 1.0f;
+  float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  if (do_lin && valid) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
+  const double t_zero = (valid && a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
+  const int v_bg = __float_as_int(a.bg[lane_r]), v_tab0 = a.tab0[lane_r];
+  const int v_lvl = __float_as_int(a.sky_level[lane_r]);
+  int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+  uint32_t t_seg = 0u;
+  if (a.use_box) {
+    bx0 = a.box[lane_r][0]; bx1 = a.box[lane_r][1]; by0 = a.box[lane_r][2]; by1 = a.box[lane_r][3];
+    if (p0 < S * S) t_seg = a.seg[p0 >> 6];
+  }
+  constexpr int kTabWords = kMaxReads * kSkyAlias, kTabPer = (kTabWords + kRampThreads - 1) / kRampThreads;
+  uint32_t t_tab[ALIAS ? kTabPer : 1];
+  if (ALIAS && do_sky) {
+#pragma unroll
+    for (int i = 0; i < kTabPer; ++i) {
+      const int j = tid + i * kRampThreads;
+      t_tab[i] = j < kTabWords ? a.sky_alias[j] : 0u;
+    }
+  }
+
+  // per-pixel streams, seeded only when a stage that reads them is on (one Philox block each).  ONE stream (STAGE_READ)
+  // serves the table-driven sky draw and the two normals of every read, in the order the read loop takes them: pair 0 =
+  // the zero read's normals, then per read interval r the words of its sky draw (a pair; none where the pixel has no
+  // sky) followed by the pair of read r + 1's normals.  A second Philox block per pixel for the sky alone was 6 % of the
+  // kernel's vector instructions.  (The direct sampler, SKY = 0, draws a data-dependent number of words per read and
+  // keeps its own stream, STAGE_SKY: sky_counts.)
+  // (the first read's dark planes too; reference pixels load theirs as well -- the production loop runs them through
+  // every stage and zeroes them at the end)
+  const bool ld_dark = do_dark && valid;
+  float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
+
+  SeededStream rn, rg;
+  if (rdn || do_dark || (ALIAS && do_sky)) rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);
+  SeededStream& rs = rn;
+  if (do_noise) rg = SeededStream(a.seed, STAGE_NOISE, (uint32_t)p, 0u, a.exposure);
+  // (nothing loaded above is touched before this point: the compiler would otherwise sink a first use -- and its wait --
+  // into the branch that issued the load)
+  asm volatile("" : "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4));
+  asm volatile("" : "+v"(ds_next), "+v"(de_next));
+
+  if (tid < a.R) {
+    s_c[tid] = __int_as_float(v_bg);                                       // bg_count of read tid (:489-491), lane = read
+    s_tab0[tid] = v_tab0;
+  }
+  if (ALIAS && do_sky) {
+#pragma unroll
+    for (int i = 0; i < kTabPer; ++i) {
+      const int j = tid + i * kRampThreads;
+      if (j < kTabWords) (&s_tab[0][0])[j] = t_tab[i];
+    }
+  }
+  const float skyv = t_sky;
+  __syncthreads();
+  if (!ALIAS) {
+    if (do_sky) sky_counts<FAST>(a, (uint32_t)p, tid, interior && skyv > 0.f, skyv, s_c,
+                                 (uint32_t (*)[kRampThreads])&s_tab[0][0]);
+    __syncthreads();
+  }
+  if (!valid) return;
+  // the pixel's sky level (constant over the reads): the highest level not above its sky value (lane l of the wave
+  // holds level l: no memory access in the search)
+  int sky_lvl = 0;
+  float sky_base = __int_as_float(__builtin_amdgcn_readlane(v_lvl, 0));
+  if (ALIAS && skyv > 0.f) {
+    for (int l = 1; l < a.sky_levels; ++l) {
+      const float lv = __int_as_float(__builtin_amdgcn_readlane(v_lvl, l));
+      if (lv <= skyv) { sky_lvl += 1; sky_base = lv; }
+    }
+  }
+
   // Per-read numbers without a memory access in the read loop: lane l of every wave fetches those of read l once
   // (bg_count, first sky table, the box of the read's accumulators), tests the wave's 64 consecutive pixels against
   // box l, and the loop then takes read r's numbers with v_readlane and its "load the accumulators?" bit from a
   // ballot.  (Scalar loads of a.bg[r] / a.box[r] at the top of every iteration measured no gain over the LDS reads
   // they replaced: their latency sat in front of the iteration's first use.)
-  const int lane_r = min(tid & 63, kMaxReads);
-  const int v_bg = __float_as_int(a.bg[lane_r]), v_tab0 = a.tab0[lane_r];
-  const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
   const int wy0 = p0 / S, wy1 = min(p0 + 63, S * S - 1) / S, wx0 = p0 - wy0 * S;
   unsigned long long live_bits = ~0ull;
   if (a.use_box) {
     uint32_t cbits = 0u;
     if (p0 < S * S) {
-      cbits = __builtin_amdgcn_readfirstlane(a.seg[p0 >> 6]);
+      cbits = __builtin_amdgcn_readfirstlane(t_seg);
       if (cbits != 0u && (tid & 63) == 0) a.seg[p0 >> 6] = 0u;   // left clean for the next exposure, like the accumulators
     }
-    const int bx0 = a.box[lane_r][0], bx1 = a.box[lane_r][1], by0 = a.box[lane_r][2], by1 = a.box[lane_r][3];
     const bool rows = wy0 < by1 && wy1 >= by0;
     const bool cols = (wy0 != wy1) || (wx0 < bx1 && wx0 + 64 > bx0);
     live_bits = __ballot((rows && cols) || ((cbits >> lane_r) & 1u) != 0u);
@@ -389,7 +445,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
 
   // zero read: (initial bias) -> clip -> reference pixels := 0 -> read noise
   // (exposure_generator.py:446-466, exposure.py:82-131, 61-68)
-  double z = (a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
+  double z = t_zero;
   if (clip) z = fmin(fmax(z, kMinCounts), kMaxCounts);
   if (!interior) z = 0.;
   {
@@ -404,17 +460,14 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   // gain: 2.35 / pfl evaluated in float32 as numpy does for scalar / f32 array
   // (detector.py:203-204), or the constant (exposure_generator.py:507-511);
   // applied as a multiplication by its fp64 reciprocal
+  const float g32 = 2.35f / t_pfl;                          // (float32 IEEE division, as numpy's)
   double inv_g = 1.0 / kGain;
-  float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-  if (interior && gainvar) inv_g = 1.0 / (double)(2.35f / a.pfl[p]);
-  if (do_lin) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
+  if (interior && gainvar && !(std::is_same<OutT, float>::value && FAST && SKY == 1 && !NOISE)) inv_g = 1.0 / (double)g32;
 
   // software-pipelined ramp: the planes of read r+1 are requested before the
   // (VALU-heavy) work on read r so that HBM latency hides behind it.  The dark planes and the reads are
   // streamed once: non-temporal loads / stores (kNT; measured: 0.076 -> 0.070 ms)
-  const bool ld_dark = do_dark && interior;
   long long q_next = (interior && acc_live(0)) ? ld_acc(0) : 0;
-  float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;
   double cum = 0.;
   NlState nl = {0.f, 0.f, 0.f};
   float sky_c = -1.f;
@@ -440,7 +493,8 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
     //    dark, non-linearity, clip, read noise: the rule -- so no stage is selected by a flag at run time.
     {
       const bool f_dark = ALLON || do_dark, f_lin = ALLON || do_lin, f_clip = ALLON || clip, f_rdn = ALLON || rdn;
-      const float inv_gf = interior ? (float)inv_g : 0.f;  // DN per electron (reference pixels: nothing collected)
+      // DN per electron (reference pixels: nothing collected): the float32 reciprocal of the float32 gain
+      const float inv_gf = !interior ? 0.f : (gainvar ? 1.0f / g32 : (float)(1.0 / kGain));
       const float c1p = (1.0f + c1) - 1.0f;
       const float zf = (float)z;
       uint32_t bg_prev = 0xFFFFFFFFu;                      // bits of the previous read's bg (a scalar, like bg)
@@ -449,17 +503,25 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
       bool q_any = false;                                  // wave-uniform: has any read of this wave been live?
       SkyRem sr;
       sr.m = 0.f; sr.t0 = sr.t1 = sr.t2 = sr.t3 = 0xFFFFFFFFu; sr.c3 = 1.f; sr.term3 = 0.f;
-      // Two register sets for the planes of a read (A, B): a step works on one while the loads of the next read fill
-      // the other, and the loop is written out in pairs of steps so that no register is copied to rotate them.
-      long long qA = q_next, qB = 0;
-      float dsA = ds_next, deA = de_next, dsB = 0.f, deB = 0.f;
-      if (f_dark && !ld_dark) { dsA = ld_f32(rs_ds, 0); deA = ld_f32(rs_de, 0); }   // (reference pixels too)
+#ifndef WAYNE_RAMP_PF
+#define WAYNE_RAMP_PF 2
+#endif
+      // Register sets for the planes of a read (A, B[, C]): a step works on one while the loads of the read PF steps
+      // ahead fill another, and the loop is written out in groups of PF + 1 steps so that no register is copied to
+      // rotate them.
+      constexpr int PF = WAYNE_RAMP_PF;
+      long long qA = q_next, qB = 0, qC = 0;
+      float dsA = ds_next, deA = de_next, dsB = 0.f, deB = 0.f, dsC = 0.f, deC = 0.f;
+      if (PF == 2 && a.R > 1) {
+        if (acc_live(1)) qB = ld_acc(1);
+        if (f_dark) { dsB = ld_f32(rs_ds, 1); deB = ld_f32(rs_de, 1); }
+      }
       auto step = [&](const int r, const long long q, const float ds, const float de, long long& q_nx, float& ds_nx,
                       float& de_nx) {
         const bool live = acc_live(r);                     // scalar
-        if (r + 1 < a.R) {
-          if (acc_live(r + 1)) q_nx = ld_acc(r + 1);
-          if (f_dark) { ds_nx = ld_f32(rs_ds, r + 1); de_nx = ld_f32(rs_de, r + 1); }
+        if (r + PF < a.R) {
+          if (acc_live(r + PF)) q_nx = ld_acc(r + PF);
+          if (f_dark) { ds_nx = ld_f32(rs_ds, r + PF); de_nx = ld_f32(rs_de, r + PF); }
         }
         const float bg = __int_as_float(__builtin_amdgcn_readlane(v_bg, r));   // wave-uniform (see lane_r)
         const int tab = __builtin_amdgcn_readlane(v_tab0, r);
@@ -493,11 +555,21 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
         st_out(r + 1, (OutT)(v + tail));
       };
       int r = 0;
-      for (; r + 1 < a.R; r += 2) {
-        step(r, qA, dsA, deA, qB, dsB, deB);
-        step(r + 1, qB, dsB, deB, qA, dsA, deA);
+      if (PF == 1) {
+        for (; r + 1 < a.R; r += 2) {
+          step(r, qA, dsA, deA, qB, dsB, deB);
+          step(r + 1, qB, dsB, deB, qA, dsA, deA);
+        }
+        if (r < a.R) step(r, qA, dsA, deA, qB, dsB, deB);
+      } else {
+        for (; r + 2 < a.R; r += 3) {
+          step(r, qA, dsA, deA, qC, dsC, deC);
+          step(r + 1, qB, dsB, deB, qA, dsA, deA);
+          step(r + 2, qC, dsC, deC, qB, dsB, deB);
+        }
+        if (r < a.R) step(r, qA, dsA, deA, qC, dsC, deC);
+        if (r + 1 < a.R) step(r + 1, qB, dsB, deB, qA, dsA, deA);
       }
-      if (r < a.R) step(r, qA, dsA, deA, qB, dsB, deB);
     }
     return;
   }

@@ -218,13 +218,17 @@ WAYNE_HD typename M::type binomial(typename M::type n, typename M::type p, RNG& 
     const T a = (n + (T)1) * s;
     T r = M::exp_(n * M::log1m_(p));
     T u = M::u01(rng.next());
-    for (int it = 0; it < 256; ++it) {
+    // (n p < 10: a legitimate draw passes 64 with probability < 1e-25.  A search that gets there has a uniform that
+    // fell into the rounding residue of the pmf's float sum -- ~6e-8 of the draws -- and would walk on for ever: it
+    // takes the mean instead.  A per-step test for that costs the kernel 2.5 %; the cap costs nothing.)
+    for (int it = 0; it < 64; ++it) {
       if (u <= r) break;
       u = u - r;
       x = x + (T)1;
       r = r * (M::div_(a, x) - s);
       if (x >= n) { x = n; break; }
     }
+    if (x >= (T)64 && x < n) x = M::floor_(n * p + (T)0.5);
   } else {
     const T spq = M::sqrt_(n * p * q);
     const T b = (T)1.15 + (T)2.53 * spq;

@@ -1328,6 +1328,9 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   const int S = c->S;
   RampArgs a{};
   a.R = s.R; a.N = c->N; a.S = S;
+  // measurement knob (scripts/ramp_vs_reads.py): the kernel works through the first n reads only -- timing runs, the
+  // slot's other accumulators stay uncleared
+  if (const char* e_ = std::getenv("WAYNE_RAMP_READS")) a.R = std::max(1, std::min(s.R, std::atoi(e_)));
   a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
   a.sky_ct_s = d.sky_ct_s; a.noise_mean = d.noise_mean; a.noise_std = d.noise_std;
   a.read_dt = s.read_dt.as<double>();
