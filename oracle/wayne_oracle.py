@@ -718,8 +718,12 @@ class ExposureOracle(object):
             _, sample_mid_points, sample_durations, read_index = self._gen_scanning_sample_times(sample_rate)
         s_y_refs = self._gen_sample_yref(y_ref, sample_mid_points, scan_speed)    # :258
         if ssv_generator is not None:
-            sample_durations = ssv_generator.get_subsample_exposure_times(
-                s_y_refs, sample_durations, self.read_times, sample_rate)         # :272-273
+            if isinstance(ssv_generator, SSVModulatedSine):                        # :263-267
+                sample_durations, read_index = ssv_generator.get_subsample_exposure_times(
+                    s_y_refs, sample_durations, self.read_times, sample_rate)
+            else:
+                sample_durations = ssv_generator.get_subsample_exposure_times(
+                    s_y_refs, sample_durations, self.read_times, sample_rate)     # :272-273
 
         zero_read = self._gen_zero_read(add_initial_bias)                         # :302
         reads = [zero_read.copy()]
@@ -828,10 +832,12 @@ class SSVModulatedSine(object):
     exposure_generator.py:263-267; the reference converts both to seconds, :90-91).  Returns (durations in ms,
     read indexes) as the reference does (:171)."""
 
-    def __init__(self, amplitude=10, period=1.1, blip_proba=1):
+    def __init__(self, amplitude=10, period=1.1, blip_proba=1, rs=None):
         self.amplitude, self.period, self.blip_proba = amplitude, period, blip_proba      # :78-80
+        self.rs = rs     # the stream a call draws from when none is handed to it
 
     def get_subsample_exposure_times(self, y_mid_points, sample_durations, read_times, sample_rate, rs=None):
+        rs = self.rs if rs is None else rs
         read_times = np.asarray(read_times, dtype=float)             # :90
         sample_rate = float(sample_rate) / 1000.                     # :91 (ms -> s)
         period = self.period

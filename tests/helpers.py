@@ -34,11 +34,19 @@ def oracle_generator(visit):
     return eo
 
 
-def oracle_kwargs(kw):
-    """scanning_frame keywords of the product -> the oracle's (same names)."""
+def oracle_kwargs(kw, seed=0, exposure=0):
+    """scanning_frame keywords of the product -> the oracle's (same names).  `seed`, `exposure`: the visit seed and
+    exposure index of the product generator -- the product keys the stream of a modulated-sine scan-speed generator
+    by them (exposure_generator.py build_descriptor) where the reference draws from its global numpy stream
+    (scan_speed_varations.py:100-167); the oracle's restatement gets a numpy legacy stream with that same seed."""
+    from wayne_amd.trend_generators.scan_speed_varations import SSVModulatedSine
     kw = dict(kw)
     ssv = kw.get("ssv_generator")
-    if ssv is not None:
+    if isinstance(ssv, SSVModulatedSine):
+        key = (int(seed) * 1000003 + int(exposure) * 7919 + 12345) & 0x7FFFFFFF
+        kw["ssv_generator"] = wo.SSVModulatedSine(ssv.amplitude, ssv.period, ssv.blip_proba,
+                                                  rs=np.random.RandomState(key))
+    elif ssv is not None:
         kw["ssv_generator"] = wo.SSVSine(ssv.stddev, ssv.period, ssv.start_phase)
     return kw
 

@@ -173,7 +173,7 @@ def _exposure_ensembles(m_dev=200, m_ref=100):
         dev = []
         for m in range(m_dev):
             pg = helpers.product_generator(v, m)                 # exposure index m: independent streams
-            dev.append(np.array(pg.scanning_frame(**kw).reads[-1][0], dtype=np.float64))
+            dev.append(np.array(pg.scanning_frame(out_dtype=np.float32, **kw).reads[-1][0], dtype=np.float64))
         eo = helpers.oracle_generator(v)
         okw = helpers.oracle_kwargs(kw)
         ref = [eo.scanning_frame(threads=2 if m % 2 else 1, draws=wo.LegacyDraws(4000 + m), thrower="ref",

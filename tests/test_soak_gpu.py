@@ -22,7 +22,7 @@ def test_pipelined_visit_equals_one_at_a_time_generation():
     for i in sorted(set([0, 1, 2, n // 3, n // 2, n - 2, n - 1] + [int(j) for j in np.random.default_rng(1).integers(0, n, 6)])):
         eg = ExposureGenerator(v.detector, v.grism, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=v.calibration,
                                seed=v.seed, exposure_index=i)
-        reads = np.stack([r[0] for r in eg.scanning_frame(**v.frame_kwargs(i)).reads])
+        reads = np.stack([r[0] for r in eg.scanning_frame(out_dtype=np.float32, **v.frame_kwargs(i)).reads])
         assert float(reads[-1].sum()) == seen[i][0] and float(reads[1].max()) == seen[i][1], i
         np.testing.assert_array_equal(reads[-1][::7, ::5], seen[i][2])
 

@@ -400,7 +400,7 @@ def test_pipelined_visit_runner_matches_direct_calls(tmp_path):
     got = runner.run(wv.shard(5, 1, 2) + wv.shard(5, 0, 2), keep=True, on_reads=lambda i, r: seen.append((i, float(r[-1].max()))))
     assert sorted(got) == [0, 1, 2, 3, 4] and [i for i, _ in seen] == [1, 3, 0, 2, 4]
     for i in (0, 3):
-        direct = np.stack([r[0] for r in helpers.product_generator(v, i).scanning_frame(**v.frame_kwargs(i)).reads])
+        direct = np.stack([r[0] for r in helpers.product_generator(v, i).scanning_frame(out_dtype=np.float32, **v.frame_kwargs(i)).reads])
         np.testing.assert_array_equal(got[i], direct)          # order of generation and slot / stream do not matter
         h = fitsio.read(os.path.join(str(tmp_path), "%04d_raw.fits" % (i + 1)))
         np.testing.assert_array_equal(h[1].data, direct[-1].astype(np.float64))
@@ -477,3 +477,58 @@ def test_exposure_with_modulated_sine_ssv():
     per_read = rec["acc"].reshape(4, -1).sum(axis=1)
     dt = np.diff(np.concatenate([[0.0], v.read_times]))
     np.testing.assert_allclose(per_read / per_read.sum(), dt / dt.sum(), atol=0.01)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blip", [0, 100])
+def test_modulated_sine_exposure_against_the_oracle(blip):
+    # SURVEY section 8(f4), scan_speed_varations.py:63-171 through a whole exposure: the reference's example-visit
+    # shape (cfg1: 256 x 256, NSAMP 5, 10 ms sampling -> 2233 sub-samples) driven by SSVModulatedSine, through the HIP
+    # path and through ExposureOracle (whose restatement of the generator draws from a numpy legacy stream with the
+    # product's per-exposure key; its read indexes trigger the reads as `if i in read_index` does,
+    # exposure_generator.py:361).  Deterministic switches, replay thrower: durations and read indexes equal, counts per
+    # bin exact (fp64 samplers on both sides: at most two of the 1e7 draws may fall on a 1-ulp boundary, and are then
+    # accounted for), positions 1e-9 px, accumulated electrons to the fixed-point quantum, reads to 1e-4 DN (float64 out).
+    import helpers
+    from oracle import wayne_oracle as wo
+    from wayne_amd import _lib
+    from wayne_amd.trend_generators.scan_speed_varations import SSVModulatedSine
+    i = 2
+    v = helpers.make_visit("cfg1", n_exposures=i + 1)
+    pg = helpers.product_generator(v, i)
+    # (stellar Poisson noise stays on: the expected count of a bin in a 10 ms sub-sample is 2.5 electrons -- np.round
+    # would leave a few ones in a frame of zeros; the draws are the same Philox counters on both sides)
+    det_off = dict(sky_background=0.0, cosmic_rate=None, add_dark=False, add_read_noise=False)
+    kw = v.frame_kwargs(i, ssv_generator=SSVModulatedSine(10, 1.1, blip), **det_off)
+    rec = {}
+    got = np.stack([r[0] for r in pg.scanning_frame(threads=2, rng_mode=_lib.RNG_REPLAY, out_dtype=np.float64,
+                                                    record=rec, exact_samplers=True, **kw).reads])
+    eo = helpers.oracle_generator(v)
+    orec = {}
+    okw = helpers.oracle_kwargs(kw, seed=v.seed, exposure=i)
+    assert isinstance(okw["ssv_generator"], wo.SSVModulatedSine)
+    want = np.stack(eo.scanning_frame(threads=2, draws=wo.PhiloxDraws(v.seed, i, 256), thrower="oracle", record=orec,
+                                      **okw))
+    # the generator's own output, product against oracle, on the stream of this exposure
+    key = (v.seed * 1000003 + i * 7919 + 12345) & 0x7FFFFFFF
+    d_or, idx_or = wo.SSVModulatedSine(10, 1.1, blip).get_subsample_exposure_times(
+        None, None, eo.read_times, 10.0, rs=np.random.RandomState(key))
+    K = rec["dur"].size
+    assert K == 2233 and len(d_or) in (K, K - 1)
+    np.testing.assert_array_equal(rec["dur"][:len(d_or)], d_or)
+    assert not rec["dur"][len(d_or):].any()                         # a sample without a duration exposes for 0 ms (:337-342)
+    # the sub-sample that closes each read but the last (`if i in read_index`, :361)
+    assert [int(k) for k in np.nonzero(np.diff(rec["read"]))[0]] == [min(int(b), K - 1) for b in idx_or[:-1]]
+    # the exposure
+    oc = np.stack(orec["counts"])
+    flipped = int((rec["counts"] != oc).sum())
+    slack = float(np.abs(rec["counts"].astype(np.int64) - oc).sum())      # electrons of draws that fell on a boundary
+    assert flipped <= 2 and oc.sum() > 2e7
+    np.testing.assert_allclose(rec["x"], np.stack(orec["x"]), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rec["y"], np.stack(orec["y"]), rtol=0, atol=1e-9)
+    acc_o = np.stack(orec["acc"])
+    d_acc = np.abs(rec["acc"] - acc_o)
+    assert d_acc.sum() <= 2.0 * slack + acc_o.size * 2233 * 2.0 ** -29
+    assert d_acc.max() <= slack + 2233 * 2.0 ** -29 + 1e-9
+    assert np.abs(got - want).max() <= 1e-4 + slack / 2.0
+    assert np.abs(got[-1]).max() > 50

@@ -107,7 +107,7 @@ class ExposureGenerator(object):
                        scale_factor=None, add_gain_variations=True, add_non_linear=True,
                        clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                        add_initial_bias=True, progress_bar=None, threads=2,
-                       rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
+                       rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, reference_quirks=False,
                        record=None, exact_samplers=False):
         """Generate a spatially scanned exposure (exposure_generator.py:178-405).
 
@@ -115,8 +115,10 @@ class ExposureGenerator(object):
         Philox-keyed streams, wide PSF component thrown per electron, narrow
         component drawn as one multinomial per bin), RNG_PHILOX (every electron
         thrown), or RNG_REPLAY (the reference's rand_r streams in the thrower,
-        with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` float32 or
-        float64 reads; `reference_quirks` keeps the reference's -5 px frame
+        with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` -- float64 reads (the
+        default: what the reference's Exposure.reads hold, exposure.py:47,106-120) or float32 reads (the production
+        path of bench.py, VisitRunner and the CLI: half the bytes to write and to carry over PCIe, <= 3 ulp of a
+        float32 from the float64 result); `reference_quirks` keeps the reference's -5 px frame
         offset at SUBARRAY=1024 (exposure_generator.py:630) and flat-fields G102 exposures with the
         G141 cube as the reference does (grism.py:428,453-454); `record`, if a dict,
         receives the device's intermediate products (counts, x, y per bin and
@@ -190,7 +192,7 @@ class ExposureGenerator(object):
                          scale_factor=None, add_gain_variations=True, add_non_linear=True,
                          clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                          add_initial_bias=True, progress_bar=None, threads=2,
-                         rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
+                         rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, reference_quirks=False,
                          exact_samplers=False):
         """The host half of scanning_frame: sample timing, scan positions, SSV,
         jitter / seed draws, spectrum crop (exposure_generator.py:247-334) ->
@@ -287,7 +289,7 @@ class ExposureGenerator(object):
         if eng is not None:
             eng.check_descriptor(sub_scale)
         self._read_dt = read_dt
-        self._host_vectors = {"x_ref": s_x, "y_ref": s_y, "dur": s_dur, "seeds": s_rand_seeds}
+        self._host_vectors = {"x_ref": s_x, "y_ref": s_y, "dur": s_dur, "seeds": s_rand_seeds, "read": sample_read}
         return _lib.make_desc(
             self.seed, self.exposure_index, flags, sub_scale, s_wl, flux, depth, s_x, s_y, s_dur,
             sample_read, read_dt, replay_seed=s_rand_seeds, rng_mode=rng_mode, threads_compat=threads,

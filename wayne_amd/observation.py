@@ -54,8 +54,11 @@ class Observation(object):
         self._visit_trend = False
         self.ssv_gen = None
         self.noise_mean = self.noise_std = False
-        # extra keywords for scanning_frame / staring_frame (rng_mode, out_dtype, exact_samplers, reference_quirks)
-        self.frame_options = {}
+        # extra keywords for scanning_frame / staring_frame (rng_mode, out_dtype, exact_samplers, reference_quirks).
+        # The visit driver asks for float32 reads: the FITS writer stores them as the reference's float64 SCI images
+        # (BITPIX -64) either way, and a full-array exposure is 67 MB instead of 134 MB to bring over PCIe;
+        # frame_options["out_dtype"] = np.float64 (CLI: --float64-reads) keeps the float64 arithmetic to the file.
+        self.frame_options = {"out_dtype": np.float32}
 
     # -- setup_* (observation.py:46-291) ----------------------------------------
     def setup_observation(self, x_ref, y_ref, spatial_scan=False, scan_speed=False):

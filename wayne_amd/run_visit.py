@@ -139,10 +139,16 @@ def run(argv=None):
     ap.add_argument("--max-exposures", type=int, default=None, help="only the first M exposures")
     ap.add_argument("--gpus", type=int, default=1, help="start rank processes, one per GPU of this node")
     ap.add_argument("--ranks-per-gpu", type=int, default=1, help="... and this many to a GPU (small sub-arrays)")
+    ap.add_argument("--float64-reads", action="store_true",
+                    help="float64 reads from the device (the reference's arithmetic to the file) instead of float32 ones")
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.ranks_per_gpu < 1:
         raise SystemExit("--gpus and --ranks-per-gpu must be at least 1")
     n_ranks = args.gpus * args.ranks_per_gpu
+    given = list(sys.argv[1:] if argv is None else argv)
+    if n_ranks > 1 and "WORLD_SIZE" not in os.environ and any(a == "--device" or a.startswith("--device=") for a in given):
+        # forwarded to every rank it would put them all on one GPU: each rank takes its device from LOCAL_RANK
+        raise SystemExit("--device cannot be combined with --gpus / --ranks-per-gpu (a rank's device is its LOCAL_RANK)")
     if n_ranks > 1 and "WORLD_SIZE" not in os.environ:
         # the launcher: nothing in this process has touched a GPU; the children are ranks of a fresh interpreter each
         child = [a for a in (sys.argv[1:] if argv is None else list(argv))]
@@ -169,11 +175,16 @@ def run(argv=None):
     obs = build_observation(cfg, base_dir, cal, args.device)
     if args.max_exposures is not None:
         obs.exp_start_times = obs.exp_start_times[:args.max_exposures]
+    if args.float64_reads:
+        obs.frame_options["out_dtype"] = np.float64
     os.makedirs(obs.outdir, exist_ok=True)
-    shutil.copy2(args.parameter_file, os.path.join(obs.outdir, os.path.basename(args.parameter_file)))
-    t, lc = obs.show_lightcurve()
-    np.savetxt(os.path.join(obs.outdir, "visit_plan.txt"), np.column_stack([t, lc]), header="JD white_light_model")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        # the visit's own two files are written once, by rank 0 (every rank would write the same bytes, but G x R
+        # processes truncating and rewriting one path is a race a reader can see)
+        shutil.copy2(args.parameter_file, os.path.join(obs.outdir, os.path.basename(args.parameter_file)))
+        t, lc = obs.show_lightcurve()
+        np.savetxt(os.path.join(obs.outdir, "visit_plan.txt"), np.column_stack([t, lc]), header="JD white_light_model")
     frames = obs.run_observation(rank=rank, world=world)
     print("rank %d/%d: wrote %d files to %s" % (rank, world, len(frames), obs.outdir))
     return obs
