@@ -196,3 +196,36 @@ def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):
         # and a second exposure in the same slot starts from clean accumulators and segment bits
         c = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
         np.testing.assert_array_equal(a, c)
+
+
+def test_accumulator_boxes_with_wavelengths_out_of_order(monkeypatch):
+    # the C ABI does not ask for increasing wavelengths: a descriptor whose array starts in the middle of the band (the
+    # grid rotated by half its length: first and last element are neighbours in wavelength, the bins between them cover
+    # the whole trace) must put every electron inside the boxes k_ramp loads -- same reads as with the boxes off, and
+    # accumulators left clean for the next exposure on the slot
+    from wayne_amd import _lib, engine
+    v = helpers.make_visit("small256")
+    pg = helpers.product_generator(v, 0)
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    kw = v.frame_kwargs(0, cosmic_rate=None)
+    for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX):
+        desc = pg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float64, **kw)
+        wl, flux = desc._keep[0], desc._keep[1]
+        W = wl.size
+        assert wl.shape == flux.shape == (W,) and np.all(np.diff(wl) > 0)
+        shift = W // 2
+        wl[:] = np.roll(wl, shift)
+        flux[:] = np.roll(flux, shift)
+        for a in desc._keep:
+            if getattr(a, "shape", None) == (v.K, W):
+                a[:] = np.roll(a, shift, axis=1)
+        assert abs(wl[0] - wl[-1]) < 1e-3 and wl.max() - wl.min() > 0.5
+        ctx = eng.ctx
+        a = ctx.synthesize(desc)
+        _, _, _, acc_after = ctx.debug_fetch(0, acc=True)
+        assert not acc_after.any(), "accumulators left dirty: %g electrons" % acc_after.sum()
+        monkeypatch.setenv("WAYNE_NO_ACC_BOX", "1")
+        b = ctx.synthesize(desc)
+        monkeypatch.delenv("WAYNE_NO_ACC_BOX")
+        np.testing.assert_array_equal(a, b, err_msg="rng_mode %d" % mode)
+        assert (a[-1] - a[0]).max() > 50              # the star is there

@@ -401,18 +401,23 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
 // Where can the accumulators of read interval r be non-zero after the thrower?  An electron lands within
 // sigma sqrt(2 ln 2^34) = 6.87 sigma of its bin in every rng mode (k_lane: "a tile that holds every electron"; k_throw's
 // per-electron mode reaches 6.76 sigma, the replay thrower's rand_r / RAND_MAX 6.56 sigma; k_narrow's window is +-6 px), and the bins of a sub-sample lie
-// on the straight trace between its first and its last wavelength.  So per read: the union over its sub-samples of
+// on the straight trace between its smallest and its largest wavelength.  So per read: the union over its sub-samples of
 // the trace's end points, +- (6.9 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
 // everything) when the numbers are not ones a bound can be built on.
 bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
   const int W = d->n_wl, K = d->n_samples, R = d->n_reads, S = c->S;
   const GrismDev& g = c->g;
   auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
-  double smax = 0.;
+  // (the ABI does not require increasing wavelengths: the ends of the trace are those of the smallest and the largest
+  // wavelength present, wherever they sit in the array -- the trace is linear in the wavelength)
+  double smax = 0., wl_lo = 0., wl_hi = 0.;
   for (int i = 0; i < W; ++i) {
-    const double sl = poly3(g.p_sigl, d->wl_um[i]), sh = poly3(g.p_sigh, d->wl_um[i]);
-    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3)) return false;
+    const double wl = d->wl_um[i];
+    const double sl = poly3(g.p_sigl, wl), sh = poly3(g.p_sigh, wl);
+    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3) || !(std::fabs(wl) < 1e6)) return false;
     smax = std::max(smax, std::max(sl, sh));
+    if (i == 0 || wl < wl_lo) wl_lo = wl;
+    if (i == 0 || wl > wl_hi) wl_hi = wl;
   }
   const double reach = 6.9 * smax + 2.;
   if (!(reach < 400.)) return false;
@@ -423,7 +428,7 @@ bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*b
     double tr[6];
     trace_coeffs(g, d->x_ref[k], d->y_ref[k], tr);
     for (int e = 0; e < 2; ++e) {
-      const double wl = d->wl_um[e ? W - 1 : 0];
+      const double wl = e ? wl_hi : wl_lo;
       const double x = (wl - tr[5]) / tr[4];
       const double y = tr[0] * (x - d->x_ref[k]) + tr[1] + d->y_ref[k];
       const double xs = x - (double)d->sub_scale + kBorder, ys = y - (double)d->sub_scale + kBorder;
