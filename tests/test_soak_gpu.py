@@ -204,11 +204,11 @@ def test_accumulator_boxes_with_wavelengths_out_of_order(monkeypatch):
     # the whole trace) must put every electron inside the boxes k_ramp loads -- same reads as with the boxes off, and
     # accumulators left clean for the next exposure on the slot
     from wayne_amd import _lib, engine
-    v = helpers.make_visit("small256")
-    pg = helpers.product_generator(v, 0)
-    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
-    kw = v.frame_kwargs(0, cosmic_rate=None)
     for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX):
+        v = helpers.make_visit("small256")       # (a fresh one per pass: the descriptor's arrays are views of the visit's)
+        pg = helpers.product_generator(v, 0)
+        eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+        kw = v.frame_kwargs(0, cosmic_rate=None)
         desc = pg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float64, **kw)
         wl, flux = desc._keep[0], desc._keep[1]
         W = wl.size
