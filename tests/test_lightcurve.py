@@ -265,3 +265,32 @@ def test_device_depths_interpolated_in_radius_ratio(gpu_ctx):
     eng.ctx.run_back(0)
     np.testing.assert_allclose(got, clib.lc_depths(flat.z_tr, flat.hidden, flat.planet_spectrum[i0:i1], LD),
                                rtol=0, atol=2e-8)
+
+
+def test_orbit_over_one_exposure_by_interpolation():
+    # depth_inputs evaluates the planet's position at ten Chebyshev points of an exposure's span and interpolates to
+    # its thousands of sub-sample times (lightcurve.planet_orbit_short_span): against the direct evaluation, for
+    # circular and eccentric orbits, edge-on ones (the separation has a corner at mid-transit), spans up to the
+    # routine's limit, regular and irregular sampling, in and out of transit and eclipse
+    from wayne_amd import lightcurve as lc
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    used = 0
+    for trial in range(200):
+        P, a = rng.uniform(0.5, 20), rng.uniform(3, 30)
+        e = float(rng.choice([0.0, 0.0, rng.uniform(0, 0.7)]))
+        inc = float(rng.choice([90.0, rng.uniform(80, 90)]))
+        w, mid = rng.uniform(0, 360), rng.uniform(0, 5)
+        K = int(rng.integers(50, 3000))
+        span = rng.uniform(1e-5, 0.0039) * P
+        t0 = mid + rng.uniform(-1, 1) * P * float(rng.choice([0.0, 0.01, 0.3, 0.5]))
+        t = t0 + (np.sort(rng.uniform(0, span, K)) if trial % 2 else np.linspace(0, span, K))
+        z1, l1 = lc.planet_orbit(P, a, e, inc, w, mid, t)
+        z2, l2 = lc.planet_orbit_short_span(P, a, e, inc, w, mid, t)
+        used += int(z2 is not z1)
+        worst = max(worst, float(np.abs(z1 - z2).max()), float(np.abs(l1 - l2).max()))
+    assert worst < 1e-11, worst           # stellar radii: 1e-12 of a transit depth
+    # beyond the limit, or with few samples, the direct evaluation is what runs
+    t = 5.0 + np.linspace(0, 0.2, 500)
+    np.testing.assert_array_equal(lc.planet_orbit_short_span(3.5, 8.8, 0.1, 87.0, 30.0, 5.05, t)[0],
+                                  lc.planet_orbit(3.5, 8.8, 0.1, 87.0, 30.0, 5.05, t)[0])

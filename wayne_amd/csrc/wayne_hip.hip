@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -164,6 +165,12 @@ struct wayne_ctx {
   GrismDev g{};
   DevBuf sens_wl, sens_val;
   std::vector<double> sens_wl_host, sens_val_host;   // for the host's estimate of the electron count
+  // ... and what that estimate needs per bin, kept while the spectrum handed in stays the same (every exposure of a
+  // visit brings the same wavelengths and stellar flux): est_rate = flux sens dlam 1e4 1e-3 (electrons per ms at
+  // scale 1), the wide fraction and sigma_l of the bin, the largest PSF sigma and the wavelength range
+  std::vector<double> est_wl, est_flux, est_rate, est_ratio, est_sigl;
+  double est_smax = 0., est_wl_lo = 0., est_wl_hi = 0.;
+  bool est_sig_ok = false;
   // calibration
   bool have_cal = false;
   int subarray = 0, N = 0, S = 0, cal_R = 0;
@@ -172,7 +179,9 @@ struct wayne_ctx {
        has_zero = false;
   float sky_max = 0.f, sky_min = 0.f;                            // range of the positive master sky pixels
   std::vector<float> sky_sorted;                                 // those pixels in ascending order (levels = quantiles)
-  std::map<uint32_t, std::vector<uint32_t> > alias_cache;        // float bits of lam_max -> alias table
+  // host time of wayne_exposure_upload by part, microseconds (printed at destroy when WAYNE_UPLOAD_TIMING is set)
+  double up_us[6] = {0, 0, 0, 0, 0, 0};
+  long up_calls = 0;
   Slot slots[kSlots];
   // psf_apply scratch
   DevBuf pa_prefix, pa_nwide, pa_nsplit, pa_nlane, pa_x, pa_y, pa_sl, pa_sh, pa_sub, pa_frame;
@@ -291,10 +300,12 @@ bool sky_alias_fits(double lam) {
 // Walker / Vose alias table of Poisson(lam) over 0 .. kSkyAlias-1, entry = alias << 24 | threshold:
 // a 32-bit word w selects column w >> 24 and keeps it when (w & 0xFFFFFF) < threshold, else takes the
 // alias.  Probabilities in fp64, thresholds rounded to 24 bits (the resolution of a float32 uniform).
-std::vector<uint32_t> build_sky_alias(double lam) {
-  const int n = kSkyAlias;
-  std::vector<double> q((size_t)n, 0.);
+void build_sky_alias(double lam, uint32_t* out /* kSkyAlias */) {
+  constexpr int n = kSkyAlias;
+  double q[n], prob[n];
+  int alias[n], small[n], large[n], n_small = 0, n_large = 0;
   double sum = 0.;
+  for (int k = 0; k < n; ++k) q[k] = 0.;
   if (!(lam > 0.)) { q[0] = 1.; sum = 1.; }
   else {
     // pmf by recurrence from the mode (one exp / log / lgamma per table): p(k+1) = p(k) lam / (k+1)
@@ -304,28 +315,26 @@ std::vector<uint32_t> build_sky_alias(double lam) {
     for (int k = k0; k > 0; --k) q[k - 1] = q[k] * (double)k / lam;
     for (int k = 0; k < n; ++k) sum += q[k];
   }
-  for (int k = 0; k < n; ++k) q[k] = q[k] / sum * n;
-  std::vector<int> small, large;
-  for (int k = 0; k < n; ++k) (q[k] < 1. ? small : large).push_back(k);
-  std::vector<double> prob((size_t)n, 1.);
-  std::vector<int> alias((size_t)n);
-  for (int k = 0; k < n; ++k) alias[k] = k;
-  while (!small.empty() && !large.empty()) {
-    const int s_ = small.back(); small.pop_back();
-    const int l_ = large.back(); large.pop_back();
+  for (int k = 0; k < n; ++k) {
+    q[k] = q[k] / sum * n;
+    if (q[k] < 1.) small[n_small++] = k; else large[n_large++] = k;
+    prob[k] = 1.;
+    alias[k] = k;
+  }
+  while (n_small > 0 && n_large > 0) {
+    const int s_ = small[--n_small];
+    const int l_ = large[--n_large];
     prob[s_] = q[s_];
     alias[s_] = l_;
     q[l_] = (q[l_] + q[s_]) - 1.;
-    (q[l_] < 1. ? small : large).push_back(l_);
+    if (q[l_] < 1.) small[n_small++] = l_; else large[n_large++] = l_;
   }
-  std::vector<uint32_t> out((size_t)n);
   for (int k = 0; k < n; ++k) {
     double t = std::floor(prob[k] * 16777216. + 0.5);
     if (t > 16777215.) t = 16777215.;
     if (t < 0.) t = 0.;
     out[k] = ((uint32_t)alias[k] << 24) | (uint32_t)t;
   }
-  return out;
 }
 
 // Copy `n` elements into the slot's pinned arena and enqueue the host-to-device copy from there.
@@ -343,19 +352,18 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
 // in the longest sub-sample of an exposure
 // (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
 // the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
-double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
-                       unsigned char* lane_order, double* max_chunk_electrons, double* max_narrow) {
-  const int W = d->n_wl, K = d->n_samples;
-  const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
-  const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
-  std::vector<double> chunk_e((size_t)n_chunks, 0.), lane_e((size_t)n_lane_chunks, 0.);
-  double dur_max = 0.;
-  for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
+// (per-bin factors that depend on the spectrum alone are cached in the context: spectrum_cache)
+void spectrum_cache(wayne_ctx* c, const wayne_exposure_desc* d) {
+  const int W = d->n_wl;
+  if ((int)c->est_wl.size() == W && std::memcmp(c->est_wl.data(), d->wl_um, (size_t)W * 8) == 0 &&
+      std::memcmp(c->est_flux.data(), d->flux, (size_t)W * 8) == 0) return;
+  c->est_wl.assign(d->wl_um, d->wl_um + W);
+  c->est_flux.assign(d->flux, d->flux + W);
+  c->est_rate.assign((size_t)W, 0.); c->est_ratio.assign((size_t)W, 0.); c->est_sigl.assign((size_t)W, 0.);
   const GrismDev& g = c->g;
   const std::vector<double>&sw = c->sens_wl_host, &sv = c->sens_val_host;
   auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
-  double total = 0.;
-  *max_narrow = 0.;
+  c->est_smax = 0.; c->est_sig_ok = true;
   for (int i = 0; i < W; ++i) {
     const double x = d->wl_um[i];
     double sens = 1.0;
@@ -370,14 +378,38 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
     }
     const double left = (i == 0) ? (d->wl_um[1] - d->wl_um[0]) / 2. : (x - d->wl_um[i - 1]) / 2.;
     const double right = (i == W - 1) ? (d->wl_um[W - 1] - d->wl_um[W - 2]) / 2. : (d->wl_um[i + 1] - x) / 2.;
-    double cnt = d->flux[i] * sens * (left + right) * 1e4 * dur_max * 1e-3 * d->scale_factor;
+    c->est_rate[i] = d->flux[i] * sens * (left + right) * 1e4 * 1e-3;
+    c->est_ratio[i] = poly3(g.p_ratio, x);
+    const double sl = poly3(g.p_sigl, x), sh = poly3(g.p_sigh, x);
+    c->est_sigl[i] = sl;
+    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3) || !(std::fabs(x) < 1e6)) c->est_sig_ok = false;
+    c->est_smax = std::max(c->est_smax, std::max(sl, sh));
+    if (i == 0 || x < c->est_wl_lo) c->est_wl_lo = x;
+    if (i == 0 || x > c->est_wl_hi) c->est_wl_hi = x;
+  }
+}
+
+double estimate_thrown(wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
+                       unsigned char* lane_order, double* max_chunk_electrons, double* max_narrow) {
+  const int W = d->n_wl, K = d->n_samples;
+  const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
+  const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
+  std::vector<double> chunk_e((size_t)n_chunks, 0.), lane_e((size_t)n_lane_chunks, 0.);
+  double dur_max = 0.;
+  for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
+  spectrum_cache(c, d);
+  const double per_ms = dur_max * d->scale_factor;
+  double total = 0.;
+  *max_narrow = 0.;
+  for (int i = 0; i < W; ++i) {
+    double cnt = c->est_rate[i] * per_ms;
     if (!(cnt > 0.)) continue;
     chunk_e[(size_t)(i / kNarrowThreads)] += cnt;
     lane_e[(size_t)(i / kLaneThreads)] += cnt;
     if (d->rng_mode == WAYNE_RNG_SPLIT) {
-      const double wide = std::floor(std::min(std::max(cnt * poly3(g.p_ratio, x), 0.), cnt));
+      const double wide = std::floor(std::min(std::max(cnt * c->est_ratio[i], 0.), cnt));
       *max_narrow = std::max(*max_narrow, cnt - wide);
-      const double sl = poly3(g.p_sigl, x);
+      const double sl = c->est_sigl[i];
       if (cnt - wide >= (double)kSplitMinHost && cnt - wide <= (double)kSplitMaxNarrow && sl > 0.05 &&
           sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
       if (cnt <= 0.9 * (double)kLaneMax) cnt = 0.;    // thrown by the bin's own lane (k_lane); 10 % headroom for the noise
@@ -404,43 +436,50 @@ double estimate_thrown(const wayne_ctx* c, const wayne_exposure_desc* d, unsigne
 // on the straight trace between its smallest and its largest wavelength.  So per read: the union over its sub-samples of
 // the trace's end points, +- (6.9 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
 // everything) when the numbers are not ones a bound can be built on.
-bool accumulator_boxes(const wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
-  const int W = d->n_wl, K = d->n_samples, R = d->n_reads, S = c->S;
+bool accumulator_boxes(wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
+  const int K = d->n_samples, R = d->n_reads, S = c->S;
   const GrismDev& g = c->g;
-  auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
-  // (the ABI does not require increasing wavelengths: the ends of the trace are those of the smallest and the largest
-  // wavelength present, wherever they sit in the array -- the trace is linear in the wavelength)
-  double smax = 0., wl_lo = 0., wl_hi = 0.;
-  for (int i = 0; i < W; ++i) {
-    const double wl = d->wl_um[i];
-    const double sl = poly3(g.p_sigl, wl), sh = poly3(g.p_sigh, wl);
-    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3) || !(std::fabs(wl) < 1e6)) return false;
-    smax = std::max(smax, std::max(sl, sh));
-    if (i == 0 || wl < wl_lo) wl_lo = wl;
-    if (i == 0 || wl > wl_hi) wl_hi = wl;
-  }
-  const double reach = 6.9 * smax + 2.;
+  spectrum_cache(c, d);      // (the ABI does not require increasing wavelengths: smallest and largest present, wherever they sit)
+  if (!c->est_sig_ok) return false;
+  // + 1 px: the ends of the trace are taken at the four corners of the rectangle a read's star positions span, not at
+  // every sub-sample (thousands on a finely sampled scan).  The end points move monotonically with the star (d end / d
+  // star = 1 + O(1e-3)); what a corner can miss is the curvature of the trace polynomials over the rectangle -- their
+  // second derivatives are ~1e-8 / px^2, a scan is a few hundred pixels long: < 0.01 px
+  const double reach = 6.9 * c->est_smax + 2. + 1.;
   if (!(reach < 400.)) return false;
-  for (int r = 0; r < 16; ++r) { box[r][0] = box[r][2] = 0x3FFFFFFF; box[r][1] = box[r][3] = -0x3FFFFFFF; }
+  double lo_x[16], hi_x[16], lo_y[16], hi_y[16];
+  bool any[16];
+  for (int r = 0; r < 16; ++r) { any[r] = false; lo_x[r] = lo_y[r] = 0.; hi_x[r] = hi_y[r] = 0.; }
   for (int k = 0; k < K; ++k) {
     const int r = d->sample_read[k];
     if (r < 0 || r >= R || r >= 16) return false;
-    double tr[6];
-    trace_coeffs(g, d->x_ref[k], d->y_ref[k], tr);
-    for (int e = 0; e < 2; ++e) {
-      const double wl = e ? wl_hi : wl_lo;
-      const double x = (wl - tr[5]) / tr[4];
-      const double y = tr[0] * (x - d->x_ref[k]) + tr[1] + d->y_ref[k];
-      const double xs = x - (double)d->sub_scale + kBorder, ys = y - (double)d->sub_scale + kBorder;
-      if (!(std::fabs(xs) < 1e6 && std::fabs(ys) < 1e6)) return false;
-      box[r][0] = std::min(box[r][0], (int)std::floor(xs - reach));
-      box[r][1] = std::max(box[r][1], (int)std::floor(xs + reach) + 1);
-      box[r][2] = std::min(box[r][2], (int)std::floor(ys - reach));
-      box[r][3] = std::max(box[r][3], (int)std::floor(ys + reach) + 1);
+    const double xr = d->x_ref[k], yr = d->y_ref[k];
+    if (!(std::fabs(xr) < 1e6 && std::fabs(yr) < 1e6)) return false;
+    if (!any[r]) { any[r] = true; lo_x[r] = hi_x[r] = xr; lo_y[r] = hi_y[r] = yr; }
+    else {
+      lo_x[r] = std::min(lo_x[r], xr); hi_x[r] = std::max(hi_x[r], xr);
+      lo_y[r] = std::min(lo_y[r], yr); hi_y[r] = std::max(hi_y[r], yr);
     }
   }
   for (int r = 0; r < 16; ++r) {
-    if (box[r][0] > box[r][1]) { box[r][0] = box[r][1] = box[r][2] = box[r][3] = 0; continue; }   // a read without sub-samples
+    box[r][0] = box[r][2] = 0x3FFFFFFF; box[r][1] = box[r][3] = -0x3FFFFFFF;
+    if (!any[r]) { box[r][0] = box[r][1] = box[r][2] = box[r][3] = 0; continue; }   // a read without sub-samples
+    for (int corner = 0; corner < 4; ++corner) {
+      const double xr = (corner & 1) ? hi_x[r] : lo_x[r], yr = (corner & 2) ? hi_y[r] : lo_y[r];
+      double tr[6];
+      trace_coeffs(g, xr, yr, tr);
+      for (int e = 0; e < 2; ++e) {
+        const double wl = e ? c->est_wl_hi : c->est_wl_lo;
+        const double x = (wl - tr[5]) / tr[4];
+        const double y = tr[0] * (x - xr) + tr[1] + yr;
+        const double xs = x - (double)d->sub_scale + kBorder, ys = y - (double)d->sub_scale + kBorder;
+        if (!(std::fabs(xs) < 1e6 && std::fabs(ys) < 1e6)) return false;
+        box[r][0] = std::min(box[r][0], (int)std::floor(xs - reach));
+        box[r][1] = std::max(box[r][1], (int)std::floor(xs + reach) + 1);
+        box[r][2] = std::min(box[r][2], (int)std::floor(ys - reach));
+        box[r][3] = std::max(box[r][3], (int)std::floor(ys + reach) + 1);
+      }
+    }
     box[r][0] = std::max(box[r][0], 0); box[r][2] = std::max(box[r][2], 0);
     box[r][1] = std::min(box[r][1], S); box[r][3] = std::min(box[r][3], S);
   }
@@ -497,14 +536,10 @@ int prepare_sky_tables(wayne_ctx* c, Slot& s) {
         std::memset(s.sky_tab_host, 0, bytes);
         for (size_t t = 0; t < keys.size(); ++t) {
           if (!fits[t / L]) continue;
-          auto it = c->alias_cache.find(keys[t]);
-          if (it == c->alias_cache.end()) {
-            float lam;
-            std::memcpy(&lam, &keys[t], 4);
-            if (c->alias_cache.size() > 4096) c->alias_cache.clear();
-            it = c->alias_cache.emplace(keys[t], build_sky_alias((double)lam)).first;
-          }
-          std::memcpy(s.sky_tab_host + t * kSkyAlias, it->second.data(), kSkyAlias * sizeof(uint32_t));
+          // (a table is ~1 us to build -- no cache: the sky level, and with it every rate, changes with the exposure)
+          float lam;
+          std::memcpy(&lam, &keys[t], 4);
+          build_sky_alias((double)lam, s.sky_tab_host + t * kSkyAlias);
         }
         HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
@@ -682,6 +717,10 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
 
 void wayne_ctx_destroy(wayne_ctx* c) {
   if (!c) return;
+  if (std::getenv("WAYNE_UPLOAD_TIMING") && c->up_calls > 0)
+    std::fprintf(stderr, "wayne_exposure_upload: %ld calls; us per call: staging + copies %.1f, electron estimate %.1f, "
+                 "accumulator boxes %.1f, sky tables %.1f\n", c->up_calls, c->up_us[0] / c->up_calls,
+                 c->up_us[1] / c->up_calls, c->up_us[2] / c->up_calls, c->up_us[3] / c->up_calls);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -987,6 +1026,13 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   (void)hipSetDevice(c->device);
   use_slot_stream(c, slot);
   Slot& s = c->slots[slot];
+  const auto t_up0 = std::chrono::steady_clock::now();
+  auto lap = [&](int part, std::chrono::steady_clock::time_point& t_) {
+    const auto now = std::chrono::steady_clock::now();
+    c->up_us[part] += std::chrono::duration<double, std::micro>(now - t_).count();
+    t_ = now;
+  };
+  auto t_lap = t_up0;
   // the slot is unusable until this call has succeeded: a failure half way leaves re-pointed views behind
   s.uploaded = false;
   s.front_done = false;
@@ -1075,7 +1121,9 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.d.lc_z = s.d.lc_hidden = s.d.lc_rp = nullptr;
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
+  lap(0, t_lap);     // staging, copies, reservations
   s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons, &s.max_narrow);
+  lap(1, t_lap);
   {
     // k_lane's batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled
     // scan (K in the thousands) otherwise launches tens of thousands of workgroups of ~1000 electrons each
@@ -1089,6 +1137,7 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     if (const char* e = std::getenv("WAYNE_THIN")) s.thin = std::atoi(e) != 0;
   }
   s.use_box = accumulator_boxes(c, d, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
+  lap(2, t_lap);
   {
     const size_t seg_bytes = ((SS + 63) / 64) * sizeof(uint32_t);
     if (s.seg.cap < seg_bytes) {
@@ -1097,6 +1146,8 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     }
   }
   if ((rc = prepare_sky_tables(c, s))) return rc;
+  lap(3, t_lap);
+  c->up_calls += 1;
   s.force_throw = false;
   s.uploaded = true;
   s.front_done = false;

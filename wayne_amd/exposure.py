@@ -147,17 +147,37 @@ class Exposure(object):
         if filename is None:
             filename = self.exp_info.get("filename", "exposure_raw.fits")
         path = os.path.join(out_dir, filename)
-        hdus = [fitsio.HDU(self.generate_science_header(ldcoeffs=ldcoeffs), None)]
+        # Rendered piece by piece rather than HDU object by HDU object: the extension headers are the same bytes in every
+        # file of a visit (cached blocks), the reads are byte-swapped into ONE big-endian cube and the file goes out in one
+        # os.writev -- what is left under the interpreter lock per file is the primary header's ~100 (memoised) cards.
+        # Byte for byte the file fitsio.write([HDU, ...]) produces (tests/test_visit_driver.py).
+        primary = fitsio._image_hdu_parts(None, self.generate_science_header(ldcoeffs=ldcoeffs).cards, primary=True)[0]
         n = len(self.reads)
+        arrs = [np.asarray(d) for d, _ in self.reads]
+        same = n > 0 and all(a.shape == arrs[0].shape and a.ndim == 2 for a in arrs)
+        pieces = [primary]
+        if same:
+            cube = np.empty((n,) + arrs[0].shape, dtype=">f8")
+            for i, a in enumerate(arrs):
+                cube[i] = a                                     # cast + byte swap, interpreter lock released
+            pad = b"\x00" * ((-cube[0].nbytes) % fitsio.BLOCK)
         for i, (data, hdr) in enumerate(reversed(self.reads)):
             samp = n - 1 - i
-            cards = [("SAMPNUM", samp, ""), ("SAMPTIME", float(hdr.get("SAMPTIME", 0.0)), "s"),
-                     ("DELTATIM", float(hdr.get("DELTATIM", 0.0)), "s"), ("CRPIX1", hdr.get("CRPIX1", 0), ""),
+            sampt, delt, crpix = float(hdr.get("SAMPTIME", 0.0)), float(hdr.get("DELTATIM", 0.0)), hdr.get("CRPIX1", 0)
+            cards = [("SAMPNUM", samp, ""), ("SAMPTIME", sampt, "s"), ("DELTATIM", delt, "s"), ("CRPIX1", crpix, ""),
                      ("EXTVER", i + 1, ""), ("BUNIT", "COUNTS", "")]
-            hdus.append(fitsio.HDU(fitsio.Header(cards), np.asarray(data, dtype=np.float64), name="SCI"))
+            if same:
+                shape = arrs[samp].shape
+                pieces.append(fitsio.cached_header_block(("SCI", shape, samp, sampt, delt, type(crpix), crpix, i + 1),
+                                                         cards, data_shape=shape, name="SCI"))
+                pieces.append(memoryview(cube[samp].reshape(-1)).cast("B"))
+                if pad:
+                    pieces.append(pad)
+            else:
+                pieces += fitsio._image_hdu_parts(np.asarray(data, dtype=np.float64), cards, primary=False, name="SCI")
             for ext in ("ERR", "DQ", "SAMP", "TIME"):
-                hdus.append(fitsio.HDU(fitsio.Header([("EXTVER", i + 1, "")]), None, name=ext))
-        fitsio.write(path, hdus)        # (replaces an existing file, as the reference's remove + writeto does: exposure.py:211-213)
+                pieces.append(fitsio.cached_header_block((ext, i + 1), [("EXTVER", i + 1, "")], name=ext))
+        fitsio.write_pieces(path, pieces)   # (replaces an existing file, as the reference's remove + writeto does: exposure.py:211-213)
         return path
 
 

@@ -30,6 +30,8 @@ from . import _lib, engine as _engine, exposure, lightcurve, tools
 from .trend_generators import scan_speed_varations
 
 MS_PER_YEAR = 365.25 * 86400. * 1000.
+_CROP_CACHE = {}      # spectrum grid -> crop indices (build_descriptor)
+_TIMES_CACHE = {}     # (read times, sample rate) -> sample starts / mid points / durations / read index
 
 
 class WFC3SimNoDarkFileWarning(Warning):
@@ -48,6 +50,7 @@ class ExposureGenerator(object):
         self.calibration = calibration if calibration is not None else grism.calibration
         self.device, self.seed, self.exposure_index = device, seed, exposure_index
         self._submit_slot, self._pending = None, None      # pipelined use: submit() / collect()
+        self._prepare_only, self._prepared = False, None   # ... or prepare() on one thread, launch() / collect() on another
 
         self.exptime = self.detector.exptime(NSAMP, SUBARRAY, SAMPSEQ)             # s
         self.read_times = self.detector.get_read_times(NSAMP, SUBARRAY, SAMPSEQ)   # s
@@ -66,20 +69,27 @@ class ExposureGenerator(object):
         sub-sample of each read (exposure_generator.py:531-579): sample at
         `sample_rate` from the previous read up to each read; the last sample
         before a read is cut short so that it ends on the read."""
-        read_times = self.read_times * 1000.
-        starts, read_index, i, previous = [], [], -1, 0.
-        for read_time in read_times:
-            s = np.arange(previous, read_time, sample_rate)
-            starts.append(s)
-            i += len(s)
-            read_index.append(i)
-            previous = read_time
-        sample_starts = np.concatenate(starts)
-        ends = np.roll(sample_starts, -1)
-        ends[-1] = read_times[-1]
-        sample_durations = ends - sample_starts
-        sample_mid_points = sample_starts + (sample_durations / 2)
-        return sample_starts, sample_mid_points, sample_durations, read_index
+        key = (tuple(float(t) for t in self.read_times), float(sample_rate))
+        hit = _TIMES_CACHE.get(key)
+        if hit is None:
+            read_times = self.read_times * 1000.
+            starts, read_index, i, previous = [], [], -1, 0.
+            for read_time in read_times:
+                s = np.arange(previous, read_time, sample_rate)
+                starts.append(s)
+                i += len(s)
+                read_index.append(i)
+                previous = read_time
+            sample_starts = np.concatenate(starts)
+            ends = np.roll(sample_starts, -1)
+            ends[-1] = read_times[-1]
+            sample_durations = ends - sample_starts
+            sample_mid_points = sample_starts + (sample_durations / 2)
+            if len(_TIMES_CACHE) > 16:
+                _TIMES_CACHE.clear()
+            hit = _TIMES_CACHE[key] = (sample_starts, sample_mid_points, sample_durations, read_index)
+        # (the same numbers for every exposure of a visit; handed out as copies: callers scale the durations)
+        return hit[0].copy(), hit[1].copy(), hit[2].copy(), list(hit[3])
 
     def _gen_sample_yref(self, y_ref, mid_points, scan_speed):
         """y of the star at each sub-sample mid-point; scan_speed in px/ms (:517-529)."""
@@ -137,6 +147,9 @@ class ExposureGenerator(object):
             add_flat, cosmic_rate, sky_background, scale_factor, add_gain_variations, add_non_linear,
             clip_values_det_limits, add_read_noise, add_stellar_noise, add_initial_bias, progress_bar, threads,
             rng_mode, out_dtype, reference_quirks, exact_samplers)
+        if self._prepare_only:
+            self._prepared = (eng, desc, start_time)        # host half done; launch(slot) does the rest
+            return None
         if slot is not None:
             # pipelined use (submit / collect): enqueue everything and return; the reads are picked up later
             eng.ctx.upload(slot, desc)
@@ -176,6 +189,27 @@ class ExposureGenerator(object):
             (self.staring_frame if staring else self.scanning_frame)(*args, **kw)
         finally:
             self._submit_slot = None
+        return self
+
+    def prepare(self, *args, staring=False, **kw):
+        """The HOST half of a scanning (or staring) frame -- same arguments -- and nothing else: sample timing, scan
+        positions, jitter draws, the descriptor.  No GPU call, so it may run on another thread than the one that
+        owns the context; launch(slot) then uploads and enqueues it, collect() returns the Exposure."""
+        self._prepare_only = True
+        try:
+            (self.staring_frame if staring else self.scanning_frame)(*args, **kw)
+        finally:
+            self._prepare_only = False
+        return self
+
+    def launch(self, slot):
+        """Upload a prepared frame into context slot `slot` and enqueue its kernels and the copy of its reads."""
+        eng, desc, start_time = self._prepared
+        self._prepared = None
+        eng.ctx.upload(int(slot), desc)
+        eng.ctx.run(int(slot))
+        eng.ctx.fetch_async(int(slot))
+        self._pending = (eng, int(slot), start_time)
         return self
 
     def collect(self):
@@ -251,8 +285,16 @@ class ExposureGenerator(object):
         n_dur = min(K, len(sample_durations))
         s_dur[:n_dur] = np.asarray(sample_durations, dtype=float)[:n_dur]
 
-        # crop to the grism's limits (:332-334)
-        i0, i1 = tools.crop_spectrum_ind(self.grism.wl_limits[0], self.grism.wl_limits[-1], wl)
+        # crop to the grism's limits (:332-334); every exposure of a visit brings the same grid: looked up once
+        key = (wl.size, float(wl[0]), float(wl[-1]), float(wl[wl.size // 2]), self.grism.wl_limits[0],
+               self.grism.wl_limits[-1])
+        hit = _CROP_CACHE.get(key)
+        if hit is None or not np.array_equal(hit[0], wl):
+            if len(_CROP_CACHE) > 16:
+                _CROP_CACHE.clear()
+            hit = _CROP_CACHE[key] = (wl.copy(), tools.crop_spectrum_ind(self.grism.wl_limits[0],
+                                                                         self.grism.wl_limits[-1], wl))
+        i0, i1 = hit[1]
         s_wl = wl[i0:i1]
         flux = stellar_flux[i0:i1]
         depth = None

@@ -269,19 +269,57 @@ def _image_hdu_parts(data, extra_cards, primary, name=None):
     return [_header_bytes(cards), payload, b"\x00" * ((-nbytes) % BLOCK)]
 
 
+def _write_all(fd, pieces):
+    """Write the byte pieces to the file descriptor with os.writev (one system call for a whole file, the interpreter
+    lock released while it runs), going on after a short write -- a signal, a quota, a payload beyond 2 GiB -- until
+    every byte is out.  (A raw FileIO.write may return early and Python does not retry it: a silently truncated file.)"""
+    import os
+    bufs = [memoryview(p_).cast("B") for p_ in pieces if len(p_)]
+    IOV = 512
+    while bufs:
+        n = os.writev(fd, bufs[:IOV])
+        while n > 0:
+            if n >= len(bufs[0]):
+                n -= len(bufs[0])
+                bufs.pop(0)
+            else:
+                bufs[0] = bufs[0][n:]
+                n = 0
+        while bufs and not len(bufs[0]):
+            bufs.pop(0)
+
+
+def write_pieces(path, pieces):
+    """Write pre-rendered pieces (header blocks, big-endian payloads, padding) as one file; an existing file is
+    replaced (truncated in place)."""
+    import os
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        _write_all(fd, pieces)
+    finally:
+        os.close(fd)
+
+
 def write(path, hdus):
     """Write [HDU, ...]; the first becomes the primary HDU.  An existing file is replaced."""
-    with open(path, "wb", buffering=0) as f:
-        small = []                      # consecutive header / padding pieces go out in one write
-        for i, h in enumerate(hdus):
-            cards = h.header.cards if isinstance(h.header, Header) else list(h.header or [])
-            head, payload, pad = _image_hdu_parts(h.data, cards, primary=(i == 0), name=h.name or None)
-            small.append(head)
-            if len(payload):
-                f.write(b"".join(small))
-                small = []
-                f.write(payload)
-            if pad:
-                small.append(pad)
-        if small:
-            f.write(b"".join(small))
+    pieces = []
+    for i, h in enumerate(hdus):
+        cards = h.header.cards if isinstance(h.header, Header) else list(h.header or [])
+        pieces += _image_hdu_parts(h.data, cards, primary=(i == 0), name=h.name or None)
+    write_pieces(path, pieces)
+
+
+_BLOCK_CACHE = {}
+
+
+def cached_header_block(key, cards, data_shape=None, dtype_code="f8", name=None, primary=False):
+    """The header bytes of an image HDU whose cards are a pure function of `key` (memoised): the five extensions of a
+    read carry the same few cards in every file of a visit -- rendering them per file kept the writer threads holding
+    the interpreter lock for a millisecond per 266 x 266 exposure.  `data_shape` None: a data-less HDU."""
+    hit = _BLOCK_CACHE.get(key)
+    if hit is None:
+        if len(_BLOCK_CACHE) > 4096:
+            _BLOCK_CACHE.clear()
+        data = None if data_shape is None else np.empty((0,) * 0 + tuple(data_shape), dtype=dtype_code)[...]
+        hit = _BLOCK_CACHE[key] = _image_hdu_parts(data, cards, primary=primary, name=name)[0]
+    return hit

@@ -116,9 +116,9 @@ def uniform_overlap_fraction(z, p):
     return out
 
 
-def planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array):
-    """Projected star-planet separation z (stellar radii) and the planet's
-    line-of-sight coordinate (> 0: in front of the star) at each time."""
+def planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array):
+    """The planet's position in stellar radii at each time: (X, Y) on the sky, Z along the line of sight (> 0: in
+    front of the star)."""
     t = np.asarray(time_array, dtype=float)
     e = float(eccentricity)
     inc = np.radians(inclination_deg)
@@ -138,7 +138,69 @@ def planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_
     X = -r * np.cos(w + f)
     Y = -r * np.sin(w + f) * np.cos(inc)
     Zlos = r * np.sin(w + f) * np.sin(inc)
+    return X, Y, Zlos
+
+
+def planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array):
+    """Projected star-planet separation z (stellar radii) and the planet's
+    line-of-sight coordinate (> 0: in front of the star) at each time."""
+    X, Y, Zlos = planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array)
     return np.sqrt(X * X + Y * Y), Zlos
+
+
+_CHEB_NODES = 10
+_cheb_cache = {}
+
+
+def _cheb_matrix(x):
+    """Barycentric interpolation matrix from the _CHEB_NODES Chebyshev points of [-1, 1] to the abscissae x."""
+    m = _CHEB_NODES
+    j = np.arange(m)
+    nodes = np.cos(np.pi * j / (m - 1))
+    wts = (-1.0) ** j
+    wts[0] *= 0.5
+    wts[-1] *= 0.5
+    d = x[:, None] - nodes[None, :]
+    exact = d == 0.0
+    d[exact] = 1.0
+    B = wts[None, :] / d
+    B /= B.sum(axis=1)[:, None]
+    rows = exact.any(axis=1)
+    B[rows] = exact[rows].astype(float)
+    return nodes, B
+
+
+def planet_orbit_short_span(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array):
+    """planet_orbit for the K sub-sample times of ONE exposure (thousands of them on a finely sampled scan: 2233 in
+    the reference's example visit, the host's largest per-exposure cost at 0.15 ms).  Over an exposure the planet moves
+    along ~1e-4 of its orbit and its position is an analytic function of time, so X, Y and Z are evaluated at ten
+    Chebyshev points of the span and interpolated (barycentric form; the n-th term of their Taylor series falls like
+    (2 pi span / period)^n / n!: the interpolant is exact to rounding, tests/test_lightcurve.py) -- the position, not
+    the separation sqrt(X^2 + Y^2), which has a corner at mid-transit for an edge-on orbit.  Longer spans (more than
+    0.4 % of the period: half an hour of a five-day orbit) or few samples take planet_orbit."""
+    t = np.asarray(time_array, dtype=float)
+    if t.size < 4 * _CHEB_NODES:
+        return planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, t)
+    t_lo, t_hi = float(t.min()), float(t.max())
+    half = 0.5 * (t_hi - t_lo)
+    if not (0.0 < half <= 0.002 * period):
+        return planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, t)
+    mid = 0.5 * (t_hi + t_lo)
+    # the sub-sample times of every exposure of a visit are the same offsets from its start: one matrix serves them all
+    off = t - t[0]
+    key = (t.size, off[1], off[-1], half)
+    hit = _cheb_cache.get(key)
+    if hit is None or not np.array_equal(hit[0], off):
+        x = (t - mid) / half
+        nodes, B = _cheb_matrix(x)
+        if len(_cheb_cache) > 64:
+            _cheb_cache.clear()
+        hit = _cheb_cache[key] = (off.copy(), nodes, B)
+    _, nodes, B = hit
+    X, Y, Zlos = planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time,
+                                 mid + half * nodes)
+    P = B @ np.stack([X, Y, Zlos], axis=1)
+    return np.sqrt(P[:, 0] * P[:, 0] + P[:, 1] * P[:, 1]), P[:, 2]
 
 
 def transit(ld, rp_over_rs, period, sma_over_rs, eccentricity, inclination, periastron, mid_time, time_array):
@@ -159,9 +221,12 @@ def eclipse(fp_over_fs, rp_over_rs, period, sma_over_rs, eccentricity, inclinati
 def depth_inputs(period, sma_over_rs, eccentricity, inclination, periastron, mid_time, time_array, rp_white):
     """The K-vectors the device kernel needs: z for the transit (>= 10 when the planet is
     behind the star) and the hidden fraction of the planet for the eclipse term."""
-    z, los = planet_orbit(period, sma_over_rs, eccentricity, inclination, periastron, mid_time, time_array)
+    z, los = planet_orbit_short_span(period, sma_over_rs, eccentricity, inclination, periastron, mid_time, time_array)
     z_tr = np.where(los > 0, z, 10.0 + z)
-    hidden = np.where(los < 0, uniform_overlap_fraction(z, rp_white), 0.0)
+    behind = los < 0
+    hidden = np.zeros(z.shape)
+    if behind.any():                     # (the eclipse side of the orbit only: in transit there is nothing to evaluate)
+        hidden[behind] = uniform_overlap_fraction(z[behind], rp_white)
     return z_tr, hidden
 
 

@@ -201,7 +201,9 @@ class Observation(object):
         if rank == 0:
             frames[0] = self._generate_direct_image(write_fits)
         # files are written by background threads while the GPU works on the next exposures
+        import sys
         from .exposure import FitsWriterPool
+        old_interval = sys.getswitchinterval()
         pool = FitsWriterPool() if write_fits else None
         # ... and the host prepares exposure n+1.. while the GPU generates n: up to `depth` exposures
         # in flight on alternating context slots (even / odd slots run on different HIP streams)
@@ -217,22 +219,58 @@ class Observation(object):
             else:
                 frames[j + 1] = frame
 
+        # ... on two host threads: a producer runs the host half of every exposure (sample times, orbit phases, jitter
+        # draws, the descriptor: ExposureGenerator.prepare -- no GPU call), this thread uploads, launches and collects.
+        # Their C calls release the interpreter lock, so the example visit is paced by the device, not by Python.
+        import queue
+        import threading
+        ahead = queue.Queue(maxsize=depth + 1)
+        mine = list(range(rank, len(self.exp_start_times), world))
+
+        def produce():
+            try:
+                for i in mine:
+                    ahead.put((i, self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False,
+                                                          prepare_only=True)))
+            except BaseException as e:          # surfaced in the consuming thread
+                ahead.put(e)
+                return
+            ahead.put(None)
+
+        producer = threading.Thread(target=produce, daemon=True)
+        sys.setswitchinterval(min(old_interval, 2e-4))
+        producer.start()
         try:
-            for n, i in enumerate(range(rank, len(self.exp_start_times), world)):
+            n = 0
+            while True:
+                item = ahead.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, gen = item
                 if len(in_flight) >= depth:
                     finish_oldest()
-                in_flight.append((i, self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False,
-                                                             submit_slot=n % (depth + 1))))
+                in_flight.append((i, gen.launch(n % (depth + 1))))
+                n += 1
             while in_flight:
                 finish_oldest()
         finally:
+            while producer.is_alive():          # (after an error: let the producer run out instead of blocking on put)
+                try:
+                    ahead.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            producer.join()
             if pool is not None:
                 pool.close()
+            sys.setswitchinterval(old_interval)
         return frames
 
-    def _generate_exposure(self, expstart, number, write_fits=True, submit_slot=None):
+    def _generate_exposure(self, expstart, number, write_fits=True, submit_slot=None, prepare_only=False):
         """observation.py:415-504.  With `submit_slot` the exposure is only enqueued on that context
-        slot and the ExposureGenerator is returned: call its collect() for the Exposure."""
+        slot and the ExposureGenerator is returned: call its collect() for the Exposure.  With `prepare_only`
+        only its host half runs (ExposureGenerator.prepare): launch(slot) and collect() follow on the context's thread."""
         index_number = number - 1
         filename = "{:04d}_raw.fits".format(number)
         exp_gen = ExposureGenerator(self.detector, self.grism, self.NSAMP, self.SAMPSEQ, self.SUBARRAY, self.planet,
@@ -260,6 +298,8 @@ class Observation(object):
         else:
             args = (x_ref, y_ref, self.x_jitter, self.y_jitter, self.wl, self.stellar_flux, planet_depths,
                     sample_mid_points, sample_durations, read_index)
+        if prepare_only:
+            return exp_gen.prepare(*args, staring=not self.spatial_scan, **common)
         if submit_slot is not None:
             return exp_gen.submit(submit_slot, *args, staring=not self.spatial_scan, **common)
         exp_frame = exp_gen.scanning_frame(*args, **common) if self.spatial_scan else exp_gen.staring_frame(*args, **common)
