@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16
 REPS = 5
-SUSTAIN_S = 2.5       # length of the sustained-rate pass
+SUSTAIN_S = 6.5       # length of the sustained-rate pass (longer than the period of the driver's gpu_busy sampler)
 RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th exposure (they cost the stream ~10 us a pair)
 
 
@@ -296,6 +296,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    own_rates = []       # one entry per timed() call: what THIS rank did by its own clock (not the max over ranks)
+
     def timed(slot_of, steps, warmup, events_every=0):
         """Exactly `steps` exposures after `warmup` untimed ones, bracketed by barrier + synchronise;
         returns the elapsed seconds (max over ranks).  events_every = n: the selected kernels' HIP events are
@@ -311,6 +313,7 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        own_rates.append(steps / elapsed if (steps and elapsed > 0) else 0.0)    # this rank's own exposures/s
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -333,18 +336,29 @@ def main():
     ctx.profile_select(["k_ramp"])
     ctx.profile_enable(True)
     ctx.profile_reset()
+    del own_rates[:]
     reps = [timed(slot_of, args.steps, 0, events_every=RAMP_EVENTS_EVERY) for _ in range(REPS)]
+    rank_rates = list(own_rates)                      # this rank's exposures/s in each repetition of the timed region
     ctx.profile_enable(True)
     prof_ramp = ctx.profile_get()
     elapsed = float(np.median(reps))
+    # every exposure of the timed region must have been complete: a slot whose status word says otherwise would have
+    # been run a second time by a download -- which a loop of run() calls never makes
+    statuses = [ctx.status(slot_of(j)) for j in range(min(n_res, args.steps))]
+    reruns_timed = sum(1 for st in statuses if st != 0)
+    if reruns_timed:
+        raise SystemExit("rank %d: %d exposures of the timed region were incomplete (status %s)" % (
+            rank, reruns_timed, sorted(set(statuses))))
 
     ranks_reported = 1
+    per_rank = {0: rank_rates}
     if dist is not None:
         got = [None] * world
-        dist.all_gather_object(got, (rank, args.steps))
-        ranks_reported = len(set(r for r, _ in got))
-        if ranks_reported != world or any(s != args.steps for _, s in got):
+        dist.all_gather_object(got, (rank, args.steps, rank_rates))
+        ranks_reported = len(set(r for r, _, _ in got))
+        if ranks_reported != world or any(s != args.steps for _, s, _ in got):
             raise SystemExit("ranks disagree: %s" % (got,))
+        per_rank = {r: rates for r, _, rates in got}
 
     # breakdown pass (not part of `value`): the same exposures again with every kernel timed
     ctx.profile_select(None)
@@ -492,8 +506,11 @@ def main():
             "ranks_reported": ranks_reported,
             "repetitions": {"n": REPS, "steps_each": args.steps, "values": [args.steps * n_gpus / e for e in reps],
                             "median": rates[len(rates) // 2], "min": rates[0], "max": rates[-1],
+                            "per_rank_exposures_s": {str(r): [round(x, 1) for x in per_rank[r]] for r in sorted(per_rank)},
+                            "incomplete_exposures": reruns_timed,
                             "note": "value = the median repetition; each is exactly `steps` exposures per rank between "
-                                    "barrier + synchronise, max over ranks"},
+                                    "barrier + synchronise, max over ranks; per_rank_exposures_s: every rank's own rate "
+                                    "in each repetition by its own clock (an imbalance shows here, not in the max)"},
             "config": {"workload": "%s: %s spatial scan %g px/s, SUBARRAY=%d (frame %dx%d), %s NSAMP=%d, "
                                    "K=%d sub-samples, W=%d bins, %.3g electrons/exposure, all detector effects on "
                                    "(flat, sky, cosmic rays, gain, dark, non-linearity, clip, read noise), "

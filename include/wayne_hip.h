@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 4
+#define WAYNE_ABI_VERSION 5
 
 /* status codes */
 #define WAYNE_OK 0
@@ -219,6 +219,14 @@ int wayne_exposure_upload(wayne_ctx *ctx, int slot, const wayne_exposure_desc *d
 /* Enqueue the whole synthesis of slot `slot` on the context stream
  * (asynchronous; inputs and outputs stay in HBM). */
 int wayne_exposure_run(wayne_ctx *ctx, int slot);
+/* The status word of the slot's last run (synchronises its stream): 0 = complete; bit 0 = a count overflowed (the
+ * download / wait calls report it as WAYNE_E_OVERFLOW); bit 1 = a bin held more electrons than the launch sequence
+ * chosen from the host's estimate handles -- wayne_exposure_download / _wait / _debug_fetch then run the exposure a
+ * second time with the general sequence, but a caller that only ever calls wayne_exposure_run (a throughput loop) must
+ * look here to learn that a slot's reads are incomplete.  wayne_ctx_reruns: how many such second runs the context has
+ * made (their electrons are counted twice in wayne_profile.electrons). */
+int wayne_exposure_status(wayne_ctx *ctx, int slot, int *status);
+unsigned long long wayne_ctx_reruns(const wayne_ctx *ctx);
 /* Copy the NSAMP reads (read 0 = zero read) of `slot` to the host:
  * NSAMP*S*S float32, or float64 when WAYNE_F_OUT_F64 was set.  Synchronises. */
 int wayne_exposure_download(wayne_ctx *ctx, int slot, void *out_reads);

@@ -10,6 +10,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
@@ -27,7 +29,7 @@ ctx = eng.ctx
 slots = 10
 for j in range(slots):
     eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
-    ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, threads=2, **v.frame_kwargs(j)))
+    ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, threads=2, out_dtype=np.float32, **v.frame_kwargs(j)))
 for j in range(slots):
     ctx.run(2 * j)
 ctx.synchronize()

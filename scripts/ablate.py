@@ -42,7 +42,7 @@ def main():
     out = {}
     for vn, over in variants.items():
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
-        desc = eg.build_descriptor(eng, **v.frame_kwargs(0, **over))
+        desc = eg.build_descriptor(eng, out_dtype=np.float32, **v.frame_kwargs(0, **over))
         ctx.upload(0, desc)
         ctx.run(0)
         ctx.synchronize()

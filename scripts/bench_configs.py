@@ -26,7 +26,7 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     ctx = eng.ctx
     for j in range(n + 2):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
-        ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(j)))
+        ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(j)))
     for j in range(2):
         ctx.run(2 * j)
     ctx.synchronize()
@@ -48,7 +48,7 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     # the same exposures alternating over the context's two streams
     for j in range(n + 2):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
-        ctx.upload(j, eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(j)))
+        ctx.upload(j, eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(j)))
     for j in range(2):
         ctx.run(j)
     ctx.synchronize()

@@ -28,7 +28,7 @@ v = synthetic.Visit("cfg4", det, gr, cal, n_exposures=1)
 eng = engine.get_engine(0, gr, det, cal, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
 ctx = eng.ctx
 eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
-ctx.upload(0, eg.build_descriptor(eng, **v.frame_kwargs(0)))
+ctx.upload(0, eg.build_descriptor(eng, out_dtype=np.float32, **v.frame_kwargs(0)))
 ctx.run(0)
 ctx.synchronize()
 rows = []

@@ -33,7 +33,7 @@ def main():
     bad = 0
     for i in sorted(set([0, 1, 2, n // 3, n // 2, n - 2, n - 1] + list(np.random.default_rng(1).integers(0, n, 12)))):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=int(i))
-        reads = np.stack([r[0] for r in eg.scanning_frame(**v.frame_kwargs(int(i))).reads])
+        reads = np.stack([r[0] for r in eg.scanning_frame(out_dtype=np.float32, **v.frame_kwargs(int(i))).reads])
         ok = (float(reads[-1].sum()) == sums[i][0] and float(reads[1].max()) == sums[i][1]
               and np.array_equal(reads[-1][::7, ::5], sums[i][2]))
         bad += 0 if ok else 1

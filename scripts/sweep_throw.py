@@ -4,6 +4,8 @@ import itertools
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
@@ -24,7 +26,7 @@ for wgs, tile, margin in itertools.product([512, 1024, 1536, 2048, 3072, 4096], 
         os.environ["WAYNE_TILE_INTS"] = str(tile)
     else:
         os.environ.pop("WAYNE_TILE_INTS", None)
-    desc = eg.build_descriptor(eng, rng_mode=mode, **v.frame_kwargs(0))
+    desc = eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(0))
     desc.thrower_margin = margin
     ctx.upload(0, desc)
     ctx.run(0)

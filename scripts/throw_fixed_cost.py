@@ -7,6 +7,8 @@ the intercept is the per-exposure fixed cost (tile zeroing + flush), the slope t
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
@@ -27,7 +29,7 @@ def main():
             eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
             kw = v.frame_kwargs(0, add_flat=flat)
             kw["scale_factor"] = kw["scale_factor"] * f
-            desc = eg.build_descriptor(eng, rng_mode=mode, **kw)
+            desc = eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **kw)
             ctx.upload(0, desc)
             ctx.run(0)
             ctx.synchronize()

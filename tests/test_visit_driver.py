@@ -532,3 +532,43 @@ def test_modulated_sine_exposure_against_the_oracle(blip):
     assert d_acc.max() <= slack + 2233 * 2.0 ** -29 + 1e-9
     assert np.abs(got - want).max() <= 1e-4 + slack / 2.0
     assert np.abs(got[-1]).max() > 50
+
+
+def test_cli_launcher_at_eight_ranks_dry_run(tmp_path):
+    # CPU: `python -m wayne_amd.run_visit -p ... --gpus 8 --dry-run` -- the CLI's own launcher at the rank count of an
+    # 8-GPU node: eight fresh rank processes, each with its RANK / LOCAL_RANK / WORLD_SIZE, its device = its local rank,
+    # a capped host thread count, and its round-robin share of the visit; together they cover every exposure once.
+    # (bench.py's launcher is rehearsed at N = 8 by tests/test_bench_contract.py; no GPU work in either.)
+    import subprocess
+    import sys
+    pfile = os.path.join(MINI, [f for f in os.listdir(MINI) if f.endswith(".yml")][0])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OMP_NUM_THREADS")}
+    env["PYTHONPATH"] = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", pfile, "--gpus", "8", "--dry-run",
+                          "--max-exposures", "21"], capture_output=True, text=True, timeout=600, env=env,
+                         cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = sorted(l for l in out.stdout.splitlines() if l.startswith("dry-run rank"))
+    assert len(lines) == 8 and "run_visit: 8 ranks done" in out.stdout
+    seen = []
+    from wayne_amd import launch
+    want_threads = str(launch.host_threads_per_rank(8))
+    for r, line in enumerate(lines):
+        f = line.split()
+        assert f[2] == "%d/8" % r and f[4] == str(r) and f[6] == want_threads, line
+        seen += [int(i) for i in f[8].split(",")]
+    assert sorted(seen) == list(range(21))
+    # --device with several ranks would put them all on one GPU: refused
+    bad = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", pfile, "--gpus", "2", "--device", "0",
+                          "--dry-run"], capture_output=True, text=True, timeout=120, env=env, cwd=os.path.dirname(HERE))
+    assert bad.returncode != 0 and "--device cannot be combined" in (bad.stderr + bad.stdout)
+
+
+def test_rank_environment_caps_host_threads():
+    from wayne_amd import launch
+    env = launch.rank_env(3, 8, 12345, {"X": "1"})
+    assert env["RANK"] == env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["MASTER_ADDR"] == "127.0.0.1"
+    n = launch.host_threads_per_rank(8)
+    assert n >= 1 and n <= max(1, (os.cpu_count() or 1))
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        assert env[var] == os.environ.get(var, str(n))

@@ -94,6 +94,8 @@ SYMBOLS = {
     "wayne_ctx_slots": (C.c_int, [_vp]),
     "wayne_exposure_upload": (C.c_int, [_vp, C.c_int, C.POINTER(ExposureDesc)]),
     "wayne_exposure_run": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_status": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "wayne_ctx_reruns": (C.c_ulonglong, [_vp]),
     "wayne_exposure_download": (C.c_int, [_vp, C.c_int, _vp]),
     "wayne_exposure_fetch_async": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_wait": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -130,7 +132,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
-        if L.wayne_abi_version() != 4:
+        if L.wayne_abi_version() != 5:
             raise ImportError("libwayne_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -284,6 +286,17 @@ class Context(object):
 
     def run_back(self, slot):
         self.check(self._L.wayne_exposure_run_back(self._h, int(slot)))
+
+    def status(self, slot):
+        """Status word of the slot's last run (0 = complete; see wayne_exposure_status).  Synchronises."""
+        st = C.c_int(0)
+        self.check(self._L.wayne_exposure_status(self._h, int(slot), C.byref(st)))
+        return st.value
+
+    @property
+    def reruns(self):
+        """Exposures this context ran a second time (a bin beyond the first launch sequence's reach)."""
+        return int(self._L.wayne_ctx_reruns(self._h))
 
     def download(self, slot):
         K, W, R, f64out = self._slot_meta[slot]

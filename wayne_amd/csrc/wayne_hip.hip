@@ -196,6 +196,7 @@ struct wayne_ctx {
   uint64_t prof_launches[WAYNE_PROF_KERNELS] = {0};
   double prof_ms[WAYNE_PROF_KERNELS] = {0};
   uint64_t electrons = 0;  // thrown through wayne_psf_apply (host-counted)
+  uint64_t reruns = 0;     // exposures run a second time because a bin lay beyond what the first launch sequence handles
   DevBuf counters;         // [0] u64: electrons thrown by exposures (device-counted)
 };
 
@@ -1438,6 +1439,22 @@ int wayne_exposure_run(wayne_ctx* c, int slot) {
   return wayne_exposure_run_back(c, slot);
 }
 
+int wayne_exposure_status(wayne_ctx* c, int slot, int* status) {
+  if (!c || !status) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "status: slot");
+  Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "status: slot not uploaded");
+  (void)hipSetDevice(c->device);
+  use_slot_stream(c, slot);
+  Slot::Misc m{};
+  HIP_TRY(c, hipMemcpyAsync(&m, s.misc.p, sizeof m, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *status = m.status;
+  return WAYNE_OK;
+}
+
+unsigned long long wayne_ctx_reruns(const wayne_ctx* c) { return c ? (unsigned long long)c->reruns : 0ull; }
+
 // Status word of the slot's last run: bit 0 = overflow (an error), bit 1 = a bin beyond the lanes' reach in an
 // exposure launched without k_throw (*rerun is set: the caller runs the exposure again, now with k_throw).
 static int check_status(wayne_ctx* c, Slot& s, bool* rerun = nullptr) {
@@ -1463,6 +1480,7 @@ int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
   int rc = check_status(c, s, &rerun);
   if (rc || !rerun) return rc;
   s.force_throw = true;
+  c->reruns += 1;
   if ((rc = wayne_exposure_run(c, slot))) return rc;
   HIP_TRY(c, hipMemcpyAsync(out_reads, s.out.p, (size_t)(s.R + 1) * SS * out_elem, hipMemcpyDeviceToHost, c->stream));
   return check_status(c, s);
@@ -1512,6 +1530,7 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
   if (s.pinned_misc->status & 2) {           // a bin beyond the lanes' reach: once more, with k_throw
     s.force_throw = true;
+    c->reruns += 1;
     int rc = wayne_exposure_run(c, slot);
     if (rc == WAYNE_OK) rc = wayne_exposure_fetch_async(c, slot);
     if (rc) return rc;
@@ -1563,6 +1582,7 @@ int wayne_exposure_debug_fetch(wayne_ctx* c, int slot, int32_t* counts, double* 
     if (rc) return rc;
     if (rerun && s.front_done) {
       s.force_throw = true;
+      c->reruns += 1;
       if ((rc = wayne_exposure_run_front(c, slot))) return rc;
       return wayne_exposure_debug_fetch(c, slot, counts, x_pos, y_pos, acc_e);
     }

@@ -23,9 +23,23 @@ def free_port():
         return s.getsockname()[1]
 
 
+def host_threads_per_rank(world):
+    """Threads a rank's host libraries may start: the CPUs this process may run on, shared out over the ranks of the
+    node (at least 1).  Without a cap every rank's numpy / OpenMP / BLAS pool sizes itself for the whole machine:
+    eight ranks x 256 threads on a 256-CPU host is how the delivered rate of an 8-GPU run falls apart."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    return max(1, cpus // max(1, int(world)))
+
+
 def rank_env(rank, world, port, extra=None):
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port))
+    n = str(host_threads_per_rank(world))
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        env.setdefault(var, n)           # (a value the caller exported is respected)
     env.update(extra or {})
     return env
 

@@ -139,6 +139,7 @@ def run(argv=None):
     ap.add_argument("--max-exposures", type=int, default=None, help="only the first M exposures")
     ap.add_argument("--gpus", type=int, default=1, help="start rank processes, one per GPU of this node")
     ap.add_argument("--ranks-per-gpu", type=int, default=1, help="... and this many to a GPU (small sub-arrays)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # ranks meet and report, no GPU work
     ap.add_argument("--float64-reads", action="store_true",
                     help="float64 reads from the device (the reference's arithmetic to the file) instead of float32 ones")
     args = ap.parse_args(argv)
@@ -167,6 +168,18 @@ def run(argv=None):
         args.device = int(os.environ["LOCAL_RANK"]) // args.ranks_per_gpu
     if os.environ.get("WAYNE_SHARE_GPU") == "1":       # every rank on device 0: a one-GPU box, or several ranks per GPU on small sub-arrays
         args.device = 0
+    if args.dry_run:
+        # rehearsal of the N-rank path on a box without N GPUs (tests/test_visit_driver.py): every rank parses the
+        # visit, takes its round-robin share and says so; nothing touches a GPU
+        with open(args.parameter_file) as f:
+            cfg = yaml.safe_load(f)
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        n_exp = int(args.max_exposures or 0) or 16
+        from . import visit as _visit
+        mine = _visit.shard(n_exp, rank, world)
+        print("dry-run rank %d/%d device %d threads %s exposures %s" % (
+            rank, world, args.device, os.environ.get("OMP_NUM_THREADS", "-"), ",".join(str(i) for i in mine)), flush=True)
+        return None
     launch.pin_to_gpu_numa(args.device)
     with open(args.parameter_file) as f:
         cfg = yaml.safe_load(f)
