@@ -397,7 +397,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   __shared__ SubInfo s_sub[FUSED ? kLaneBatchMax : 1];
   __shared__ uint32_t s_hits;
   __shared__ unsigned short s_list[THIN ? kLaneListCap : 1];
-  __shared__ int s_cnt;
+  __shared__ int s_cnt[2];                // THIN: cells on the flush list; two counters used in turn (see the flush)
   __shared__ int s_box[4];
   __shared__ int s_reach;                 // max over the lanes of 6.9 sigma + 1 (float bits; 0x7F800000 if a lane is not sane)
   // (sub-sample fastest: see ThrowArgs::chunk_order; BATCH = false: one sub-sample, as k_narrow)
@@ -461,7 +461,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   }
   if (!__syncthreads_or(any)) return;
   // workgroup tile: bounding box of its bins' positions +- margin, clipped to [1, N) and to the LDS budget
-  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; s_reach = 0; s_cnt = 0; }
+  if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; s_reach = 0; s_cnt[0] = 0; s_cnt[1] = 0; }
   __syncthreads();
   {
     // (reduced over the wave first: one atomic per wave, see k_narrow)
@@ -487,6 +487,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   const int tarea = tw * th;
   for (int i = tid; i < tarea; i += kLaneThreads) tile[i] = 0;
 
+  int par = 0;                            // which list counter the current sub-sample uses (THIN)
   // the tile cell at byte offset `addr` gets an electron; THIN: the first one there puts the cell on the flush list
   auto tile_add = [&](int addr) {
     if (THIN) {
@@ -494,7 +495,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
         const unsigned long long m = __ballot(1);
         const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         int base = 0;
-        if (before == 0) base = atomicAdd(&s_cnt, __popcll(m));
+        if (before == 0) base = atomicAdd(&s_cnt[par], __popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
         if (base + before < kLaneListCap) s_list[base + before] = (unsigned short)(addr >> 2);
       }
@@ -521,7 +522,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   } else if (inw) {
     n = a.nlane[kw];
   }
-  if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and s_cnt is 0 again)
+  if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and this round's list counter is 0)
   const SubInfo si = FUSED ? s_sub[k - k0] : a.sub[k];
   if (!FUSED && n > 0) {
     x = (float)a.xpos[kw];
@@ -626,7 +627,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   }
   __syncthreads();
   // flush with THIS sub-sample's flat, leaving the tile clean
-  const int listed = THIN ? s_cnt : 0;
+  const int listed = THIN ? s_cnt[par] : 0;
   if (THIN && listed <= kLaneListCap) {
     for (int t = tid; t < listed; t += kLaneThreads) {
       const int i = (int)s_list[t];
@@ -645,7 +646,12 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
       }
     }
   }
-  if (THIN && tid == 0) s_cnt = 0;
+  // The counter of the NEXT round is cleared here, not this round's: every thread reads this round's count after the
+  // barrier above and nothing orders a late reader before a reset by thread 0 -- a wave that read 0 would skip its
+  // share of the list and leave cells that never return 0 on first touch again.  The other counter was last read in
+  // the previous round's flush, which every thread left before this round's first barrier.
+  if (THIN && tid == 0) s_cnt[par ^ 1] = 0;
+  par ^= 1;
   }   // sub-samples of the batch
   if (FUSED) {
     // electrons handed to the lanes: ONE atomic per workgroup (the counter is a single address for the whole chip:
