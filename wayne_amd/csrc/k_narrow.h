@@ -116,18 +116,29 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   if (threadIdx.x < 10) s_fc[threadIdx.x] = (float)kStirlingSmall[threadIdx.x];
   const int k = blockIdx.x;                                    // (sub-sample fastest: see ThrowArgs::chunk_order)
   const int tid = threadIdx.x;
-  const int w = (int)a.chunk_order[blockIdx.y] * kNarrowThreads + tid;
+  // (the workgroup's chunk by a scalar load of the argument word that holds its byte; the bin's count, position and
+  // sigma asked for together, whether or not the count turns out positive: see k_lane)
+  const uint32_t order_word = reinterpret_cast<const uint32_t*>(a.chunk_order)[blockIdx.y >> 2];
+  const int w = (int)((order_word >> (8 * (blockIdx.y & 3))) & 0xFFu) * kNarrowThreads + tid;
   const SubInfo si = a.sub[k];
-  const int n0 = (w < a.W) ? a.nsplit[(size_t)k * a.W + w] : 0;   // narrow electrons of the bin's multinomial
+  int n0 = 0;                                                  // narrow electrons of the bin's multinomial
+  double xd = 0., yd = 0., sgd = 1.;
+  if (w < a.W) {
+    const size_t kw = (size_t)k * a.W + w;
+    n0 = a.nsplit[kw];
+    xd = a.xpos[kw];
+    yd = a.ypos[kw];
+    sgd = a.sigl[w];
+  }
   if (!__syncthreads_or(n0 > 0)) return;
   const bool act = n0 > 0;
 
   float x = 0.f, y = 0.f, sg = 1.f;
   int ic0 = 0, jc0 = 0;
   if (act) {
-    x = (float)a.xpos[(size_t)k * a.W + w];
-    y = (float)a.ypos[(size_t)k * a.W + w];
-    sg = (float)a.sigl[w];
+    x = (float)xd;
+    y = (float)yd;
+    sg = (float)sgd;
     ic0 = (int)floorf(x);
     jc0 = (int)floorf(y);
   }
@@ -403,11 +414,29 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   // (sub-sample fastest: see ThrowArgs::chunk_order; BATCH = false: one sub-sample, as k_narrow)
   const int k0 = BATCH ? (int)blockIdx.x * a.kb : (int)blockIdx.x, k1 = BATCH ? min(k0 + a.kb, a.K) : k0 + 1;
   const int tid = threadIdx.x;
-  const int w = (int)a.lane_order[blockIdx.y] * kLaneThreads + tid;
+  // (the chunk of this workgroup from the kernel arguments by a scalar load of the word that holds its byte: indexed as
+  // a byte array it is a vector load from the argument segment, a memory latency in front of every other load here)
+  const uint32_t order_word = reinterpret_cast<const uint32_t*>(a.lane_order)[blockIdx.y >> 2];
+  const int w = (int)((order_word >> (8 * (blockIdx.y & 3))) & 0xFFu) * kLaneThreads + tid;
   const bool inw = w < a.W;
+  // One sub-sample per workgroup (the rule: BATCH = false): everything the bin needs is asked for at once -- its
+  // sigmas, its count, position and wide count -- instead of count first, then (if positive) the rest, then all of it
+  // again in the throw loop: four memory latencies in a row per workgroup of a kernel whose launch-independent cost
+  // was 30 us (scripts/thrower_vs_electrons.py)
+  int n_one = 0, nw_one = 0;
+  float x_one = 0.f, y_one = 0.f;
   float ch = 0.f, cl = 0.f, sh = 0.f, sl = 0.f;
   if (inw) {
-    sh = (float)a.sigh[w]; sl = (float)a.sigl[w];
+    double sh_d = a.sigh[w], sl_d = a.sigl[w];
+    if (!FUSED && !BATCH) {
+      const size_t kw0 = (size_t)k0 * a.W + w;
+      n_one = a.nlane[kw0];
+      const double xd = a.xpos[kw0], yd = a.ypos[kw0];
+      nw_one = a.nwide[kw0];
+      x_one = (float)xd; y_one = (float)yd;
+      nw_one = min(max(nw_one, 0), n_one);
+    }
+    sh = (float)sh_d; sl = (float)sl_d;
     ch = (-1.3862943611198906f * sh) * sh;
     cl = (-1.3862943611198906f * sl) * sl;
   }
@@ -441,6 +470,9 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
         bin_position_bound(p, f_wl, p.tr + kTrStride * (size_t)k, p.x_ref[k], p.y_ref[k], &x, &y);
         n = 2; nw = 1;
       }
+    } else if (!BATCH) {
+      n = n_one;
+      if (n > 0) { x = x_one; y = y_one; nw = nw_one; }
     } else if (inw) {
       n = a.nlane[kw];
       if (n > 0) { x = (float)a.xpos[kw]; y = (float)a.ypos[kw]; nw = min(max(a.nwide[kw], 0), n); }
@@ -519,12 +551,16 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
       f_electrons += b.lane;
       if (n > 0) { x = (float)b.xs; y = (float)b.ys; nw = min(max(b.nwide, 0), n); }
     }
+  } else if (!BATCH) {
+    n = n_one;
   } else if (inw) {
     n = a.nlane[kw];
   }
   if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and this round's list counter is 0)
-  const SubInfo si = FUSED ? s_sub[k - k0] : a.sub[k];
-  if (!FUSED && n > 0) {
+  const SubInfo si = FUSED ? s_sub[k - k0] : a.sub[__builtin_amdgcn_readfirstlane(k)];     // (a scalar load: k is the workgroup's)
+  if (!FUSED && !BATCH) {
+    if (n > 0) { x = x_one; y = y_one; nw = nw_one; }
+  } else if (!FUSED && n > 0) {
     x = (float)a.xpos[kw];
     y = (float)a.ypos[kw];
     nw = min(max(a.nwide[kw], 0), n);
