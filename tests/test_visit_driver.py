@@ -572,3 +572,33 @@ def test_rank_environment_caps_host_threads():
     assert n >= 1 and n <= max(1, (os.cpu_count() or 1))
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         assert env[var] == os.environ.get(var, str(n))
+
+
+def test_fits_write_continues_after_short_writes(tmp_path, monkeypatch):
+    # os.writev may write fewer bytes than it was handed (a signal, a quota, a payload beyond 2 GiB) and Python does not
+    # retry: the writer has to go on from where the call stopped, across piece boundaries, until every byte is out.
+    # Here every call writes at most 1000 bytes -- less than a header block -- and the file must still equal the one
+    # written in one piece, for the HDU-list writer and for the exposure writer's pre-rendered pieces.
+    import os as _os
+    rng = np.random.default_rng(5)
+    hdus = [fitsio.HDU(fitsio.Header([("OBJECT", "x", "")]), None),
+            fitsio.HDU(fitsio.Header([("EXTVER", 1, "")]), rng.normal(size=(37, 53)).astype(np.float32), name="SCI"),
+            fitsio.HDU(fitsio.Header([("EXTVER", 1, "")]), None, name="ERR"),
+            fitsio.HDU(fitsio.Header([("EXTVER", 2, "")]), rng.integers(0, 100, (5, 7)).astype(np.int16), name="DQ")]
+    whole = str(tmp_path / "whole.fits")
+    fitsio.write(whole, hdus)
+    real = _os.writev
+    calls = []
+
+    def short(fd, bufs):
+        first = bytes(memoryview(bufs[0]).cast("B")[:1000])          # at most 1000 bytes of the first piece
+        calls.append(len(first))
+        return real(fd, [first])
+
+    monkeypatch.setattr(_os, "writev", short)
+    piecewise = str(tmp_path / "piecewise.fits")
+    fitsio.write(piecewise, hdus)
+    monkeypatch.undo()
+    assert len(calls) > 10 and open(piecewise, "rb").read() == open(whole, "rb").read()
+    back = fitsio.read(piecewise)
+    np.testing.assert_array_equal(back[1].data, hdus[1].data)
