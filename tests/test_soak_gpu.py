@@ -229,3 +229,41 @@ def test_accumulator_boxes_with_wavelengths_out_of_order(monkeypatch):
         monkeypatch.delenv("WAYNE_NO_ACC_BOX")
         np.testing.assert_array_equal(a, b, err_msg="rng_mode %d" % mode)
         assert (a[-1] - a[0]).max() > 50              # the star is there
+
+
+def test_a_new_grism_on_a_live_context_forgets_the_old_spectrum_estimates():
+    # wayne_ctx_set_grism on a context that has already synthesized exposures: what the upload keeps per spectrum
+    # (count rates per bin through the OLD sensitivity, which size the throwers' launches; the OLD largest PSF sigma,
+    # which sizes the boxes of the accumulators k_ramp loads) must not survive -- the same descriptor through a context
+    # whose grism was swapped for one six times as sensitive with a PSF three times as wide gives the reads of a
+    # context that was built with the new grism, leaves no electron behind in the accumulators, and reruns no more
+    from wayne_amd import _lib, engine
+    v = helpers.make_visit("small256")
+    pg = helpers.product_generator(v, 0)
+    kw = v.frame_kwargs(0, cosmic_rate=None)
+    sens_wl, sens_val = v.calibration.sensitivity(v.grism.name)
+    g = v.grism
+
+    def set_grism(eng, scale):
+        wmin, wmax = v.calibration.flat_wl.get(g.name, (0.0, 1.0))
+        eng.ctx.set_grism(g.trace_coeff, g.wl_solution, g.psf_ratio_poly.coeffs, np.asarray(g.psf_sigmal_poly.coeffs) * 3,
+                          np.asarray(g.psf_sigmah_poly.coeffs) * 3, sens_wl, np.asarray(sens_val) * scale, wmin, wmax)
+
+    for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX):
+        swapped = engine.Engine(0, g, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+        fresh = engine.Engine(0, g, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+        try:
+            desc = pg.build_descriptor(swapped, rng_mode=mode, out_dtype=np.float64, **kw)
+            first = swapped.ctx.synthesize(desc)
+            set_grism(swapped, 6.0)
+            set_grism(fresh, 6.0)
+            a = swapped.ctx.synthesize(desc)
+            _, _, _, acc_after = swapped.ctx.debug_fetch(0, acc=True)
+            assert not acc_after.any(), "accumulators left dirty: %g electrons" % acc_after.sum()
+            b = fresh.ctx.synthesize(desc)
+            np.testing.assert_array_equal(a, b, err_msg="rng_mode %d" % mode)
+            assert (a[-1] - a[0]).sum() > 2 * (first[-1] - first[0]).sum()      # (non-linearity and the clip eat part of the 6x)
+            assert swapped.ctx.reruns == fresh.ctx.reruns
+        finally:
+            swapped.close()
+            fresh.close()

@@ -948,6 +948,9 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   d.sens_wl = c->sens_wl.as<double>();
   d.sens_val = c->sens_val.as<double>();
   c->have_grism = true;
+  // what the upload keeps per spectrum was worked out with the previous grism's polynomials and sensitivity
+  c->est_wl.clear();
+  c->est_flux.clear();
   return WAYNE_OK;
 }
 
