@@ -690,8 +690,8 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   par ^= 1;
   }   // sub-samples of the batch
   if (FUSED) {
-    // electrons handed to the lanes: ONE atomic per workgroup (the counter is a single address for the whole chip:
-    // 8 ns apiece, measured -- one per wave was 1.4 ms of a finely sampled exposure)
+    // electrons handed to the lanes: ONE atomic per workgroup, on the workgroup's stripe of the counter (count_electrons;
+    // one per wave on a single address was 1.4 ms of a finely sampled exposure)
     for (int off = 32; off > 0; off >>= 1) f_electrons += __shfl_down(f_electrons, off);
     __shared__ unsigned long long s_tot[kLaneThreads / 64];
     if ((tid & 63) == 0) s_tot[tid >> 6] = f_electrons;
@@ -699,7 +699,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
     if (tid == 0) {
       unsigned long long t = 0;
       for (int i = 0; i < kLaneThreads / 64; ++i) t += s_tot[i];
-      if (t) atomicAdd(p.total_electrons, t);
+      if (t) count_electrons(p.total_electrons, blockIdx.y * gridDim.x + blockIdx.x, t);
     }
   }
 }

@@ -123,7 +123,19 @@ struct PrepArgs {
   int no_narrow;             // k_narrow is not launched either (the host expects no bin with split_min narrow electrons)
 };
 
-constexpr int kPrepThreads = 512;
+// The device-side electron count (wayne_profile_get) is kept in kCounterStripes words a cache line apart, a workgroup adding
+// to the stripe of its index: atomics on ONE address complete one after the other (8 ns apiece) and the 1152 workgroups of
+// a k_prep_sub launch queued 2.7 us behind theirs.  The host adds the stripes up.
+constexpr int kCounterStripes = 64;
+constexpr int kCounterStride = 16;        // in 8-byte words: 128 B
+__device__ __forceinline__ void count_electrons(unsigned long long* counter, unsigned wg, unsigned long long n) {
+  atomicAdd(counter + (size_t)kCounterStride * (wg & (kCounterStripes - 1)), n);
+}
+
+#ifndef WAYNE_PREP_THREADS
+#define WAYNE_PREP_THREADS 512
+#endif
+constexpr int kPrepThreads = WAYNE_PREP_THREADS;
 constexpr int kMaxPrepChunks = 128;     // chunks of kPrepThreads bins per sub-sample (32768 bins)
 constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
 constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
   if (tid == 0) {
     unsigned long long tot = 0;
     for (int i = 0; i < NW; ++i) tot += s_split[i];
-    if (tot) atomicAdd(a.total_electrons, tot);
+    if (tot) count_electrons(a.total_electrons, blockIdx.y * gridDim.x + blockIdx.x, tot);
   }
 
   // Split mode with no k_throw launch (the default: every bin's one-by-one electrons fit its lane): nothing of the
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_fix(PrepArgs a, int n_chu
     const uint32_t E = s_E;
     a.prefix[(size_t)k * (W + 1) + W] = E;
     a.sub[k] = make_sub_info(a, k, x_ref, y_ref, tr, E, xmin, xmax, ymin, ymax);
-    atomicAdd(a.total_electrons, (unsigned long long)E);
+    count_electrons(a.total_electrons, k, (unsigned long long)E);
   }
 }
 

@@ -144,6 +144,8 @@ constexpr int kSlots = 256;
 
 constexpr int kStreams = 2;   // exposures in even / odd slots run on different HIP streams
 
+constexpr size_t kCounterBytes = (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long);
+
 struct wayne_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // stream of the call in progress (one of streams[])
@@ -197,7 +199,8 @@ struct wayne_ctx {
   double prof_ms[WAYNE_PROF_KERNELS] = {0};
   uint64_t electrons = 0;  // thrown through wayne_psf_apply (host-counted)
   uint64_t reruns = 0;     // exposures run a second time because a bin lay beyond what the first launch sequence handles
-  DevBuf counters;         // [0] u64: electrons thrown by exposures (device-counted)
+  DevBuf counters;         // kCounterStripes u64 words, 128 B apart: electrons thrown by exposures (device-counted,
+                           // count_electrons); word [1]: a spare for debug_fetch's own k_prep_sub launch
 };
 
 namespace {
@@ -706,7 +709,7 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
     c->fork_narrow = c->fork_narrow && e && std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
-  if (c->counters.reserve(64) != hipSuccess || hipMemset(c->counters.p, 0, 64) != hipSuccess) {
+  if (c->counters.reserve(kCounterBytes) != hipSuccess || hipMemset(c->counters.p, 0, kCounterBytes) != hipSuccess) {
     for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
     delete c;
     set(WAYNE_E_NOMEM);
@@ -1658,7 +1661,7 @@ int wayne_profile_reset(wayne_ctx* c) {
   if (rc) return rc;
   for (int i = 0; i < WAYNE_PROF_KERNELS; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; }
   c->electrons = 0;
-  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64, c->streams[0]));
+  HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, kCounterBytes, c->streams[0]));
   return sync_all(c);
 }
 
@@ -1671,8 +1674,9 @@ int wayne_profile_get(wayne_ctx* c, wayne_profile* out) {
     out->launches[i] = c->prof_launches[i];
     out->ms[i] = c->prof_ms[i];
   }
-  unsigned long long dev = 0;
-  HIP_TRY(c, hipMemcpy(&dev, c->counters.p, sizeof dev, hipMemcpyDeviceToHost));
+  unsigned long long words[kCounterStripes * kCounterStride], dev = 0;
+  HIP_TRY(c, hipMemcpy(words, c->counters.p, sizeof words, hipMemcpyDeviceToHost));
+  for (int i = 0; i < kCounterStripes; ++i) dev += words[i * kCounterStride];
   out->electrons = c->electrons + dev;
   return WAYNE_OK;
 }
