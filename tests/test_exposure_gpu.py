@@ -77,11 +77,11 @@ def test_prep_counts_with_stellar_poisson_over_six_decades():
     assert (a != b).mean() < 1e-5
 
 
-@pytest.mark.parametrize("table", ["gaps", "two_points", "dense", "off_band"])
+@pytest.mark.parametrize("table", ["gaps", "two_points", "one_point", "dense", "off_band"])
 def test_sensitivity_tables_of_any_spacing(table):
     # k_prep_wl finds a bin's interval of the sensitivity table (np.interp, grism.py:116-118) by a proportional guess
     # and bisects only where that fails: tables that are far from uniform -- clustered points with a wide gap, the
-    # minimum of two points, one denser than the bins, one that covers only part of the band (clamped outside) -- must
+    # minimum of two points, a single point, one denser than the bins, one that covers only part of the band (clamped outside) -- must
     # give the oracle's counts exactly
     import copy
     from wayne_amd import calibration as calmod, detector, grism, synthetic
@@ -92,6 +92,8 @@ def test_sensitivity_tables_of_any_spacing(table):
         wl = np.sort(np.concatenate([rng.uniform(1.0, 1.18, 150), rng.uniform(1.52, 1.8, 7), [1.0, 1.8]]))
     elif table == "two_points":
         wl = np.array([1.05, 1.72])
+    elif table == "one_point":               # np.interp over one point: that value everywhere
+        wl = np.array([1.4])
     elif table == "dense":
         wl = np.sort(rng.uniform(0.9, 1.9, 20000)) ** 1.0
     else:

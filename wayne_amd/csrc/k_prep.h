@@ -35,8 +35,8 @@ __global__ void k_prep_wl(GrismDev g, int W, const double* __restrict__ wl, WlAr
   const int n = g.n_sens;
   if (n <= 0) {
     s = 1.0;
-  } else if (x <= g.sens_wl[0]) {
-    s = g.sens_val[0];
+  } else if (n < 2 || x <= g.sens_wl[0]) {      // (a one-entry table has no bracket to search: its value, NaN for a NaN wavelength)
+    s = (x != x) ? x : g.sens_val[0];
   } else if (x >= g.sens_wl[n - 1]) {
     s = g.sens_val[n - 1];
   } else {
