@@ -57,4 +57,45 @@ __device__ __forceinline__ double poly3(const double* c, double x) {
   return ((c[0] * x + c[1]) * x + c[2]) * x + c[3];
 }
 
+#if defined(__HIPCC__)
+// Reductions over the 16 lanes of a DPP row (butterfly of row rotations): every lane of the row gets the result.
+// All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ int dpp_row(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+#define WAYNE_ROW16(name, T, cast_in, cast_out, op)                                   \
+  __device__ __forceinline__ T name(T v) {                                            \
+    v = op(v, cast_out(dpp_row<0x128>(cast_in(v))));  /* row_ror:8 */                 \
+    v = op(v, cast_out(dpp_row<0x124>(cast_in(v))));  /* row_ror:4 */                 \
+    v = op(v, cast_out(dpp_row<0x122>(cast_in(v))));  /* row_ror:2 */                 \
+    v = op(v, cast_out(dpp_row<0x121>(cast_in(v))));  /* row_ror:1 */                 \
+    return v;                                                                         \
+  }
+__device__ __forceinline__ int wayne_addi(int a, int b) { return a + b; }
+WAYNE_ROW16(row16_min, float, __float_as_int, __int_as_float, fminf)
+WAYNE_ROW16(row16_max, float, __float_as_int, __int_as_float, fmaxf)
+WAYNE_ROW16(row16_mini, int, , , min)
+WAYNE_ROW16(row16_maxi, int, , , max)
+WAYNE_ROW16(row16_sum, int, , , wayne_addi)
+#undef WAYNE_ROW16
+// ... and over the whole wave (wave-uniform result)
+__device__ __forceinline__ int wave_mini(int v) {
+  v = row16_mini(v);
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_maxi(int v) {
+  v = row16_maxi(v);
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// the sum of one 32-bit number per lane, as 64 bits (two 16-lane sums of 24 + 8 bits each: no carry to lose)
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t n) {
+  const int lo = row16_sum((int)(n & 0xFFFFFFu)), hi = row16_sum((int)(n >> 24));
+  const unsigned long long L = (unsigned long long)(uint32_t)(__builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) +
+                                                              __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48));
+  const unsigned long long H = (unsigned long long)(uint32_t)(__builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) +
+                                                              __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48));
+  return L + (H << 24);
+}
+#endif
+
 }  // namespace wayne

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
 
   double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
   bool overflow = false;
-  unsigned long long n_split_total = 0;   // per thread
+  uint32_t n_split = 0;                   // per thread: electrons handed to k_lane / k_narrow
 
   const int w = ch * kPrepThreads + tid;
   uint32_t c = 0;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     if (a.nsplit) {
       a.nsplit[kw] = (int32_t)b.narrow;
       a.nlane[kw] = (int32_t)b.lane;
-      n_split_total += b.narrow + b.lane;
+      n_split = b.narrow + b.lane;
       c = b.rest;                                            // c: electrons left for k_throw
       // launched without k_throw (the host expected no bin beyond a lane's reach) and here is one after all:
       // tell the host, which runs the exposure again with k_throw (wayne_hip.hip, check_status)
@@ -482,8 +482,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prep_sub(PrepArgs a, CosmicArg
     }
   }
   if (overflow) atomicOr(a.status, 1);
-  // electrons handed to k_lane / k_narrow: one atomic per workgroup (wave shuffle, then LDS)
-  for (int off = 32; off > 0; off >>= 1) n_split_total += __shfl_down(n_split_total, off);
+  // electrons handed to k_lane / k_narrow: one atomic per workgroup (DPP row sums per wave -- six rounds of 64-bit
+  // shuffles through the LDS crossbar at the end of a wave that has nothing to hide them behind were 1.8 us of the
+  // launch --, then LDS)
+  const unsigned long long n_split_total = wave_sum_u32(n_split);
   __shared__ unsigned long long s_split[NW];
   if (lane == 0) s_split[wave] = n_split_total;
 
