@@ -214,6 +214,42 @@ def compare_with_moments(A, mean, var, var_other=None, min_sum=400, min_mean_var
     return out
 
 
+def wings_against_moments(A, mean, var, x, y, wing=(13, 30)):
+    """The wing cells of compare() -- (row offset from the trace, third of the columns) -- of ONE ensemble against the
+    exact law: chi-square of the summed counts with the exact variances (covariances between the pixels of a cell are
+    negative and tiny out there: the figure is conservative)."""
+    A = np.asarray(A, dtype=np.float64)
+    M, n = A.shape[0], A.shape[1]
+    S = A.sum(axis=0)
+    off = trace_row_offsets(x, y, n)
+    lo, hi = wing
+    thirds = np.array_split(np.arange(n), 3)
+    obs, exp, vv = [], [], []
+    for d in list(range(-hi, -lo + 1)) + list(range(lo, hi + 1)):
+        sel = off == d
+        for cols in thirds:
+            m = np.zeros_like(sel)
+            m[:, cols] = sel[:, cols]
+            obs.append(S[m].sum()); exp.append(M * mean[m].sum()); vv.append(M * var[m].sum())
+    obs, exp, vv = np.array(obs), np.array(exp), np.array(vv)
+    ok = exp >= 50
+    z = (obs[ok] - exp[ok]) / np.sqrt(vv[ok])
+    return {"wing_exact_chi2": float((z * z).sum()), "wing_exact_dof": int(ok.sum()), "wing_exact_z_mean": float(z.mean()),
+            "wing_exact_rel": float((obs[ok].sum() - exp[ok].sum()) / exp[ok].sum()),
+            "wing_exact_rel_se": float(np.sqrt(vv[ok].sum()) / exp[ok].sum())}
+
+
+def check_wings_against_moments(w, sigma=5.0):
+    bad = []
+    dof = w["wing_exact_dof"]
+    if dof > 0 and w["wing_exact_chi2"] > dof + sigma * np.sqrt(2.0 * dof):
+        bad.append("wings against the exact law: chi2 %.1f for %d cells" % (w["wing_exact_chi2"], dof))
+    if dof > 0 and abs(w["wing_exact_rel"]) > sigma * w["wing_exact_rel_se"] + 1e-4:
+        bad.append("electrons in the wings against the exact law: %+.2e (se %.1e)" % (w["wing_exact_rel"],
+                                                                                      w["wing_exact_rel_se"]))
+    return bad
+
+
 def check_moments(s, sigma=5.0):
     bad = []
     if abs(s["z_mean"]) > sigma * s["z_mean_se"]:

@@ -51,7 +51,12 @@ CASES = {
     "edge":   ("edge_low", 20,    None, 64,    400),
 }
 _cache = {}
-REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "ensemble_parity.json")
+# WAYNE_ENSEMBLE_SCALE=n: n times as many frames on both sides (the bands are standard errors, so they tighten by
+# sqrt(n)); the figures then go to ensemble_parity_x<n>.json.  profiles/r04/ensemble_parity_x8.json is such a run.
+SCALE = max(1, int(os.environ.get("WAYNE_ENSEMBLE_SCALE", "1")))
+REF_SEED = int(os.environ.get("WAYNE_ENSEMBLE_REF_SEED", "5"))      # which `test` seeds the reference frames take
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                      "ensemble_parity.json" if SCALE == 1 else "ensemble_parity_x%d.json" % SCALE)
 
 
 def report(key, **figures):
@@ -72,7 +77,7 @@ def case_inputs(name):
     if clip is not None:
         counts = np.minimum(counts, clip)
         counts[::3] //= 4
-    return k, counts.astype(np.int32), m_ref, m_dev
+    return k, counts.astype(np.int32), m_ref * SCALE, m_dev * SCALE
 
 
 def reference_ensemble(name):
@@ -82,7 +87,7 @@ def reference_ensemble(name):
             pytest.skip("oracle/_ref not built")
         k, counts, m_ref, _ = case_inputs(name)
         n = k["nr"]
-        tests = np.random.RandomState(5).randint(0, 100000, m_ref)        # exposure_generator.py:327
+        tests = np.random.RandomState(REF_SEED).randint(0, 100000, m_ref)        # exposure_generator.py:327
         A = np.stack([clib.psf_reference(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, int(tests[m]),
                                          1 if m % 2 == 0 else 4).reshape(n, n) for m in range(m_ref)])
         _cache[name] = (A, es.analytic_moments(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n))
@@ -102,8 +107,10 @@ def test_reference_ensemble_follows_the_exact_moments(name):
     # reference itself before anything is compared with it
     A, (mean, var, var_other, _) = reference_ensemble(name)
     s = es.compare_with_moments(A, mean, var, var_other)
-    report("psf/%s/reference_vs_exact_moments" % name, **s)
-    bad = es.check_moments(s)
+    k, _, _, _ = case_inputs(name)
+    w = es.wings_against_moments(A, mean, var, k["x"], k["y"])
+    report("psf/%s/reference_vs_exact_moments" % name, **dict(s, **w))
+    bad = es.check_moments(s) + es.check_wings_against_moments(w)
     assert not bad, "; ".join(bad)
 
 
@@ -119,7 +126,8 @@ def test_production_thrower_against_reference_ensemble(gpu_ctx, name, mode):
     bad = es.check(two, require_subpoisson=0.95 if name != "thin" else None)
     # one-sample: device ensemble against the exact moments of the reference's law (the sharper test: M' >> M)
     one = es.compare_with_moments(B, mean, var, var_other)
-    bad += es.check_moments(one)
+    one.update(es.wings_against_moments(B, mean, var, k["x"], k["y"]))      # the wings once more, one-sample
+    bad += es.check_moments(one) + es.check_wings_against_moments(one)
     tag = "split" if mode == _lib.RNG_SPLIT else "philox"
     report("psf/%s/%s_vs_reference" % (name, tag), **two)
     report("psf/%s/%s_vs_exact_moments" % (name, tag), **one)
@@ -143,7 +151,7 @@ def test_split_and_philox_ensembles_agree_with_each_other(gpu_ctx):
     ens = {}
     for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX):
         fr = []
-        for m in range(96):
+        for m in range(96 * SCALE):
             f = gpu_ctx.psf_apply(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"], n, n, 77, rng_mode=mode,
                                   exposure=m, subsample=3).reshape(n, n)
             assert f.sum() == f[y0:y1, x0:x1].sum() == counts.sum()      # reach: nothing beyond 6.9 sigma_h
@@ -161,7 +169,7 @@ def test_split_and_philox_ensembles_agree_with_each_other(gpu_ctx):
 # ---------------------------------------------------------------------------------------------------------------
 # exposure level
 # ---------------------------------------------------------------------------------------------------------------
-def _exposure_ensembles(m_dev=200, m_ref=100):
+def _exposure_ensembles(m_dev=200 * SCALE, m_ref=100 * SCALE):
     key = ("exposures", m_dev, m_ref)
     if key not in _cache:
         if not clib.have_ref():
