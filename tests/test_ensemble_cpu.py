@@ -39,8 +39,10 @@ def test_reference_and_split_oracle_ensembles_follow_the_exact_moments(name):
                   for m in range(m_ref)])
     B = np.stack([clib.psf_split_oracle(*args, n, 1963, m, m % 7).reshape(n, n) for m in range(m_split)])
     bad = ["reference: " + b for b in es.check_moments(es.compare_with_moments(A, mean, var, var_other))]
+    bad += ["reference: " + b for b in es.check_wings_against_moments(es.wings_against_moments(A, mean, var, k["x"], k["y"]))]
     one = es.compare_with_moments(B, mean, var, var_other)
     bad += ["split oracle: " + b for b in es.check_moments(one)]
+    bad += ["split oracle: " + b for b in es.check_wings_against_moments(es.wings_against_moments(B, mean, var, k["x"], k["y"]))]
     bad += ["split oracle vs reference: " + b for b in es.check(es.compare(B, A, k["x"], k["y"]))]
     assert not bad, "; ".join(bad)
 
@@ -62,8 +64,10 @@ def test_the_statistics_see_a_wrong_law():
 
     good = ens(counts, *base, 0)
     assert not es.check_moments(es.compare_with_moments(good, mean, var, var_other))
+    assert not es.check_wings_against_moments(es.wings_against_moments(good, mean, var, k["x"], k["y"]))
     wide = ens(counts, k["x"], k["y"], k["ratio"], k["sl"], k["sh"] * 1.01, 100)
     assert es.check(es.compare(wide, good, k["x"], k["y"]))
+    assert es.check_wings_against_moments(es.wings_against_moments(wide, mean, var, k["x"], k["y"]))     # 1 % wider: more in the wings
     assert es.check_moments(es.compare_with_moments(wide, mean, var, var_other))
     moved = ens(counts, k["x"] + 0.004, k["y"] + 0.004, k["ratio"], k["sl"], k["sh"], 200)
     assert es.check_moments(es.compare_with_moments(moved, mean, var, var_other))
