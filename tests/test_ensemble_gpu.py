@@ -34,6 +34,7 @@ import os
 
 import numpy as np
 import pytest
+from scipy.special import polygamma
 
 import ensemble_stats as es
 import helpers
@@ -169,12 +170,12 @@ def test_split_and_philox_ensembles_agree_with_each_other(gpu_ctx):
 # ---------------------------------------------------------------------------------------------------------------
 # exposure level
 # ---------------------------------------------------------------------------------------------------------------
-def _exposure_ensembles(m_dev=200 * SCALE, m_ref=100 * SCALE):
-    key = ("exposures", m_dev, m_ref)
+def _exposure_ensembles(m_dev=200 * SCALE, m_ref=100 * SCALE, visit="small256", threads=(1, 2)):
+    key = ("exposures", visit, m_dev, m_ref)
     if key not in _cache:
         if not clib.have_ref():
             pytest.skip("oracle/_ref not built")
-        v = helpers.make_visit("small256")
+        v = helpers.make_visit(visit)
         off = dict(cosmic_rate=None)      # 15 hits of 10-35 ke per exposure would swamp every pixel variance; the
         #                                   cosmic-ray statistics have their own test (tests/test_configs_gpu.py)
         kw = v.frame_kwargs(0, **off)
@@ -184,12 +185,12 @@ def _exposure_ensembles(m_dev=200 * SCALE, m_ref=100 * SCALE):
             dev.append(np.array(pg.scanning_frame(out_dtype=np.float32, **kw).reads[-1][0], dtype=np.float64))
         eo = helpers.oracle_generator(v)
         okw = helpers.oracle_kwargs(kw)
-        ref = [eo.scanning_frame(threads=2 if m % 2 else 1, draws=wo.LegacyDraws(4000 + m), thrower="ref",
+        ref = [eo.scanning_frame(threads=threads[m % 2], draws=wo.LegacyDraws(4000 + m), thrower="ref",
                                  **okw)[-1] for m in range(m_ref)]
         # where the star's electrons land, from a run of its own with every noise source off (a mask taken from either
         # ensemble would select on that ensemble's noise and bias the comparison): last read less the initial bias frame
         quiet = dict(add_stellar_noise=False, sky_background=0.0, add_dark=False, add_read_noise=False, cosmic_rate=None)
-        star = eo.scanning_frame(threads=1, draws=wo.LegacyDraws(1), thrower="ref",
+        star = eo.scanning_frame(threads=threads[1], draws=wo.LegacyDraws(1), thrower="ref",
                                  **helpers.oracle_kwargs(v.frame_kwargs(0, **quiet)))[-1] - eo._gen_zero_read(True)
         _cache[key] = (v, np.stack(dev), np.stack(ref), star)
     return _cache[key]
@@ -203,10 +204,10 @@ def _region_stats(D, R, sel):
     z = (md - mr) / np.sqrt(vd / Md + vr / Mr)
     n = int(sel.sum())
     nu = (1.0 / Md + 1.0 / Mr) ** 2 / (1.0 / (Md * Md * (Md - 1.0)) + 1.0 / (Mr * Mr * (Mr - 1.0)))
-    lr = np.log(vd / vr) + 1.0 / (Md - 1) - 1.0 / (Mr - 1)
+    lr = np.log(vd / vr) - es.log_s2_bias(Md) + es.log_s2_bias(Mr)
     return dict(n=n, z_mean=float(z.mean()), z_mean_se=1.0 / np.sqrt(n), z_std=float(z.std(ddof=1)),
                 z_std_expect=float(np.sqrt(nu / (nu - 2.0))), z_std_se=float(1.0 / np.sqrt(2.0 * n)),
-                log_var=float(lr.mean()), log_var_se=float(np.sqrt(2.0 / (Md - 1) + 2.0 / (Mr - 1)) / np.sqrt(n)),
+                log_var=float(lr.mean()), log_var_se=float(np.sqrt(polygamma(1, (Md - 1) / 2.0) + polygamma(1, (Mr - 1) / 2.0)) / np.sqrt(n)),
                 mean_d=float(md.mean()), mean_r=float(mr.mean()), var_d=float(vd.mean()), var_r=float(vr.mean()))
 
 
@@ -246,4 +247,32 @@ def test_production_exposures_against_reference_driven_oracle_ensemble():
     for label, got in (("device", s_b["var_d"]), ("oracle", s_b["var_r"])):
         if abs(got / (14.1 / 2.35) ** 2 - 1.0) > 0.03:
             bad.append("%s border variance %.2f DN^2" % (label, got))
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.skipif(not os.environ.get("WAYNE_ENSEMBLE_FULLSIZE"), reason="minutes of reference C at 10^9 electrons per "
+                    "exposure: WAYNE_ENSEMBLE_FULLSIZE=1 (profiles/r04/ensemble_parity_cfg4.json is such a run)")
+def test_production_exposures_of_the_benchmarked_configuration_against_reference_driven_oracle_ensemble():
+    # the same comparison on the workload `bench.py` times (cfg4: 1014^2, NSAMP 16, 128 sub-samples, 10^9 electrons, every
+    # detector effect on but the cosmic rays): fewer frames -- an exposure of the reference's thrower is seconds on all
+    # the box's cores -- over twenty times as many pixels
+    m_dev, m_ref = 48 * SCALE, 16 * SCALE
+    ncpu = max(2, min(64, os.cpu_count() or 2))
+    v, D, R, star = _exposure_ensembles(m_dev, m_ref, visit="cfg4", threads=(ncpu, max(1, ncpu // 2)))
+    S = D.shape[1]
+    interior = np.zeros((S, S), dtype=bool)
+    interior[5:-5, 5:-5] = True
+    inside, outside, border = interior & (star > 30.0), interior & (star < 0.5), ~interior
+    assert inside.sum() > 50000 and outside.sum() > 300000
+    bad = []
+    for name, sel, jitter_floor in (("inside", inside, 0.01), ("outside", outside, 0.0), ("border", border, 0.0)):
+        s = _region_stats(D, R, sel)
+        report("exposure/cfg4/%s" % name, **dict(s, m_dev=m_dev, m_ref=m_ref))
+        if abs(s["z_mean"]) > 5.0 * s["z_mean_se"] + jitter_floor:
+            bad.append("%s: pixel means differ, mean z %.4f (se %.4f)" % (name, s["z_mean"], s["z_mean_se"]))
+        if abs(s["z_std"] - s["z_std_expect"]) > 5.0 * s["z_std_se"] + 0.02:
+            bad.append("%s: spread of z %.4f, expected %.4f" % (name, s["z_std"], s["z_std_expect"]))
+        if abs(s["log_var"]) > 5.0 * s["log_var_se"] + 0.01:
+            bad.append("%s: pixel variances differ, mean log ratio %.4f (se %.4f)" % (name, s["log_var"],
+                                                                                    s["log_var_se"]))
     assert not bad, "; ".join(bad)
