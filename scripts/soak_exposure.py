@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised soak of WHOLE EXPOSURES against the numpy oracle on the same random counters (GPU only; test
+infrastructure: uses oracle/).  Each case draws a small configuration (SUBARRAY 64 ... 256, RAPID / SPARS10, staring and
+scanning, G141 / G102), the star's brightness over three decades, every detector switch on or off independently, a sky
+level from none to bright, cosmic rays from none to a shower, optional gaussian noise and a scale factor, the rng mode
+(replay / every electron / split), exact or production samplers, float32 or float64 reads -- and compares the reads
+pixel by pixel:
+
+  replay thrower + exact samplers     all but 1e-4 of the pixels within 1e-3 DN + 1e-6 relative (float32 reads: 0.02 DN +
+                                      2e-7): what differs is a Poisson / normal decision flipped by a 1-ulp libm / ocml
+                                      difference
+  any other combination               all but 3e-3 of the pixels within 0.05 DN (+ the same relative terms): an electron
+                                      in the neighbouring pixel, a flipped float32 sampler decision; median |d| < 5e-3
+
+    python scripts/soak_exposure.py [cases=100] [seed=1]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+from oracle import wayne_oracle as wo  # noqa: E402  (the checker)
+from wayne_amd import _lib  # noqa: E402
+
+NAMES = ["tiny", "tiny_g102", "tiny128", "stare256", "small256"]
+MODES = [(_lib.RNG_REPLAY, "oracle"), (_lib.RNG_PHILOX, "philox"), (_lib.RNG_SPLIT, "split")]
+
+
+def case(rng):
+    name = NAMES[int(rng.integers(0, len(NAMES)))]
+    flag = lambda p=0.5: bool(rng.random() < p)      # noqa: E731
+    over = dict(add_flat=flag(0.7), add_dark=flag(0.7), add_gain_variations=flag(0.7), add_non_linear=flag(0.7),
+                add_read_noise=flag(0.7), add_stellar_noise=flag(0.7), clip_values_det_limits=flag(0.7),
+                add_initial_bias=flag(0.7),
+                sky_background=float(rng.choice([0.0, 0.3, 1.2, 5.0])),
+                cosmic_rate=[None, 11.0, 300.0][int(rng.integers(0, 3))])
+    if flag(0.3):
+        over.update(noise_mean=2.0, noise_std=0.5)
+    if flag(0.3):
+        over["scale_factor"] = float(rng.choice([None, 0.3, 3.0]) or 1.0)
+    mode = MODES[int(rng.integers(0, 3))]
+    return dict(name=name, E=float(10.0 ** rng.uniform(3.5, 6.3)), over=over, mode=mode, exact=flag(),
+                f64=flag(), i=int(rng.integers(0, 4)), threads=int(rng.integers(1, 7)))
+
+
+def run_case(c):
+    v = helpers.make_visit(c["name"], n_exposures=c["i"] + 1, E=c["E"])
+    kw = v.frame_kwargs(c["i"], **c["over"])
+    pg = helpers.product_generator(v, c["i"])
+    dt = np.float64 if c["f64"] else np.float32
+    exp = pg.scanning_frame(threads=c["threads"], rng_mode=c["mode"][0], out_dtype=dt, exact_samplers=c["exact"], **kw)
+    got = np.stack([np.asarray(r[0], dtype=np.float64) for r in exp.reads])
+    eo = helpers.oracle_generator(v)
+    draws = wo.PhiloxDraws(v.seed, c["i"], pg.detector.light_sensitive_size(v.SUBARRAY))
+    want = np.stack(eo.scanning_frame(threads=c["threads"], draws=draws, thrower=c["mode"][1],
+                                      **helpers.oracle_kwargs(kw, v.seed, c["i"])))
+    d = np.abs(got - want)
+    tight = c["mode"][0] == _lib.RNG_REPLAY and c["exact"]
+    rel = (1e-6 if c["f64"] else 2e-7 + 6e-8) * np.abs(want)
+    tol = (1e-3 if c["f64"] else 0.02) + rel if tight else 0.05 + rel
+    bad = int((d > tol).sum())
+    allowed = (1e-4 if tight else 3e-3) * got.size + 2
+    ok = bad <= allowed and np.median(d) < (1e-4 if tight and c["f64"] else 5e-3) and np.isfinite(got).all()
+    return ok, bad, got.size, float(np.median(d)), float(d.max())
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    failed = 0
+    for j in range(n_cases):
+        c = case(rng)
+        ok, bad, size, med, worst = run_case(c)
+        failed += not ok
+        on = "".join(k[4] if c["over"][k] else "-" for k in ("add_flat", "add_dark", "add_gain_variations", "add_non_linear",
+                                                              "add_read_noise", "add_stellar_noise", "add_initial_bias"))
+        print("case %4d %-9s E=%.1e mode=%d %s %s sky=%.1f cr=%s [%s] pixels off %d of %d, median %.1e, max %.2f  %s" % (
+            j, c["name"], c["E"], c["mode"][0], "exact" if c["exact"] else "fast ", "f64" if c["f64"] else "f32",
+            c["over"]["sky_background"], c["over"]["cosmic_rate"], on, bad, size, med, worst, "ok" if ok else "FAILED"),
+            flush=True)
+    print("soak_exposure %s: %d cases, %d failed" % ("ok" if not failed else "FAILED", n_cases, failed))
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
