@@ -267,3 +267,21 @@ def test_a_new_grism_on_a_live_context_forgets_the_old_spectrum_estimates():
         finally:
             swapped.close()
             fresh.close()
+
+
+def test_random_exposures_against_the_oracle():
+    # a fixed-seed stretch of scripts/soak_exposure.py: random small configuration, brightness, detector switches, sky,
+    # cosmic rays, rng mode, exact / production samplers, float32 / float64 reads -- whole exposures against the numpy
+    # oracle on the same counters (3000 cases of it: profiles/r04/soak.txt)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_exposure
+    rng = np.random.default_rng(20261004)
+    modes = set()
+    for j in range(60):
+        c = soak_exposure.case(rng)
+        ok, bad, size, med, worst = soak_exposure.run_case(c)
+        assert ok, "case %d %r: %d of %d pixels off, median %.2e, max %.2f" % (j, c, bad, size, med, worst)
+        modes.add((c["mode"][0], c["exact"], c["f64"]))
+    assert len(modes) >= 10          # the stretch visits nearly every (rng mode, samplers, dtype) combination
