@@ -26,7 +26,7 @@ import helpers  # noqa: E402
 from oracle import wayne_oracle as wo  # noqa: E402  (the checker)
 from wayne_amd import _lib  # noqa: E402
 
-NAMES = ["tiny", "tiny_g102", "tiny128", "stare256", "small256"]
+NAMES = ["tiny", "tiny_g102", "tiny128", "stare256", "small256", "tiny512"]
 MODES = [(_lib.RNG_REPLAY, "oracle"), (_lib.RNG_PHILOX, "philox"), (_lib.RNG_SPLIT, "split")]
 
 
@@ -43,13 +43,25 @@ def case(rng):
     if flag(0.3):
         over["scale_factor"] = float(rng.choice([None, 0.3, 3.0]) or 1.0)
     mode = MODES[int(rng.integers(0, 3))]
+    # scan-speed variations (scanning configurations), the star moved by up to 40 px (a trace partly off the array),
+    # another number of sub-samples
+    ssv = ("sine", float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.3, 2.0)), float(rng.uniform(0, 6.28))) if flag(0.4) else None
+    shift = (float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40))) if flag(0.3) else (0.0, 0.0)
+    K = int(rng.integers(5, 25)) if flag(0.3) and name != "stare256" else None
     return dict(name=name, E=float(10.0 ** rng.uniform(3.5, 6.3)), over=over, mode=mode, exact=flag(),
-                f64=flag(), i=int(rng.integers(0, 4)), threads=int(rng.integers(1, 7)))
+                f64=flag(), i=int(rng.integers(0, 4)), threads=int(rng.integers(1, 7)), ssv=ssv, shift=shift, K=K)
 
 
 def run_case(c):
-    v = helpers.make_visit(c["name"], n_exposures=c["i"] + 1, E=c["E"])
-    kw = v.frame_kwargs(c["i"], **c["over"])
+    from wayne_amd.trend_generators.scan_speed_varations import SSVSine
+    v = helpers.make_visit(c["name"], n_exposures=c["i"] + 1, E=c["E"], **({"K": c["K"]} if c.get("K") else {}))
+    over = dict(c["over"])
+    if c.get("ssv") and v.scan_speed:
+        kind, a, b, z = c["ssv"]
+        over["ssv_generator"] = SSVSine(a, b, z)      # (the modulated sine needs a rate-sampled visit: tests/test_visit_driver.py)
+    kw = v.frame_kwargs(c["i"], **over)
+    kw["x_ref"] += c.get("shift", (0.0, 0.0))[0]
+    kw["y_ref"] += c.get("shift", (0.0, 0.0))[1]
     pg = helpers.product_generator(v, c["i"])
     dt = np.float64 if c["f64"] else np.float32
     exp = pg.scanning_frame(threads=c["threads"], rng_mode=c["mode"][0], out_dtype=dt, exact_samplers=c["exact"], **kw)
@@ -79,6 +91,7 @@ def main():
         failed += not ok
         on = "".join(k[4] if c["over"][k] else "-" for k in ("add_flat", "add_dark", "add_gain_variations", "add_non_linear",
                                                               "add_read_noise", "add_stellar_noise", "add_initial_bias"))
+        on += " ssv=%s shift=(%.0f,%.0f) K=%s" % (c["ssv"][0] if c["ssv"] else None, c["shift"][0], c["shift"][1], c["K"])
         print("case %4d %-9s E=%.1e mode=%d %s %s sky=%.1f cr=%s [%s] pixels off %d of %d, median %.1e, max %.2f  %s" % (
             j, c["name"], c["E"], c["mode"][0], "exact" if c["exact"] else "fast ", "f64" if c["f64"] else "f32",
             c["over"]["sky_background"], c["over"]["cosmic_rate"], on, bad, size, med, worst, "ok" if ok else "FAILED"),
