@@ -58,3 +58,37 @@ def test_no_gpu_fails_loudly():
     from wayne_amd import pyparallel
     with pytest.raises(_lib.WayneError):
         pyparallel.apply_psf(np.ones(3), np.ones(3), np.ones(3), np.ones(3), np.ones(3), np.ones(3), 8, 8, 0, 1)
+
+
+def test_header_is_plain_c_and_the_binding_mirrors_its_layout(tmp_path):
+    # include/wayne_hip.h is the boundary a C (cgo / JNI / ctypes) caller binds: it must compile as strict C99 and as
+    # C++ by itself, and the ctypes mirror must agree with the compiler on the size of every struct and the offset of
+    # every field (a drifted struct corrupts every call silently)
+    import ctypes as C
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    pairs = [("wayne_grism_desc", _lib.GrismDesc), ("wayne_calibration", _lib.Calibration),
+             ("wayne_exposure_desc", _lib.ExposureDesc), ("wayne_profile", _lib.Profile)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "wayne_hip.h"', "int main(void) {"]
+    for cname, ct in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in ct._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = str(tmp_path / "layout")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", exe], check=True)
+    out = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in pairs:
+        assert int(out[cname]) == C.sizeof(ct), cname
+        for f in ct._fields_:
+            assert int(out["%s.%s" % (cname, f[0])]) == getattr(ct, f[0]).offset, "%s.%s" % (cname, f[0])
+    gxx = shutil.which("g++")
+    if gxx:
+        subprocess.run([gxx, "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-x", "c++", "-I", inc, "-c", str(src),
+                        "-o", str(tmp_path / "layout.o")], check=True)
