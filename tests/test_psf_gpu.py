@@ -217,3 +217,34 @@ def test_hostile_inputs_all_modes(gpu_ctx):
     a = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 5, rng_mode=_lib.RNG_SPLIT)
     moved = int(np.abs(a.astype(np.int64) - w2).sum()) // 2
     assert moved <= 5 + 1e-3 * w2.sum(), "%d of %d electrons moved" % (moved, w2.sum())
+
+
+def test_inner_boundary_from_plain_c(tmp_path):
+    # examples/psf_from_c.c: the thrower called from a C program that sees nothing but include/wayne_hip.h and
+    # libwayne_hip.so (no Python, no torch on its side of the boundary) -- a golden vector of the reference in, the
+    # reference's frame out, bit for bit
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "wayne_amd")
+    exe = str(tmp_path / "psf_from_c")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "psf_from_c.c"), "-o", exe, "-L", libdir, "-lwayne_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    for name in ("s64_t3", "s256_t4"):
+        k = load_golden_psf(name)
+        n = k["counts"].size
+        with open(str(tmp_path / "in.bin"), "wb") as f:
+            f.write(np.array([n, k["nr"], k["nc"], k["test"], k["threads"]], dtype=np.int32).tobytes())
+            f.write(k["counts"].astype(np.int32).tobytes())
+            for a in ("x", "y", "ratio", "sl", "sh"):
+                f.write(np.ascontiguousarray(k[a], dtype=np.float64).tobytes())
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        frame = np.fromfile(str(tmp_path / "out.bin"), dtype=np.int32)
+        np.testing.assert_array_equal(frame, k["frame"].ravel())
+        assert ("%d electrons" % int(k["frame"].sum())) in r.stdout
