@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 5
+#define WAYNE_ABI_VERSION 6
 
 /* status codes */
 #define WAYNE_OK 0
@@ -269,6 +269,13 @@ int wayne_exposure_debug_boxes(wayne_ctx *ctx, int slot, int32_t *boxes, int32_t
  * back = the fused up-the-ramp kernel. */
 int wayne_exposure_run_front(wayne_ctx *ctx, int slot);
 int wayne_exposure_run_back(wayne_ctx *ctx, int slot);
+/* Which instantiation of the fused up-the-ramp kernel the back half of `slot` launches, written into buf (cap bytes,
+ * NUL-terminated) in the form a kernel trace prints it, e.g. "k_ramp<float, true, 1, false, true>": <type of the reads,
+ * production (hardware) math, sky sampler 0 direct / 1 alias tables / 2 tables + pieces, gaussian-noise stage, every
+ * detector switch on>.  The arithmetic differs between them (float: exact integer sums + an all-float32 per-read
+ * chain; double: fp64 cumulative sum), so a measurement names the one it timed (bench.py `dtype`, `roofline.kernel`).
+ * No reference counterpart: the reference has one float64 numpy path (exposure_generator.py:407-515). */
+int wayne_exposure_ramp_variant(wayne_ctx *ctx, int slot, char *buf, int cap);
 
 /* ---- measurement ------------------------------------------------------- */
 

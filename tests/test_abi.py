@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_strerror():
     L = _lib.load()
-    assert L.wayne_abi_version() == 5
+    assert L.wayne_abi_version() == 6
     assert L.wayne_strerror(0) == b"ok"
     assert b"gfx950" in L.wayne_strerror(_lib.E_NODEVICE)
 

@@ -1,0 +1,400 @@
+"""CPU: the product's host-side launch planner (wayne_amd/csrc/host_plan.h) under AddressSanitizer + UBSan.
+
+The planner decides, per exposure, where k_ramp may skip accumulators (`accumulator_boxes`), in which order and
+batches the thrower's workgroups run (`estimate_thrown`, `lane_batches`) and which sky alias tables are built
+(`plan_sky`).  A wrong answer loses electrons silently: round 3 took the trace's ends from the FIRST and LAST array
+element of an unordered wavelength grid (fixed by commit 081cbbc), round 4 kept spectrum estimates alive across
+wayne_ctx_set_grism (fixed by commit d35fc47).  Both lived behind wayne_ctx_create, reachable only on a GPU box.  Here
+the same header is compiled with g++ -fsanitize=address,undefined (tests/native/) and driven with random and hostile
+descriptors; the checker is the oracle's own trace (oracle/wayne_oracle.py: grism.py:491-506, 553-602, 779-803) and
+numpy / scipy restatements of the other rules.  Negative-control builds bring each historical defect back and must FAIL.
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+import plan_harness as ph
+from oracle import wayne_oracle as wo
+
+REACH = 6.9          # sigma: what every thrower mode provably stays within (k_ramp)
+MODES = [("SPARS10", 2.932, 10.0), ("RAPID", 0.278, 0.278), ("STEP25", 2.9, 25.0)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    ph.build()
+
+
+def grism_args(name, sigma_scale=1.0, sens_scale=1.0, n_sens=200):
+    g = wo.Grism(name)
+    lo, hi = g.wl_limits
+    sens_wl = np.linspace(lo - 0.05, hi + 0.05, n_sens)
+    sens_val = sens_scale * (1.0 + 0.5 * np.sin(7.0 * sens_wl)) * 1e16
+    return dict(trace=g.trace_coeff, wlsol=g.wl_solution, p_ratio=g.psf_ratio_poly.coeffs,
+                p_sigl=np.asarray(g.psf_sigmal_poly.coeffs) * sigma_scale,
+                p_sigh=np.asarray(g.psf_sigmah_poly.coeffs) * sigma_scale, sens_wl=sens_wl, sens_val=sens_val), g
+
+
+def random_descriptor(rng, hostile=False):
+    """One exposure descriptor as wayne_exposure_upload would see it, with the oracle's view of it."""
+    name = rng.choice(["G141", "G102"])
+    sub = int(rng.choice([64, 128, 256, 512, 1024]))
+    N = 1014 if sub == 1024 else sub
+    S = N + 10
+    sub_scale = 507 - sub // 2
+    if sub == 1024 and rng.random() < 0.7:
+        sub_scale = 0                                     # (the product's choice; -5 is the reference's quirk)
+    R = int(rng.integers(1, 16))
+    K = int(np.clip(np.round(np.exp(rng.uniform(0, np.log(4096)))), R, 4096))
+    ga, g = grism_args(name, sigma_scale=float(rng.choice([1.0, 1.0, 0.5, 3.0])))
+    lo, hi = g.wl_limits
+    W = int(rng.choice([2, 3, 17, 511, 512, 513, 1500, 4494, 5000]))
+    wl = np.sort(1.0 / np.linspace(1.0 / hi, 1.0 / lo, W))
+    order = rng.choice(["sorted", "sorted", "reversed", "rolled", "shuffled", "repeated"])
+    if order == "reversed":
+        wl = wl[::-1].copy()
+    elif order == "rolled":
+        wl = np.roll(wl, W // 2)
+    elif order == "shuffled":
+        wl = rng.permutation(wl)
+    elif order == "repeated":
+        wl = wl[rng.integers(0, W, W)]
+    flux = np.abs(rng.normal(1.0, 0.3, W)) * 10.0 ** rng.uniform(-18, -12)
+    # star: somewhere around the frame's centre in full-frame coordinates, scanning up; sometimes well off the frame
+    x0 = 507 + rng.uniform(-0.45, 0.25) * N
+    y0 = 507 + rng.uniform(-0.5, 0.4) * N
+    if rng.random() < 0.2:
+        y0 += rng.choice([-1, 1]) * rng.uniform(0.6, 3.0) * N            # the scan leaves (or never enters) the frame
+    scan = rng.choice([0.0, rng.uniform(0.0, 1.2) * N])
+    t = np.sort(rng.random(K))
+    x_ref = x0 + rng.normal(0, 0.03, K)
+    y_ref = y0 + scan * t + rng.normal(0, 0.03, K)
+    sample_read = np.minimum((t * R).astype(np.int32), R - 1)
+    if rng.random() < 0.15:
+        sample_read = rng.integers(0, R, K).astype(np.int32)             # reads in no order at all
+    dur = rng.uniform(1.0, 500.0, K)
+    poisoned = False
+    if hostile:
+        what = rng.choice(["wl_nan", "wl_inf", "x_nan", "y_inf", "flux_nan", "huge_sigma", "read_range"])
+        if what == "wl_nan":
+            wl[rng.integers(0, W)] = np.nan
+            poisoned = True
+        elif what == "wl_inf":
+            wl[rng.integers(0, W)] = rng.choice([np.inf, -np.inf, 1e300])
+            poisoned = True
+        elif what == "x_nan":
+            x_ref[rng.integers(0, K)] = np.nan
+            poisoned = True
+        elif what == "y_inf":
+            y_ref[rng.integers(0, K)] = rng.choice([np.inf, -1e9])
+            poisoned = True
+        elif what == "flux_nan":
+            flux[rng.integers(0, W)] = np.nan                              # (a bound can still be built: flux is not in it)
+        elif what == "huge_sigma":
+            ga["p_sigh"] = np.asarray(ga["p_sigh"]) * 1e4
+            poisoned = True
+        else:
+            sample_read[rng.integers(0, K)] = rng.choice([-1, R, 99])
+            poisoned = True
+    return dict(ga=ga, g=g, S=S, sub_scale=sub_scale, R=R, wl=wl, flux=flux, x_ref=x_ref, y_ref=y_ref, dur=dur,
+                sample_read=sample_read, poisoned=poisoned, rng_mode=int(rng.choice([0, 1, 2, 2])),
+                scale=float(rng.choice([1.0, 0.3, 40.0])))
+
+
+def add_plan(batch, d):
+    batch.set_grism(**d["ga"])
+    return batch.plan(d["S"], d["sub_scale"], d["rng_mode"], d["wl"], d["flux"], d["x_ref"], d["y_ref"], d["dur"],
+                      d["sample_read"], d["R"], d["scale"])
+
+
+def positions_outside_box(d, res):
+    """How many (sub-sample, bin) pairs can put an electron on the frame outside box[read]: the oracle's trace for every
+    sub-sample's star position, +- 6.9 sigma of the bin's own PSF, in bordered pixel indices."""
+    S, R = d["S"], d["R"]
+    wl = d["wl"]
+    sl = np.polyval(d["ga"]["p_sigl"], wl)
+    sh = np.polyval(d["ga"]["p_sigh"], wl)
+    reach = REACH * np.maximum(sl, sh)
+    bad = 0
+    box = res["box"]
+    for k in range(d["x_ref"].size):
+        tr = wo.SpectrumTrace(d["x_ref"][k], d["y_ref"][k], d["g"].trace_coeff, d["g"].wl_solution)
+        x = tr.wl_to_x(wl)
+        y = tr.x_to_y(x)
+        xs, ys = x - d["sub_scale"] + 5, y - d["sub_scale"] + 5
+        lo_x, hi_x = np.floor(xs - reach), np.floor(xs + reach)
+        lo_y, hi_y = np.floor(ys - reach), np.floor(ys + reach)
+        on = (hi_x >= 0) & (lo_x <= S - 1) & (hi_y >= 0) & (lo_y <= S - 1)       # some pixel of the frame is in reach
+        b = box[d["sample_read"][k]]
+        ok = (np.maximum(lo_x, 0) >= b[0]) & (np.minimum(hi_x, S - 1) < b[1]) & \
+             (np.maximum(lo_y, 0) >= b[2]) & (np.minimum(hi_y, S - 1) < b[3])
+        bad += int((on & ~ok).sum())
+    return bad
+
+
+def test_boxes_hold_every_electron_random_descriptors():
+    rng = np.random.default_rng(20261004)
+    cases = [random_descriptor(rng) for _ in range(160)]
+    batch = ph.Batch()
+    idx = [add_plan(batch, d) for d in cases]
+    out = batch.run()
+    n_box = 0
+    for d, i in zip(cases, idx):
+        r = out[i]
+        assert np.isfinite(r["smax"]) and r["sig_ok"]
+        assert r["wl_lo"] == d["wl"].min() and r["wl_hi"] == d["wl"].max()
+        assert r["use_box"], "a clean descriptor must get its boxes"
+        n_box += 1
+        assert ((r["box"][:, 0] >= 0) & (r["box"][:, 1] <= d["S"]) & (r["box"][:, 2] >= 0) & (r["box"][:, 3] <= d["S"])).all()
+        assert positions_outside_box(d, r) == 0
+        # reads without a sub-sample get an empty box
+        for rr in range(16):
+            if rr >= d["R"] or not (d["sample_read"] == rr).any():
+                assert (r["box"][rr] == 0).all()
+    assert n_box == len(cases)
+
+
+def test_hostile_descriptors_fall_back_to_loading_everything():
+    rng = np.random.default_rng(7)
+    cases = [random_descriptor(rng, hostile=True) for _ in range(120)]
+    batch = ph.Batch()
+    idx = [add_plan(batch, d) for d in cases]
+    out = batch.run()                      # (no sanitizer report: run() raises on a non-zero exit)
+    seen = {True: 0, False: 0}
+    for d, i in zip(cases, idx):
+        r = out[i]
+        seen[d["poisoned"]] += 1
+        if d["poisoned"]:
+            assert not r["use_box"], "numbers no bound can be built on must mean `load everything`"
+        else:
+            assert r["use_box"] and positions_outside_box(d, r) == 0
+        # whatever came in: the launch orders are permutations, the batches within their limits
+        for key, n in (("chunk_order", r["n_chunks"]), ("lane_order", r["n_lane_chunks"])):
+            assert sorted(r[key][:n].tolist()) == list(range(n))
+        assert 1 <= r["kb"] <= 32
+    assert seen[True] > 40 and seen[False] > 5
+
+
+def test_negative_control_nan_wavelength_read_past_the_sensitivity_table():
+    # found by this harness on its first run (round 5): in rounds 1-4 a NaN wavelength passed neither clamp of the
+    # sensitivity interpolation, std::upper_bound(NaN) is end(), and the planner read sens_val[n] -- one element past the
+    # table, inside wayne_exposure_upload.  The shipped code takes the first value; the old form must be REPORTED here.
+    rng = np.random.default_rng(7)
+    d = random_descriptor(rng)
+    d["wl"] = np.sort(d["wl"])
+    d["wl"][d["wl"].size // 2] = np.nan
+    good, bad = ph.Batch(), ph.Batch()
+    i = add_plan(good, d)
+    add_plan(bad, d)
+    assert not good.run()[i]["use_box"]
+    with pytest.raises(ph.HarnessError, match="heap-buffer-overflow"):
+        bad.run("nan")
+
+
+def test_launch_order_follows_the_expected_electrons():
+    rng = np.random.default_rng(3)
+    batch = ph.Batch()
+    cases = []
+    for _ in range(40):
+        d = random_descriptor(rng)
+        d["wl"] = np.sort(d["wl"])             # (bin widths are those of an ordered grid: tools.py:106-128)
+        if np.unique(d["wl"]).size != d["wl"].size:
+            continue
+        cases.append((d, add_plan(batch, d)))
+    out = batch.run()
+    for d, i in cases:
+        r = out[i]
+        wl, W = d["wl"], d["wl"].size
+        sens = np.interp(wl, d["ga"]["sens_wl"], d["ga"]["sens_val"])
+        rate = d["flux"] * sens * wo.bin_centers_to_widths(wl) * 1e4 * 1e-3
+        np.testing.assert_allclose(r["rate"], rate, rtol=1e-12)
+        np.testing.assert_allclose(r["ratio"], np.polyval(d["ga"]["p_ratio"], wl), rtol=1e-13)
+        np.testing.assert_allclose(r["sigl"], np.polyval(d["ga"]["p_sigl"], wl), rtol=1e-13)
+        cnt = rate * d["dur"].max() * d["scale"]
+        n = (W + 511) // 512
+        assert r["n_chunks"] == r["n_lane_chunks"] == n
+        sums = np.array([cnt[c * 512:(c + 1) * 512].sum() for c in range(n)])
+        order = r["lane_order"][:n]
+        assert sorted(order.tolist()) == list(range(n))
+        assert np.all(np.diff(sums[order]) <= 1e-9 * sums.max()), "heaviest chunk first"
+        assert r["max_chunk_electrons"] == pytest.approx(sums.max(), rel=1e-12)
+        K = d["x_ref"].size
+        assert r["kb"] == min(max((K * n) // 2048, 1), 32)
+        assert r["thin"] == (sums.max() <= 0.9 * 4096)
+        if d["rng_mode"] == 2:
+            wide = np.floor(np.clip(cnt * r["ratio"], 0, cnt))
+            assert r["max_narrow"] == pytest.approx((cnt - wide).max(), rel=1e-12)
+            narrow_ok = (cnt - wide >= 32) & (cnt - wide <= 2 ** 24) & (r["sigl"] > 0.05) & (r["sigl"] * 6.5 <= 6)
+            ind = np.where(narrow_ok, wide, cnt)
+            want = ind[ind > 0.9 * 4096].sum()
+        else:
+            want = cnt[cnt > 0].sum()
+        assert r["est_thrown"] == pytest.approx(want, rel=1e-9, abs=1e-9)
+
+
+def _spec(rng, name="G141", W=1200):
+    _, g = grism_args(name)
+    wl = np.sort(1.0 / np.linspace(1.0 / g.wl_limits[1], 1.0 / g.wl_limits[0], W))
+    flux = np.abs(rng.normal(1, 0.2, W)) * 1e-14
+    K, R, S = 24, 6, 1024
+    t = np.linspace(0, 1, K)
+    return dict(S=S, sub_scale=0, rng_mode=2, wl=wl, flux=flux, x_ref=np.full(K, 404.5), y_ref=457.4 + 40 * t,
+                dur_ms=np.full(K, 100.0), sample_read=np.minimum((t * R).astype(np.int32), R - 1), R=R)
+
+
+def _same(a, b):
+    for k in ("use_box", "est_thrown", "max_chunk_electrons", "max_narrow", "kb", "thin", "smax", "wl_lo", "wl_hi"):
+        if a[k] != b[k]:
+            return False
+    return all(np.array_equal(a[k], b[k]) for k in ("box", "chunk_order", "lane_order", "rate", "ratio", "sigl"))
+
+
+def _cache_sequence(variant=""):
+    """[grism A, plan, plan again, plan(2 x flux), plan(shifted grid), plan(one bin fewer), plan, grism B, plan] in ONE process beside
+    [grism B, plan] in a fresh one."""
+    rng = np.random.default_rng(11)
+    sp = _spec(rng)
+    ga_a, _ = grism_args("G141")
+    ga_b, _ = grism_args("G141", sigma_scale=3.0, sens_scale=6.0)        # six times as sensitive, a PSF three times as wide
+    live = ph.Batch()
+    live.set_grism(**ga_a)
+    i1 = live.plan(**sp)
+    i2 = live.plan(**sp)
+    i3 = live.plan(**dict(sp, flux=sp["flux"] * 2))
+    i4 = live.plan(**dict(sp, wl=sp["wl"] + 1e-6))
+    i5 = live.plan(**dict(sp, wl=sp["wl"][:-1], flux=sp["flux"][:-1]))
+    live.plan(**sp)                                                       # (the spectrum the next grism will meet again)
+    live.set_grism(**ga_b)
+    i6 = live.plan(**sp)
+    fresh = ph.Batch()
+    fresh.set_grism(**ga_b)
+    j = fresh.plan(**sp)
+    a, b = live.run(variant), fresh.run(variant)
+    return a, (i1, i2, i3, i4, i5, i6), b[j]
+
+
+def test_cached_estimates_change_with_everything_they_depend_on():
+    a, (i1, i2, i3, i4, i5, i6), fresh = _cache_sequence()
+    assert a[i1]["rebuilds"] == 1 and a[i2]["rebuilds"] == 1 and _same(a[i1], a[i2])          # same spectrum: a hit
+    assert a[i3]["rebuilds"] == 2                                                              # the flux is part of the key
+    np.testing.assert_allclose(a[i3]["rate"], 2 * a[i1]["rate"], rtol=1e-15)
+    assert a[i4]["rebuilds"] == 3 and not np.array_equal(a[i4]["ratio"], a[i1]["ratio"])     # so is every wavelength
+    assert a[i5]["rebuilds"] == 4 and a[i5]["rate"].size == a[i1]["rate"].size - 1           # and the number of bins
+    assert a[i6]["rebuilds"] == 6                                                              # and the grism
+    assert _same(a[i6], fresh), "a context whose grism was replaced must plan like one built with the new grism"
+    assert a[i6]["smax"] == pytest.approx(3 * a[i1]["smax"]) and a[i6]["rate"].sum() == pytest.approx(6 * a[i1]["rate"].sum())
+    # the wider PSF needs wider boxes
+    w_old = a[i1]["box"][:6, 1] - a[i1]["box"][:6, 0]
+    w_new = a[i6]["box"][:6, 1] - a[i6]["box"][:6, 0]
+    assert np.all(w_new > w_old + 50)
+
+
+def test_negative_control_stale_cache_after_set_grism_is_caught():
+    # round 4's defect (fixed by d35fc47; found on the GPU box as "2829 electrons left in the accumulators"): the
+    # estimates of the OLD grism survive set_grism -- the property above must fail on that build
+    a, (_, _, _, _, _, i6), fresh = _cache_sequence("stale")
+    assert not _same(a[i6], fresh)
+    assert a[i6]["smax"] < 0.5 * fresh["smax"], "the stale build keeps the narrow PSF's reach: boxes too small"
+
+
+def _rolled_case():
+    rng = np.random.default_rng(5)
+    sp = _spec(rng)
+    W = sp["wl"].size
+    sp["wl"], sp["flux"] = np.roll(sp["wl"], W // 2), np.roll(sp["flux"], W // 2)
+    ga, g = grism_args("G141")
+    d = dict(ga=ga, g=g, S=sp["S"], sub_scale=sp["sub_scale"], R=sp["R"], wl=sp["wl"], flux=sp["flux"],
+             x_ref=sp["x_ref"], y_ref=sp["y_ref"], dur=sp["dur_ms"], sample_read=sp["sample_read"], rng_mode=2, scale=1.0)
+    return d
+
+
+def test_negative_control_array_ends_with_a_rotated_grid_is_caught():
+    # round 3's defect (fixed by 081cbbc): a grid rotated by half its length has neighbouring wavelengths in its first
+    # and last element -- boxes built from those two cover a few pixels of a 130-pixel trace
+    d = _rolled_case()
+    good, bad = ph.Batch(), ph.Batch()
+    ig, ib = add_plan(good, d), add_plan(bad, d)
+    rg, rb = good.run()[ig], bad.run("ends")[ib]
+    assert rg["use_box"] and positions_outside_box(d, rg) == 0
+    assert rb["use_box"] and positions_outside_box(d, rb) > 1000, "the harness must see the old code lose electrons"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sky levels and alias tables (k_ramp's sky draw; exposure_generator.py:488-495)
+# ---------------------------------------------------------------------------------------------------------------
+def _read_dt(rng):
+    name, first, step = MODES[rng.integers(0, len(MODES))]
+    R = int(rng.integers(1, 16))
+    return np.concatenate([[first], np.full(R - 1, step)])[:R] if rng.random() < 0.8 else rng.uniform(0.1, 30.0, R)
+
+
+def test_sky_plan_levels_tables_and_fallback():
+    rng = np.random.default_rng(99)
+    batch, cases = ph.Batch(), []
+    for _ in range(150):
+        dt = _read_dt(rng)
+        n = int(rng.choice([1, 2, 15, 1000, 200000]))
+        sky = np.sort(np.abs(rng.normal(1.0, rng.choice([0.0, 0.02, 0.3]), n)).astype(np.float32) + np.float32(1e-3))
+        if rng.random() < 0.2:
+            sky[-1] *= np.float32(rng.choice([3.0, 50.0]))                 # a hot pixel far above its level
+        rate = float(10.0 ** rng.uniform(-2, 2.2))
+        cases.append((dt, sky, rate, batch.sky(rate, dt, sky)))
+    out = batch.run()
+    n_on = n_off = n_pieces = 0
+    for dt, sky, rate, i in cases:
+        r = out[i]
+        R = dt.size
+        bg = (rate * dt).astype(np.float32)                               # float32 bg_count (:489-493)
+        _, first = np.unique(bg, return_index=True)
+        distinct = bg[np.sort(first)]
+        L = max(1, min(15 // distinct.size, 15))
+        levels = np.array([sky[l * sky.size // L] for l in range(L)], dtype=np.float32)
+        lam = (levels[None, :] * distinct[:, None]).astype(np.float32)
+        fits_j = np.all(lam.astype(np.float64) + 8 * np.sqrt(lam.astype(np.float64)) + 8 <= 255, axis=1)
+        of = np.array([int(np.nonzero(distinct == b)[0][0]) for b in bg])
+        want_mask = sum(1 << rr for rr in range(R) if fits_j[of[rr]])
+        assert r["mask"] == want_mask and r["n_bg"] == distinct.size
+        assert np.array_equal(r["keys"], lam.ravel().view(np.uint32))
+        assert np.array_equal(r["tab0"][:R], (of * L).astype(np.uint8))
+        if want_mask == (1 << R) - 1:
+            n_on += 1
+            assert r["alias_on"] and r["L"] == L
+            assert np.array_equal(r["level"][:L], levels) and np.all(np.diff(r["level"][:L]) >= 0) and r["level"][0] == sky[0]
+            gap = max([sky[-1] - levels[-1]] + [levels[l + 1] - levels[l] for l in range(L - 1)])
+            assert r["pieces"] == (not (np.float32(gap) * distinct.max() <= np.float32(16.0)))
+            n_pieces += r["pieces"]
+            for t in range(lam.size):
+                pmf = ph.alias_pmf(r["tables"][t])
+                exact = stats.poisson.pmf(np.arange(256), float(lam.ravel()[t]))
+                assert abs(pmf.sum() - 1.0) < 1e-12 and np.abs(pmf - exact).max() < 1.5e-7
+        else:
+            n_off += 1
+            assert not r["alias_on"] and r["L"] == 1 and not r["pieces"]
+    assert n_on > 40 and n_off > 10 and n_pieces > 3
+
+
+def test_sky_plan_hostile_inputs():
+    batch = ph.Batch()
+    dt = np.array([2.9, 10.0, 10.0])
+    sky = np.sort(np.abs(np.random.default_rng(1).normal(1, 0.02, 500))).astype(np.float32)
+    ids = [batch.sky(0.0, dt, sky), batch.sky(-3.0, dt, sky), batch.sky(float("nan"), dt, sky),
+           batch.sky(5.0, dt, sky, has_sky=False), batch.sky(5.0, dt, sky[:0]), batch.sky(5.0, dt[:0], sky),
+           batch.sky(5.0, np.array([2.9, float("nan"), 10.0]), sky), batch.sky(5.0, np.array([2.9, float("inf")]), sky),
+           batch.sky(5.0, np.full(40, 1.0), sky), batch.sky(1e30, dt, sky), batch.sky(5.0, -dt, sky)]
+    for r in (batch.run()[i] for i in ids):
+        assert not r["alias_on"] and r["L"] == 1 and r["tables"] is None
+
+
+def test_alias_tables_are_the_poisson_law():
+    batch = ph.Batch()
+    lams = [0.0, 1e-30, 1e-6, 0.3, 1.0, 7.5, 50.0, 120.0, 133.1, 133.2, 180.0, 254.9, 1e4, -1.0, float("nan")]
+    ids = [batch.alias(l) for l in lams]
+    out = batch.run()
+    for lam, i in zip(lams, ids):
+        r = out[i]
+        want_fit = (lam >= 0) and (lam + 8 * np.sqrt(lam) + 8 <= 255)
+        assert r["fits"] == bool(want_fit)
+        pmf = ph.alias_pmf(r["table"])
+        assert abs(pmf.sum() - 1.0) < 1e-12                     # a table is a distribution whatever came in
+        if want_fit:
+            assert np.abs(pmf - stats.poisson.pmf(np.arange(256), lam)).max() < 1.5e-7

@@ -25,6 +25,7 @@ F_ADD_INITIAL_BIAS = 1 << 7
 F_OUT_F64 = 1 << 16
 F_EXACT_SAMPLERS = 1 << 17
 PROF_KERNELS = 8
+ABI_VERSION = 6
 
 
 class WayneError(RuntimeError):
@@ -106,6 +107,7 @@ SYMBOLS = {
     "wayne_exposure_debug_boxes": (C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
     "wayne_exposure_run_front": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_run_back": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_ramp_variant": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
     "wayne_profile_enable": (C.c_int, [_vp, C.c_int]),
     "wayne_profile_select": (C.c_int, [_vp, C.c_uint]),
     "wayne_profile_reset": (C.c_int, [_vp]),
@@ -132,7 +134,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
-        if L.wayne_abi_version() != 5:
+        if L.wayne_abi_version() != ABI_VERSION:
             raise ImportError("libwayne_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -286,6 +288,12 @@ class Context(object):
 
     def run_back(self, slot):
         self.check(self._L.wayne_exposure_run_back(self._h, int(slot)))
+
+    def ramp_variant(self, slot):
+        """Name of the k_ramp instantiation the slot's back half launches, as a kernel trace prints it."""
+        buf = C.create_string_buffer(128)
+        self.check(self._L.wayne_exposure_ramp_variant(self._h, int(slot), buf, len(buf)))
+        return buf.value.decode()
 
     def status(self, slot):
         """Status word of the slot's last run (0 = complete; see wayne_exposure_status).  Synchronises."""

@@ -4,11 +4,11 @@
 #include <stdint.h>
 #include <type_traits>
 #include "philox.h"
+#include "plan_consts.h"
 #include "samplers.h"
 
 namespace wayne {
 
-constexpr int kBorder = 5;            // reference-pixel border (detector.py:146-147)
 constexpr int kQBits = 28;            // accumulator fixed point: 2^28 per electron
 constexpr double kQ = 268435456.0;    //   (int64: 3.4e10 e- of range per pixel and read interval,
 constexpr double kInvQ = 1.0 / 268435456.0;  // 1.9e-9 e- rounding per tile flush)
@@ -21,14 +21,7 @@ constexpr double kPi = 3.14159265358979323846;
 // ---------------------------------------------------------------------------
 // shared device structs
 // ---------------------------------------------------------------------------
-struct GrismDev {
-  double trace[9], wlsol[9];
-  double p_ratio[4], p_sigl[4], p_sigh[4];
-  double flat_wmin, flat_wmax;
-  int n_sens;
-  const double* sens_wl;
-  const double* sens_val;
-};
+// (GrismDev, kBorder and the routing / launch-shape constants the host planner shares: plan_consts.h)
 
 // Per sub-sample record written by k_prep_sub and read by k_throw.
 constexpr int kTrStride = 8;   // doubles per sub-sample in the trace-coefficient array (k_prep_wl): 6 coefficients, 1 / m_wl, pad

@@ -42,7 +42,7 @@ namespace wayne {
 // 0.25 sigma in y and 10 % in sigma of one another (Z >~ 0.8) and <= 2^24
 // electrons; any other group runs a column and a row chain per bin as above.
 // oracle/split_oracle.c (so_group_pools, so_narrow_pooled) is the same procedure.
-constexpr int kNarrowThreads = 512;
+// (kNarrowThreads = 512 bins per workgroup: plan_consts.h)
 constexpr int kNarrowCells = 2 * kNarrowR + 1;
 constexpr int kPoolRows = 2 * kNarrowR + 2;   // rows of a group's common window: jc_min - R .. jc_min + R + 1
 constexpr int kNarrowTile = 1536;       // ints of LDS for the workgroup's tile (its bins span ~15 x 1 px + the 13 x 13 windows)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
 // electrons (the spectrum is smooth), and the per-electron work is the draw and the deposit alone.
 // Electron j of the bin takes pair j of the bin's STAGE_LANE stream; the first n_wide electrons take
 // sigma_h (pyparallel_menu.c:89-107).  Same arithmetic as k_throw's Philox mode.
-constexpr int kLaneThreads = 512;
+// (kLaneThreads = 512 bins per workgroup: plan_consts.h)
 // The tile must hold practically every electron: one that falls outside takes the global-atomic path INSIDE the
 // loop (four flat-plane loads, the fp64 flat polynomial, a 64-bit atomic: microseconds of latency with the other
 // 63 lanes of the wave idle).  At a margin of 22 px (3.7 sigma_h) 3 % of the wave-iterations had such a lane and
@@ -363,8 +363,7 @@ constexpr int kLaneTile = 9216;         // ints of LDS (36 KB): 512 bins span ~2
 // (0.259 -> 0.286, 0.039 -> 0.057 ms: more registers, a barrier per sub-sample) and is not kept -- those kernels'
 // time on such an exposure is arithmetic per (bin, sub-sample): ~2.2 Philox blocks and an fp64 product-of-uniforms
 // search per stellar Poisson draw, not prologues (profiles/r03/cfg1_batches.txt).
-constexpr int kLaneListCap = 4096;      // cells on a THIN flush list (beyond it the flush falls back to the scan)
-constexpr int kLaneBatchMax = 32;       // most sub-samples per workgroup
+// (kLaneListCap = 4096 cells on a THIN flush list, kLaneBatchMax = 32 sub-samples per workgroup: plan_consts.h)
 
 // FUSED (thin exposures, split mode, no k_throw and no k_narrow launched): there is no k_prep_sub launch either -- the
 // lane works out its bin's position, count and routing itself, per sub-sample, with k_prep_sub's own code (plan_bin),

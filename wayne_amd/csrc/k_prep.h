@@ -7,7 +7,7 @@ namespace wayne {
 // ---------------------------------------------------------------------------
 // k_prep_wl : A8 + the wavelength-only part of A9
 // ---------------------------------------------------------------------------
-WAYNE_HD void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o);
+// (trace_coeffs: plan_consts.h -- the host's accumulator boxes use the same function)
 
 // (also: thread k computes the trace coefficients of sub-sample k -- six numbers that every workgroup of k_prep_sub
 // needs before it can start; computed there by one thread with the other 511 waiting at a barrier they were ~2 us of
@@ -137,36 +137,7 @@ __device__ __forceinline__ void count_electrons(unsigned long long* counter, uns
 #endif
 constexpr int kPrepThreads = WAYNE_PREP_THREADS;
 constexpr int kMaxPrepChunks = 128;     // chunks of kPrepThreads bins per sub-sample (32768 bins)
-constexpr int kNarrowR = 6;            // k_narrow window: +-6 pixels about the bin's pixel (>= 6.5 sigma_l)
-constexpr int kLaneMax = 4096;         // WAYNE_RNG_SPLIT: a bin's one-by-one electrons are thrown by its own lane (k_lane) up to this many
-constexpr int kLaneReach = 64 * kLaneMax;   // ... and up to this many in an exposure launched without k_throw (a lane then needs
-                                       // ~10 ms for its bin; beyond it the exposure is run again with k_throw)
-constexpr uint32_t kSplitMaxNarrow = 1u << 24;   // k_narrow's chain counts in float32: larger bins are thrown one by one
-
-WAYNE_HD void trace_coeffs(const GrismDev& g, double x_ref, double y_ref, double* o) {
-  // o = {m_t, c_t, m_w, c_w, m_wl, c_wl}
-    // wavelength_calibration_coeffs (grism.py:779-803)
-    const double* t = g.trace;
-    const double* b = g.wlsol;
-    const double m_t = t[3] + t[4] * x_ref + t[5] * y_ref + t[6] * (x_ref * x_ref) +
-                       t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);
-    const double c_t = t[0] + t[1] * x_ref + t[2] * y_ref;
-    const double m_w = b[3] + b[4] * x_ref + b[5] * y_ref + b[6] * (x_ref * x_ref) +
-                       b[7] * x_ref * y_ref + b[8] * (y_ref * y_ref);
-    const double c_w = (b[0] + b[1] * x_ref) + b[2] * y_ref;
-    // _get_x_to_wl_poly_coeffs (grism.py:553-602): line through the trace
-    // points at x_ref+10 and x_ref+20, wavelength in micron.
-    const double xa = x_ref + 10, xb = x_ref + 20;
-    const double ya = m_t * (xa - x_ref) + c_t + y_ref;  // x_to_y (grism.py:537)
-    const double yb = m_t * (xb - x_ref) + c_t + y_ref;
-    const double da = sqrt((ya - y_ref) * (ya - y_ref) + (xa - x_ref) * (xa - x_ref));
-    const double db = sqrt((yb - y_ref) * (yb - y_ref) + (xb - x_ref) * (xb - x_ref));
-    const double wa_ = (m_w * da + c_w) * 1e-4;  // angstrom -> micron
-    const double wb_ = (m_w * db + c_w) * 1e-4;
-    const double m_wl = (wb_ - wa_) / (xb - xa);
-    const double c_wl = wa_ - m_wl * xa;
-    o[0] = m_t; o[1] = c_t; o[2] = m_w; o[3] = c_w; o[4] = m_wl; o[5] = c_wl;
-}
+// (kNarrowR, kLaneMax, kLaneReach, kSplitMaxNarrow, trace_coeffs: plan_consts.h)
 
 // ---------------------------------------------------------------------------
 // cosmic rays : MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139)

@@ -40,14 +40,12 @@ struct RampArgs {
   uint32_t* seg;             // [ceil(S*S / 64)] read and cleared
 };
 
-constexpr int kSkyAlias = 256;   // entries per alias table: alias << 24 | 24-bit acceptance threshold
-constexpr float kSkyPiece = 16.f; // largest mean drawn by one sequential search
+// (kSkyAlias, kSkyPiece, kMaxReads: plan_consts.h)
 
 #ifndef WAYNE_RAMP_THREADS
 #define WAYNE_RAMP_THREADS 1024
 #endif
 constexpr int kRampThreads = WAYNE_RAMP_THREADS;
-constexpr int kMaxReads = 15;   // NSAMP <= 16 (detector.py:228)
 
 // Box-Muller pair from two words.  EXACT mirrors the oracle's libm formula;
 // FAST uses the hardware units (sin / cos take revolutions, log is log2).
@@ -184,20 +182,28 @@ __device__ __forceinline__ float nonlinear_gap_f32(float px, float c1p, float c2
 // thresholds of the random WORD: u01f(w) > c  <=>  w > c 2^32 up to the float32 rounding of u01f (6e-8 of the draws
 // decide differently from the float compare -- the hardware e^-m is itself only good to 1e-6).  They change only
 // when the read interval does, so the read loop keeps them in registers: the search is then four integer compares
-// feeding v_addc, with no conversion of the word.  (v_cvt_u32_f32 saturates: c >= 1 -> 0xFFFFFFFF, never exceeded.)
+// feeding v_addc, with no conversion of the word.
 struct SkyRem {
   float m;                   // the pixel's remainder mean (sky_px - level) * bg_count
   uint32_t t0, t1, t2, t3;
   float c3, term3;           // the float cdf and its last term, for the rare continuation beyond four
+  // c 2^32 as a word, saturating: c >= 1 -> 0xFFFFFFFF, a threshold no word exceeds.  cdf >= 1 happens routinely (m = 0
+  // gives exactly 1, the rounded partial sums of e^-m can exceed it), and a float -> uint32 conversion out of range is
+  // undefined in C++ (poison in LLVM) whatever v_cvt_u32_f32 does with it: the saturation is spelled out, the
+  // conversion only ever sees values below 2^32 (tests/test_extremes_gpu.py: pixels that sit exactly on their level)
+  static __device__ __forceinline__ uint32_t thr(float cdf) {
+    const float x = cdf * 4294967296.f;
+    return (x < 4294967296.f) ? (uint32_t)x : 0xFFFFFFFFu;
+  }
   __device__ __forceinline__ void set(float m_) {
     m = m_;
     float em;
     asm volatile("v_exp_f32 %0, %1" : "=v"(em) : "v"(-1.4426950408889634f * m_));   // (volatile: not to be speculated into every read)
     float t = em, cdf = t;
-    t0 = (uint32_t)(cdf * 4294967296.f);  t = t * m_;                  cdf += t;
-    t1 = (uint32_t)(cdf * 4294967296.f);  t = t * (m_ * 0.5f);         cdf += t;
-    t2 = (uint32_t)(cdf * 4294967296.f);  t = t * (m_ * 0.33333334f);  cdf += t;
-    t3 = (uint32_t)(cdf * 4294967296.f);
+    t0 = thr(cdf);  t = t * m_;                  cdf += t;
+    t1 = thr(cdf);  t = t * (m_ * 0.5f);         cdf += t;
+    t2 = thr(cdf);  t = t * (m_ * 0.33333334f);  cdf += t;
+    t3 = thr(cdf);
     c3 = cdf; term3 = t;
   }
 };
@@ -220,7 +226,9 @@ __device__ __forceinline__ int sky_draw_count_int(const uint32_t* tab, const Sky
     for (int it = 4; it < 512; ++it) {
       t = t * FastMath::div_(sr.m, (float)it);
       const float cn = cdf + t;
+#ifndef WAYNE_NEGCTL_SKY_RUNAWAY     // (negative-control builds of tests/test_extremes_gpu.py bring the defect of rounds 1-3 back)
       if (cn == cdf) break;          // the cdf has stopped growing below u (see sky_draw): stop, not 500 more rounds
+#endif
       cdf = cn;
       if (!(u > cdf)) break;
       k = k + 1;

@@ -38,7 +38,7 @@ namespace wayne {
 //   (detector.py:146-147).  Integer atomics commute, so the result is
 //   bit-reproducible for any launch geometry.
 constexpr int kThrowThreads = 512;
-constexpr int kMaxChunks = 128;         // >= 32768 bins / bins per k_narrow / k_lane workgroup
+// (kMaxChunks: plan_consts.h)
 constexpr int kThrowPCache = 256;       // bins of a workgroup's slice whose prefix / parameters are kept in LDS
 
 struct ThrowArgs {

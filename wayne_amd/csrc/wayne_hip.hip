@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "host_plan.h"
 
 using namespace wayne;
 
@@ -166,13 +167,9 @@ struct wayne_ctx {
   bool have_grism = false;
   GrismDev g{};
   DevBuf sens_wl, sens_val;
-  std::vector<double> sens_wl_host, sens_val_host;   // for the host's estimate of the electron count
-  // ... and what that estimate needs per bin, kept while the spectrum handed in stays the same (every exposure of a
-  // visit brings the same wavelengths and stellar flux): est_rate = flux sens dlam 1e4 1e-3 (electrons per ms at
-  // scale 1), the wide fraction and sigma_l of the bin, the largest PSF sigma and the wavelength range
-  std::vector<double> est_wl, est_flux, est_rate, est_ratio, est_sigl;
-  double est_smax = 0., est_wl_lo = 0., est_wl_hi = 0.;
-  bool est_sig_ok = false;
+  // what the upload keeps per spectrum (host_plan.h): per-bin count rates through this grism's sensitivity, the wide
+  // fraction and sigma_l of a bin, the largest PSF sigma and the wavelength range -- cached on the spectrum's content
+  plan::SpectrumEstimate est;
   // calibration
   bool have_cal = false;
   int subarray = 0, N = 0, S = 0, cal_R = 0;
@@ -293,53 +290,11 @@ int upload(wayne_ctx* c, DevBuf& b, const T* src, size_t n) {
   return WAYNE_OK;
 }
 
-constexpr int kSplitMinHost = 32;
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-// Does Poisson(lam) fit an alias table of kSkyAlias entries (mass beyond the table < 1e-14)?
-bool sky_alias_fits(double lam) {
-  return lam >= 0. && lam + 8. * std::sqrt(lam) + 8. <= (double)(kSkyAlias - 1);
-}
-
-// Walker / Vose alias table of Poisson(lam) over 0 .. kSkyAlias-1, entry = alias << 24 | threshold:
-// a 32-bit word w selects column w >> 24 and keeps it when (w & 0xFFFFFF) < threshold, else takes the
-// alias.  Probabilities in fp64, thresholds rounded to 24 bits (the resolution of a float32 uniform).
-void build_sky_alias(double lam, uint32_t* out /* kSkyAlias */) {
-  constexpr int n = kSkyAlias;
-  double q[n], prob[n];
-  int alias[n], small[n], large[n], n_small = 0, n_large = 0;
-  double sum = 0.;
-  for (int k = 0; k < n; ++k) q[k] = 0.;
-  if (!(lam > 0.)) { q[0] = 1.; sum = 1.; }
-  else {
-    // pmf by recurrence from the mode (one exp / log / lgamma per table): p(k+1) = p(k) lam / (k+1)
-    const int k0 = std::min((int)lam, n - 1);
-    q[k0] = std::exp(-lam + k0 * std::log(lam) - std::lgamma(k0 + 1.0));
-    for (int k = k0; k + 1 < n; ++k) q[k + 1] = q[k] * lam / (double)(k + 1);
-    for (int k = k0; k > 0; --k) q[k - 1] = q[k] * (double)k / lam;
-    for (int k = 0; k < n; ++k) sum += q[k];
-  }
-  for (int k = 0; k < n; ++k) {
-    q[k] = q[k] / sum * n;
-    if (q[k] < 1.) small[n_small++] = k; else large[n_large++] = k;
-    prob[k] = 1.;
-    alias[k] = k;
-  }
-  while (n_small > 0 && n_large > 0) {
-    const int s_ = small[--n_small];
-    const int l_ = large[--n_large];
-    prob[s_] = q[s_];
-    alias[s_] = l_;
-    q[l_] = (q[l_] + q[s_]) - 1.;
-    if (q[l_] < 1.) small[n_small++] = l_; else large[n_large++] = l_;
-  }
-  for (int k = 0; k < n; ++k) {
-    double t = std::floor(prob[k] * 16777216. + 0.5);
-    if (t > 16777215.) t = 16777215.;
-    if (t < 0.) t = 0.;
-    out[k] = ((uint32_t)alias[k] << 24) | (uint32_t)t;
-  }
-}
+// (the launch planner -- spectrum estimates, accumulator boxes, sky levels and alias tables -- is host_plan.h: host-only
+// code that the CPU harness under tests/native builds with sanitizers)
+using plan::build_sky_alias;
 
 // Copy `n` elements into the slot's pinned arena and enqueue the host-to-device copy from there.
 template <class T>
@@ -352,216 +307,37 @@ int upload_staged(wayne_ctx* c, Slot& s, DevBuf& b, const T* src, size_t n) {
   return WAYNE_OK;
 }
 
-// Expected number of electrons k_throw shares out (split mode: only the bins beyond a lane's cap, normally none)
-// in the longest sub-sample of an exposure
-// (the counts chain of k_prep_wl / k_prep_sub without its Poisson noise and transit depth): sizes
-// the thrower's grid, nothing else -- the kernel distributes the electrons it actually finds.
-// (per-bin factors that depend on the spectrum alone are cached in the context: spectrum_cache)
-void spectrum_cache(wayne_ctx* c, const wayne_exposure_desc* d) {
-  const int W = d->n_wl;
-  if ((int)c->est_wl.size() == W && std::memcmp(c->est_wl.data(), d->wl_um, (size_t)W * 8) == 0 &&
-      std::memcmp(c->est_flux.data(), d->flux, (size_t)W * 8) == 0) return;
-  c->est_wl.assign(d->wl_um, d->wl_um + W);
-  c->est_flux.assign(d->flux, d->flux + W);
-  c->est_rate.assign((size_t)W, 0.); c->est_ratio.assign((size_t)W, 0.); c->est_sigl.assign((size_t)W, 0.);
-  const GrismDev& g = c->g;
-  const std::vector<double>&sw = c->sens_wl_host, &sv = c->sens_val_host;
-  auto poly3 = [](const double* p_, double x) { return ((p_[0] * x + p_[1]) * x + p_[2]) * x + p_[3]; };
-  c->est_smax = 0.; c->est_sig_ok = true;
-  for (int i = 0; i < W; ++i) {
-    const double x = d->wl_um[i];
-    double sens = 1.0;
-    if (!sw.empty()) {
-      if (x <= sw.front()) sens = sv.front();
-      else if (x >= sw.back()) sens = sv.back();
-      else {
-        const size_t hi = (size_t)(std::upper_bound(sw.begin(), sw.end(), x) - sw.begin());
-        const size_t lo = hi - 1;
-        sens = sv[lo] + (sv[hi] - sv[lo]) * (x - sw[lo]) / (sw[hi] - sw[lo]);
-      }
-    }
-    const double left = (i == 0) ? (d->wl_um[1] - d->wl_um[0]) / 2. : (x - d->wl_um[i - 1]) / 2.;
-    const double right = (i == W - 1) ? (d->wl_um[W - 1] - d->wl_um[W - 2]) / 2. : (d->wl_um[i + 1] - x) / 2.;
-    c->est_rate[i] = d->flux[i] * sens * (left + right) * 1e4 * 1e-3;
-    c->est_ratio[i] = poly3(g.p_ratio, x);
-    const double sl = poly3(g.p_sigl, x), sh = poly3(g.p_sigh, x);
-    c->est_sigl[i] = sl;
-    if (!(sl >= 0. && sl < 1e3 && sh >= 0. && sh < 1e3) || !(std::fabs(x) < 1e6)) c->est_sig_ok = false;
-    c->est_smax = std::max(c->est_smax, std::max(sl, sh));
-    if (i == 0 || x < c->est_wl_lo) c->est_wl_lo = x;
-    if (i == 0 || x > c->est_wl_hi) c->est_wl_hi = x;
-  }
-}
-
-double estimate_thrown(wayne_ctx* c, const wayne_exposure_desc* d, unsigned char* chunk_order,
-                       unsigned char* lane_order, double* max_chunk_electrons, double* max_narrow) {
-  const int W = d->n_wl, K = d->n_samples;
-  const int n_chunks = (W + kNarrowThreads - 1) / kNarrowThreads;
-  const int n_lane_chunks = (W + kLaneThreads - 1) / kLaneThreads;
-  std::vector<double> chunk_e((size_t)n_chunks, 0.), lane_e((size_t)n_lane_chunks, 0.);
-  double dur_max = 0.;
-  for (int k = 0; k < K; ++k) dur_max = std::max(dur_max, d->dur_ms[k]);
-  spectrum_cache(c, d);
-  const double per_ms = dur_max * d->scale_factor;
-  double total = 0.;
-  *max_narrow = 0.;
-  for (int i = 0; i < W; ++i) {
-    double cnt = c->est_rate[i] * per_ms;
-    if (!(cnt > 0.)) continue;
-    chunk_e[(size_t)(i / kNarrowThreads)] += cnt;
-    lane_e[(size_t)(i / kLaneThreads)] += cnt;
-    if (d->rng_mode == WAYNE_RNG_SPLIT) {
-      const double wide = std::floor(std::min(std::max(cnt * c->est_ratio[i], 0.), cnt));
-      *max_narrow = std::max(*max_narrow, cnt - wide);
-      const double sl = c->est_sigl[i];
-      if (cnt - wide >= (double)kSplitMinHost && cnt - wide <= (double)kSplitMaxNarrow && sl > 0.05 &&
-          sl * 6.5 <= (double)kNarrowR) cnt = wide;   // narrow part: k_narrow
-      if (cnt <= 0.9 * (double)kLaneMax) cnt = 0.;    // thrown by the bin's own lane (k_lane); 10 % headroom for the noise
-    }
-    total += cnt;
-  }
-  // chunks by expected electrons, most first (stable for ties)
-  std::vector<int> order((size_t)n_chunks);
-  for (int i = 0; i < n_chunks; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return chunk_e[a_] > chunk_e[b_]; });
-  for (int i = 0; i < n_chunks && i < kMaxChunks; ++i) chunk_order[i] = (unsigned char)order[i];
-  *max_chunk_electrons = 0.;
-  for (double e : lane_e) *max_chunk_electrons = std::max(*max_chunk_electrons, e);
-  order.resize((size_t)n_lane_chunks);
-  for (int i = 0; i < n_lane_chunks; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return lane_e[a_] > lane_e[b_]; });
-  for (int i = 0; i < n_lane_chunks && i < kMaxChunks; ++i) lane_order[i] = (unsigned char)order[i];
-  return total;
-}
-
-// Where can the accumulators of read interval r be non-zero after the thrower?  An electron lands within
-// sigma sqrt(2 ln 2^34) = 6.87 sigma of its bin in every rng mode (k_lane: "a tile that holds every electron"; k_throw's
-// per-electron mode reaches 6.76 sigma, the replay thrower's rand_r / RAND_MAX 6.56 sigma; k_narrow's window is +-6 px), and the bins of a sub-sample lie
-// on the straight trace between its smallest and its largest wavelength.  So per read: the union over its sub-samples of
-// the trace's end points, +- (6.9 sigma_max + 2) px, in bordered coordinates.  Returns false (-> k_ramp loads
-// everything) when the numbers are not ones a bound can be built on.
-bool accumulator_boxes(wayne_ctx* c, const wayne_exposure_desc* d, int (*box)[4]) {
-  const int K = d->n_samples, R = d->n_reads, S = c->S;
-  const GrismDev& g = c->g;
-  spectrum_cache(c, d);      // (the ABI does not require increasing wavelengths: smallest and largest present, wherever they sit)
-  if (!c->est_sig_ok) return false;
-  // + 1 px: the ends of the trace are taken at the four corners of the rectangle a read's star positions span, not at
-  // every sub-sample (thousands on a finely sampled scan).  The end points move monotonically with the star (d end / d
-  // star = 1 + O(1e-3)); what a corner can miss is the curvature of the trace polynomials over the rectangle -- their
-  // second derivatives are ~1e-8 / px^2, a scan is a few hundred pixels long: < 0.01 px
-  const double reach = 6.9 * c->est_smax + 2. + 1.;
-  if (!(reach < 400.)) return false;
-  double lo_x[16], hi_x[16], lo_y[16], hi_y[16];
-  bool any[16];
-  for (int r = 0; r < 16; ++r) { any[r] = false; lo_x[r] = lo_y[r] = 0.; hi_x[r] = hi_y[r] = 0.; }
-  for (int k = 0; k < K; ++k) {
-    const int r = d->sample_read[k];
-    if (r < 0 || r >= R || r >= 16) return false;
-    const double xr = d->x_ref[k], yr = d->y_ref[k];
-    if (!(std::fabs(xr) < 1e6 && std::fabs(yr) < 1e6)) return false;
-    if (!any[r]) { any[r] = true; lo_x[r] = hi_x[r] = xr; lo_y[r] = hi_y[r] = yr; }
-    else {
-      lo_x[r] = std::min(lo_x[r], xr); hi_x[r] = std::max(hi_x[r], xr);
-      lo_y[r] = std::min(lo_y[r], yr); hi_y[r] = std::max(hi_y[r], yr);
-    }
-  }
-  for (int r = 0; r < 16; ++r) {
-    box[r][0] = box[r][2] = 0x3FFFFFFF; box[r][1] = box[r][3] = -0x3FFFFFFF;
-    if (!any[r]) { box[r][0] = box[r][1] = box[r][2] = box[r][3] = 0; continue; }   // a read without sub-samples
-    for (int corner = 0; corner < 4; ++corner) {
-      const double xr = (corner & 1) ? hi_x[r] : lo_x[r], yr = (corner & 2) ? hi_y[r] : lo_y[r];
-      double tr[6];
-      trace_coeffs(g, xr, yr, tr);
-      for (int e = 0; e < 2; ++e) {
-        const double wl = e ? c->est_wl_hi : c->est_wl_lo;
-        const double x = (wl - tr[5]) / tr[4];
-        const double y = tr[0] * (x - xr) + tr[1] + yr;
-        const double xs = x - (double)d->sub_scale + kBorder, ys = y - (double)d->sub_scale + kBorder;
-        if (!(std::fabs(xs) < 1e6 && std::fabs(ys) < 1e6)) return false;
-        box[r][0] = std::min(box[r][0], (int)std::floor(xs - reach));
-        box[r][1] = std::max(box[r][1], (int)std::floor(xs + reach) + 1);
-        box[r][2] = std::min(box[r][2], (int)std::floor(ys - reach));
-        box[r][3] = std::max(box[r][3], (int)std::floor(ys + reach) + 1);
-      }
-    }
-    box[r][0] = std::max(box[r][0], 0); box[r][2] = std::max(box[r][2], 0);
-    box[r][1] = std::min(box[r][1], S); box[r][3] = std::min(box[r][3], S);
-  }
-  return true;
-}
-
-// Plan the sky draws of an exposure (k_ramp, sky_draw): levels of the master sky, one alias table of
-// Poisson(level * bg_count) per level and distinct read interval, uploaded on the slot's stream with
+// Plan the sky draws of an exposure (plan::plan_sky) and upload the alias tables it names on the slot's stream with
 // the descriptor -- long before k_ramp needs them.
 int prepare_sky_tables(wayne_ctx* c, Slot& s) {
   const wayne_exposure_desc& d = s.d;
-  s.sky_pieces = false; s.sky_alias_on = false; s.sky_mask = 0; s.sky_L = 1;
-  for (float& l_ : s.sky_level) l_ = c->sky_min;
-  std::memset(s.sky_tab0, 0, sizeof s.sky_tab0);
-  if (d.sky_ct_s > 0. && c->has_sky && c->sky_max > 0.f) {
-    // distinct read intervals (float32 bg_count, as the kernel and numpy use it, :489-493) -> L levels each
-    std::vector<float> bg;            // distinct bg_count values, first-appearance order
-    std::vector<int> bg_of((size_t)s.R);
-    for (int r = 0; r < s.R; ++r) {
-      const float b = (float)(d.sky_ct_s * s.read_dt_host[r]);
-      size_t j = 0;
-      while (j < bg.size() && std::memcmp(&bg[j], &b, 4) != 0) ++j;
-      if (j == bg.size()) bg.push_back(b);
-      bg_of[r] = (int)j;
+  plan::SkyPlan sp;
+  plan::plan_sky(d.sky_ct_s, s.R, s.read_dt_host.data(), c->has_sky, c->sky_min, c->sky_max, c->sky_sorted, &sp);
+  s.sky_pieces = sp.pieces; s.sky_alias_on = false; s.sky_mask = 0; s.sky_L = 1;
+  for (int l = 0; l < 16; ++l) { s.sky_level[l] = sp.level[l]; s.sky_tab0[l] = sp.tab0[l]; }
+  if (!sp.alias_on) { s.sky_pieces = false; return WAYNE_OK; }    // (no sky, or a read whose rates fit no table: the direct sampler)
+  if (sp.keys != s.sky_tab_keys || !s.sky_tab.p) {
+    const size_t bytes = (size_t)kMaxReads * kSkyAlias * sizeof(uint32_t);
+    HIP_TRY(c, s.sky_tab.reserve(bytes));
+    if (!s.sky_tab_host && hipHostMalloc((void**)&s.sky_tab_host, bytes, hipHostMallocDefault) != hipSuccess)
+      return fail(c, WAYNE_E_NOMEM, "upload: pinned allocation for the sky tables failed");
+    if (!s.sky_tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.sky_tab_ev, hipEventDisableTiming));
+    if (s.sky_tab_pending) { HIP_TRY(c, hipEventSynchronize(s.sky_tab_ev)); s.sky_tab_pending = false; }
+    std::memset(s.sky_tab_host, 0, bytes);
+    for (size_t t = 0; t < sp.keys.size() && t < (size_t)kMaxReads; ++t) {
+      // (a table is ~1 us to build -- no cache: the sky level, and with it every rate, changes with the exposure)
+      float lam;
+      std::memcpy(&lam, &sp.keys[t], 4);
+      build_sky_alias((double)lam, s.sky_tab_host + t * kSkyAlias);
     }
-    const int L = std::max(1, std::min(kMaxReads / (int)bg.size(), kMaxReads));
-    // levels = the l/L quantiles of the positive sky pixels (actual pixel values, [0] = the minimum): most
-    // pixels sit just above their level, so their own remainder is a fraction of an electron
-    float levels[16];
-    for (int l = 0; l < 16; ++l) levels[l] = c->sky_max;
-    for (int l = 0; l < L; ++l) levels[l] = c->sky_sorted[(size_t)l * c->sky_sorted.size() / (size_t)L];
-    std::vector<uint32_t> keys(bg.size() * (size_t)L, 0u);
-    std::vector<char> fits(bg.size(), 1);
-    for (size_t j = 0; j < bg.size(); ++j)
-      for (int l = 0; l < L; ++l) {
-        const float level = levels[l];
-        const float lam = level * bg[j];
-        if (!sky_alias_fits((double)lam)) fits[j] = 0;
-        std::memcpy(&keys[j * L + l], &lam, 4);
-      }
-    uint32_t mask = 0;
-    for (int r = 0; r < s.R; ++r) {
-      if (fits[bg_of[r]]) mask |= 1u << r;
-      s.sky_tab0[r] = (unsigned char)(bg_of[r] * L);
-    }
-    if (mask == (1u << s.R) - 1u) {     // every read fits its tables; otherwise the exposure takes the direct sampler
-      if (keys != s.sky_tab_keys || !s.sky_tab.p) {
-        const size_t bytes = (size_t)kMaxReads * kSkyAlias * sizeof(uint32_t);
-        HIP_TRY(c, s.sky_tab.reserve(bytes));
-        if (!s.sky_tab_host && hipHostMalloc((void**)&s.sky_tab_host, bytes, hipHostMallocDefault) != hipSuccess)
-          return fail(c, WAYNE_E_NOMEM, "upload: pinned allocation for the sky tables failed");
-        if (!s.sky_tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&s.sky_tab_ev, hipEventDisableTiming));
-        if (s.sky_tab_pending) { HIP_TRY(c, hipEventSynchronize(s.sky_tab_ev)); s.sky_tab_pending = false; }
-        std::memset(s.sky_tab_host, 0, bytes);
-        for (size_t t = 0; t < keys.size(); ++t) {
-          if (!fits[t / L]) continue;
-          // (a table is ~1 us to build -- no cache: the sky level, and with it every rate, changes with the exposure)
-          float lam;
-          std::memcpy(&lam, &keys[t], 4);
-          build_sky_alias((double)lam, s.sky_tab_host + t * kSkyAlias);
-        }
-        HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
-        s.sky_tab_pending = true;
-        s.sky_tab_keys = keys;
-      }
-      s.sky_alias_on = true;
-      s.sky_mask = mask;
-      s.sky_L = L;
-      for (int l = 0; l < 16; ++l) s.sky_level[l] = levels[l];
-      // largest remainder any pixel can have: the widest gap between levels (the top one reaches sky_max)
-      float gap = c->sky_max - levels[L - 1];
-      for (int l = 0; l + 1 < L; ++l) gap = std::max(gap, levels[l + 1] - levels[l]);
-      float bg_max = 0.f;
-      for (float b : bg) bg_max = std::max(bg_max, b);
-      s.sky_pieces = !(gap * bg_max <= kSkyPiece);
-    }
+    HIP_TRY(c, hipMemcpyAsync(s.sky_tab.p, s.sky_tab_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(s.sky_tab_ev, c->stream));
+    s.sky_tab_pending = true;
+    s.sky_tab_keys = sp.keys;
   }
+  s.sky_alias_on = true;
+  s.sky_mask = sp.mask;
+  s.sky_L = sp.L;
   return WAYNE_OK;
 }
 
@@ -595,9 +371,6 @@ int launch_throw(wayne_ctx* c, const ThrowArgs& a, int lds_ints) {
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
 }
-
-constexpr int kSplitMin = 32;   // bins with fewer narrow electrons are thrown one by one
-static_assert(kSplitMin == kSplitMinHost, "split threshold");
 
 template <int FLUSH>
 int launch_narrow(wayne_ctx* c, const ThrowArgs& a, bool exact) {
@@ -640,6 +413,28 @@ int launch_lane(wayne_ctx* c, const ThrowArgs& a, bool thin, const PrepArgs* fus
   }
   HIP_TRY(c, hipGetLastError());
   return WAYNE_OK;
+}
+
+
+// The k_ramp instantiation the back half of slot `s` launches, and (if asked) its name as the kernel trace prints it.
+void (*select_ramp(const wayne_ctx* c, const Slot& s, std::string* name))(RampArgs) {
+  const wayne_exposure_desc& d = s.d;
+  const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
+  const int sky_mode = !s.sky_alias_on ? 0 : (s.sky_pieces ? 2 : 1);
+  const bool noise = d.noise_mean != 0. && d.noise_std != 0.;
+  void (*kern)(RampArgs) = pick_ramp(f64, exact, sky_mode, noise);
+  // the production variant with every detector switch on (the rule) has an instantiation of its own (k_ramp.h, ALLON)
+  const uint32_t all_on = WAYNE_F_ADD_DARK | WAYNE_F_ADD_NON_LINEAR | WAYNE_F_CLIP_DET_LIMITS | WAYNE_F_ADD_READ_NOISE;
+  const bool allon = !f64 && !exact && sky_mode == 1 && !noise && (d.flags & all_on) == all_on && c->has_dark && c->has_lin;
+  if (allon) kern = k_ramp<float, true, 1, false, true>;
+  if (name) {
+    const bool pinned = !exact && sky_mode != 0 && !noise;      // ramp_kernel(): k_ramp where it fits 64 registers, else k_ramp_wide
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "%s<%s, %s, %d, %s%s>", pinned ? "k_ramp" : "k_ramp_wide", f64 ? "double" : "float",
+                  exact ? "false" : "true", sky_mode, noise ? "true" : "false", pinned ? (allon ? ", true" : ", false") : "");
+    *name = buf;
+  }
+  return kern;
 }
 
 }  // namespace
@@ -937,8 +732,6 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   if ((rc = upload(c, c->sens_wl, g->sens_wl_um, (size_t)g->n_sens))) return rc;
   if ((rc = upload(c, c->sens_val, g->sens_val, (size_t)g->n_sens))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->sens_wl_host.assign(g->sens_wl_um, g->sens_wl_um + g->n_sens);
-  c->sens_val_host.assign(g->sens_val, g->sens_val + g->n_sens);
   GrismDev& d = c->g;
   std::memcpy(d.trace, g->trace_coeff, sizeof d.trace);
   std::memcpy(d.wlsol, g->wl_solution, sizeof d.wlsol);
@@ -951,9 +744,8 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   d.sens_wl = c->sens_wl.as<double>();
   d.sens_val = c->sens_val.as<double>();
   c->have_grism = true;
-  // what the upload keeps per spectrum was worked out with the previous grism's polynomials and sensitivity
-  c->est_wl.clear();
-  c->est_flux.clear();
+  // (... which also forgets what the upload kept per spectrum: it was worked out with the previous grism)
+  c->est.set_grism(d, g->sens_wl_um, g->sens_val, g->n_sens);
   return WAYNE_OK;
 }
 
@@ -1129,21 +921,24 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
   s.W = W; s.K = K; s.R = R;
   s.read_dt_host.assign(d->read_dt_s, d->read_dt_s + R);
   lap(0, t_lap);     // staging, copies, reservations
-  s.est_thrown = estimate_thrown(c, d, s.chunk_order, s.lane_order, &s.max_chunk_electrons, &s.max_narrow);
+  {
+    plan::ThrowPlan tp;
+    plan::estimate_thrown(c->est, W, d->wl_um, d->flux, K, d->dur_ms, d->scale_factor, d->rng_mode, &tp);
+    s.est_thrown = tp.est_thrown; s.max_chunk_electrons = tp.max_chunk_electrons; s.max_narrow = tp.max_narrow;
+    std::memcpy(s.chunk_order, tp.chunk_order, sizeof s.chunk_order);
+    std::memcpy(s.lane_order, tp.lane_order, sizeof s.lane_order);
+  }
   lap(1, t_lap);
   {
-    // k_lane's batches: enough workgroups to fill the chip several times over (~2048), no more -- a finely sampled
-    // scan (K in the thousands) otherwise launches tens of thousands of workgroups of ~1000 electrons each
-    const int n_chunks_l = (W + kLaneThreads - 1) / kLaneThreads;
-    int kb = (int)(((long long)K * n_chunks_l) / 2048);
-    kb = std::min(std::max(kb, 1), kLaneBatchMax);
+    // k_lane's batches and its first-touch flush list (plan::lane_batches)
+    int kb = 1;
+    plan::lane_batches(K, W, s.max_chunk_electrons, &kb, &s.thin);
     if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), kLaneBatchMax);
     s.kb = kb;
-    // thin: the expected electrons of the fullest chunk in the longest sub-sample fit the flush list with room to spare
-    s.thin = s.max_chunk_electrons <= 0.9 * kLaneListCap;
     if (const char* e = std::getenv("WAYNE_THIN")) s.thin = std::atoi(e) != 0;
   }
-  s.use_box = accumulator_boxes(c, d, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
+  s.use_box = plan::accumulator_boxes(c->est, W, d->wl_um, d->flux, K, R, c->S, d->sub_scale, d->x_ref, d->y_ref,
+                                      d->sample_read, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
   lap(2, t_lap);
   {
     const size_t seg_bytes = ((SS + 63) / 64) * sizeof(uint32_t);
@@ -1391,9 +1186,13 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   const int S = c->S;
   RampArgs a{};
   a.R = s.R; a.N = c->N; a.S = S;
-  // measurement knob (scripts/ramp_vs_reads.py): the kernel works through the first n reads only -- timing runs, the
-  // slot's other accumulators stay uncleared
-  if (const char* e_ = std::getenv("WAYNE_RAMP_READS")) a.R = std::max(1, std::min(s.R, std::atoi(e_)));
+#ifdef WAYNE_TIMING_KNOBS
+  // measurement knob of TIMING BUILDS only (scripts/ramp_vs_reads.py builds its own library with -DWAYNE_TIMING_KNOBS):
+  // the kernel works through the first n reads only -- the slot's other accumulators stay uncleared and the later
+  // reads' planes stale, so the shipped library does not look at the variable at all
+  bool ramp_reads_cut = false;
+  if (const char* e_ = std::getenv("WAYNE_RAMP_READS")) { a.R = std::max(1, std::min(s.R, std::atoi(e_))); ramp_reads_cut = a.R < s.R; }
+#endif
   a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
   a.sky_ct_s = d.sky_ct_s; a.noise_mean = d.noise_mean; a.noise_std = d.noise_std;
   a.read_dt = s.read_dt.as<double>();
@@ -1409,7 +1208,6 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if ((d.flags & WAYNE_F_ADD_NON_LINEAR) && !c->has_lin) return fail(c, WAYNE_E_STATE, "run: add_non_linear without coefficient planes");
   if (d.sky_ct_s > 0. && !c->has_sky) return fail(c, WAYNE_E_STATE, "run: sky background without a master sky");
   // sky tables were planned and uploaded with the descriptor (prepare_sky_tables)
-  bool sky_pieces = s.sky_pieces;
   a.sky_alias = s.sky_alias_on ? s.sky_tab.as<uint32_t>() : nullptr;
   a.alias_mask = s.sky_alias_on ? s.sky_mask : 0u;
   a.sky_levels = s.sky_L;
@@ -1422,20 +1220,27 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   const unsigned blocks = (unsigned)(((size_t)S * S + threads - 1) / threads);
   {
     ProfScope ps(c, PK_RAMP, true);
-    const bool f64 = (d.flags & WAYNE_F_OUT_F64) != 0, exact = (d.flags & WAYNE_F_EXACT_SAMPLERS) != 0;
-    const int sky_mode = a.sky_alias == nullptr ? 0 : (sky_pieces ? 2 : 1);
-    const bool noise = d.noise_mean != 0. && d.noise_std != 0.;
-    void (*kern)(RampArgs) = pick_ramp(f64, exact, sky_mode, noise);
-    // the production variant with every detector switch on (the rule) has an instantiation of its own (k_ramp.h, ALLON)
-    const uint32_t all_on = WAYNE_F_ADD_DARK | WAYNE_F_ADD_NON_LINEAR | WAYNE_F_CLIP_DET_LIMITS | WAYNE_F_ADD_READ_NOISE;
-    if (!f64 && !exact && sky_mode == 1 && !noise && (d.flags & all_on) == all_on && c->has_dark && c->has_lin)
-      kern = k_ramp<float, true, 1, false, true>;
+    void (*kern)(RampArgs) = select_ramp(c, s, nullptr);
     if (ps.on) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, ps.rec.a, ps.rec.b, 0, a);
     else hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
   }
   s.acc_dirty = false;
+#ifdef WAYNE_TIMING_KNOBS
+  if (ramp_reads_cut) s.acc_dirty = true;     // the next front half starts from cleared accumulators
+#endif
   s.front_done = false;
+  return WAYNE_OK;
+}
+
+int wayne_exposure_ramp_variant(wayne_ctx* c, int slot, char* buf, int cap) {
+  if (!c || !buf || cap <= 0) return WAYNE_E_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(c, WAYNE_E_INVALID, "ramp_variant: slot");
+  const Slot& s = c->slots[slot];
+  if (!s.uploaded) return fail(c, WAYNE_E_STATE, "ramp_variant: slot not uploaded");
+  std::string name;
+  (void)select_ramp(c, s, &name);
+  std::snprintf(buf, (size_t)cap, "%s", name.c_str());
   return WAYNE_OK;
 }
 

@@ -44,19 +44,64 @@ def rank_env(rank, world, port, extra=None):
     return env
 
 
-def launch_ranks(n, cmd, extra_env=None, capture_rank0=False):
-    """Start `cmd` (a list, e.g. [sys.executable, script, args...]) n times, one per rank; wait for all.
-    Returns (exit codes, rank 0's stdout or None)."""
+RENDEZVOUS_TIMEOUT_S = 120      # every init_process_group of this package: a missing rank is an error, not a 30 min wait
+KILLED_BY_LAUNCHER = -15        # exit code reported for a rank the launcher ended because a sibling had failed
+
+
+def rendezvous_timeout():
+    import datetime
+    return datetime.timedelta(seconds=int(os.environ.get("WAYNE_RENDEZVOUS_TIMEOUT_S", RENDEZVOUS_TIMEOUT_S)))
+
+
+def launch_ranks(n, cmd, extra_env=None, capture_rank0=False, poll_s=0.05, grace_s=5.0):
+    """Start `cmd` (a list, e.g. [sys.executable, script, args...]) n times, one per rank, and watch them all:
+    the first rank that exits non-zero ends the run -- its siblings (which may be sitting in a rendezvous or a
+    barrier that can no longer complete) are terminated, then killed after `grace_s`.
+    Returns (exit codes, rank 0's stdout or None); a rank ended by the launcher reports a negative code."""
+    import tempfile
+    import time
     port = free_port()
     procs = []
-    for r in range(n):
-        out = subprocess.PIPE if (capture_rank0 and r == 0) else (subprocess.DEVNULL if capture_rank0 else None)
-        procs.append(subprocess.Popen(cmd, env=rank_env(r, n, port, extra_env), stdout=out, text=True))
-    out0 = None
-    if capture_rank0:
-        out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    return codes, out0
+    # rank 0's stdout goes to a file, not a pipe: nobody has to drain it while the launcher polls
+    cap = tempfile.TemporaryFile(mode="w+") if capture_rank0 else None
+    try:
+        for r in range(n):
+            out = cap if (capture_rank0 and r == 0) else (subprocess.DEVNULL if capture_rank0 else None)
+            procs.append(subprocess.Popen(cmd, env=rank_env(r, n, port, extra_env), stdout=out, text=True))
+        failed = False
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = True
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+        if failed:
+            first = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            sys.stderr.write("launch: rank %d exited with code %d; ending the other ranks\n" % first[0])
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + grace_s
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.0, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        codes = [p.wait() for p in procs]
+        out0 = None
+        if cap is not None:
+            cap.seek(0)
+            out0 = cap.read()
+        return codes, out0
+    finally:
+        for p in procs:          # (an exception in the launcher itself must not leave ranks behind)
+            if p.poll() is None:
+                p.kill()
+        if cap is not None:
+            cap.close()
 
 
 def _cpulist(text):
