@@ -28,10 +28,14 @@ Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
   roofline      the fused up-the-ramp kernel k_ramp against the HBM roof
   cpu_baseline  the reference's C thrower + the numpy restatement of the host
                 loop, timed on this box's host cores on a bounded sample
-  per_electron / replay_bit_exact / out_f64 / two_streams / delivered / end_to_end / psf_apply_replay
+  delivered / end_to_end
+                SURVEY 8(d)'s second leg at every N: reads in pinned host memory
+                (PCIe-inclusive), barrier + synchronise either side, max over ranks,
+                every rank's own rate listed -- never `value`
+  per_electron / replay_bit_exact / out_f64 / two_streams / psf_apply_replay   (N = 1)
                 the same workload measured like-for-like with the reference
-                (every electron thrown; float64 reads) and through the host
-                pipeline (PCIe-inclusive) -- never `value`
+                (every electron thrown; float64 reads, with a roofline block of its
+                own) -- never `value`
 """
 import argparse
 import hashlib
@@ -163,6 +167,42 @@ def cpu_baseline(visit, budget_s=20.0):
             "thrower_electrons_per_s": electrons / float(np.sum(t_sub))}
 
 
+def timed_pass(ctx, slot_of, steps, warmup, sync=None, events_every=0):
+    """One rank's timed pass: `warmup` untimed exposures, synchronise (`sync`: the caller's barrier + device
+    synchronise; default the context's own), exactly `steps` exposures, synchronise -> elapsed seconds by this
+    process's clock.  Every device-complete rate of bench.py AND of scripts/bench_configs.py goes through here."""
+    sync = sync or ctx.synchronize
+    for j in range(warmup):
+        ctx.run(slot_of(j))
+    sync()
+    t0 = time.perf_counter()
+    for j in range(warmup, warmup + steps):
+        if events_every:
+            ctx.profile_enable((j - warmup) % events_every == 0)
+        ctx.run(slot_of(j))
+    ctx.synchronize()
+    return time.perf_counter() - t0
+
+
+def median_of_passes(ctx, slot_of, steps, reps=3, warmup=4, sync=None):
+    """Median exposures/s of `reps` passes of `steps` exposures; `warmup` untimed exposures before the first pass."""
+    vals = [steps / timed_pass(ctx, slot_of, steps, warmup if rep == 0 else 0, sync) for rep in range(reps)]
+    return float(np.median(vals)), vals
+
+
+def dtype_label(ramp_variant, out_f64):
+    """`dtype` of the JSON line: the arithmetic the TIMED kernels compute in, derived from the k_ramp instantiation the
+    library reports for the timed slots (wayne_exposure_ramp_variant) -- not a fixed string."""
+    thrower = "f32 thrower (int32 LDS tiles -> int64 fixed-point accumulators, 2^-28 e-)"
+    if ramp_variant.startswith("k_ramp<float, true"):
+        ramp = "exact integer sums (int64 accumulators + int32 sky counts) then an all-f32 per-read chain"
+    elif "<float" in ramp_variant:
+        ramp = "f64 cumulative sum and per-read chain, reads rounded to f32"
+    else:
+        ramp = "f64 cumulative sum and per-read chain"
+    return "%s: %s; %s; %s reads" % (ramp_variant, ramp, thrower, "f64" if out_f64 else "f32")
+
+
 # ---------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torchrun
 # ---------------------------------------------------------------------------
@@ -196,7 +236,10 @@ def dry_run(rank, world):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from wayne_amd import launch
+    if os.environ.get("WAYNE_DRY_RUN_FAIL_RANK") == str(rank):     # rehearsal of a rank that dies before the rendezvous
+        raise SystemExit(3)                                       # (tests/test_bench_contract.py: the launcher must fail fast)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=launch.rendezvous_timeout())
     dist.barrier()
     t = torch.tensor([float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,7 +305,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # gloo: a barrier and a max-reduce of one double on the host -- the data path has no collective
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # (a rank that never arrives is an error after launch.RENDEZVOUS_TIMEOUT_S, not a wait until the driver's limit)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=launch.rendezvous_timeout())
 
     from wayne_amd import _lib, calibration, detector, engine, grism, synthetic, visit as wvisit
     from wayne_amd.exposure_generator import ExposureGenerator
@@ -302,17 +346,7 @@ def main():
         """Exactly `steps` exposures after `warmup` untimed ones, bracketed by barrier + synchronise;
         returns the elapsed seconds (max over ranks).  events_every = n: the selected kernels' HIP events are
         recorded on every n-th exposure only (an event pair costs the stream ~5 us either side of the kernel)."""
-        for j in range(warmup):
-            ctx.run(slot_of(j))
-        sync_all()
-        t0 = time.perf_counter()
-        for j in range(warmup, warmup + steps):
-            if events_every:
-                ctx.profile_enable((j - warmup) % events_every == 0)
-            ctx.run(slot_of(j))
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_pass(ctx, slot_of, steps, warmup, sync_all, events_every)
         own_rates.append(steps / elapsed if (steps and elapsed > 0) else 0.0)    # this rank's own exposures/s
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64)
@@ -387,73 +421,155 @@ def main():
     assert np.isfinite(reads).all() and reads[-1].max() > 100.0
 
     extras = {}
+    out_mb = (eng.R + 1) * eng.S * eng.S * 4 / 1e6
+    n_x = min(args.steps, 30)
+
+    def median_rate(sl, steps, reps=3, warmup=None):
+        """Median of `reps` passes of exactly `steps` exposures (each its own barrier + synchronise bracket); the
+        first pass is preceded by `warmup` untimed exposures.  (median_of_passes with the ranks' max-reduce;
+        scripts/bench_configs.py calls median_of_passes for its one-stream / two-stream columns: same warm-up, same
+        step count, same passes -- the two scripts cannot disagree by construction.)"""
+        w = args.warmup if warmup is None else warmup
+        vals = []
+        for rep in range(reps):
+            vals.append(steps * n_gpus / timed(sl, steps, w if rep == 0 else 0))
+        return float(np.median(vals)), vals
+
+    def ramp_events_pass(sl, steps):
+        """`steps` exposures with k_ramp's own HIP events on every RAMP_EVENTS_EVERY-th -> (exposures/s, ms per launch)."""
+        ctx.profile_select(["k_ramp"])
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        e = timed(sl, steps, args.warmup, events_every=RAMP_EVENTS_EVERY)
+        ctx.profile_enable(True)
+        pr = ctx.profile_get()["k_ramp"]
+        ctx.profile_enable(False)
+        ctx.profile_select(None)
+        return steps * n_gpus / e, pr["ms"] / max(pr["launches"], 1), pr["launches"]
+
+    ramp_variant = ctx.ramp_variant(slot_of(0))          # the instantiation `value` and `roofline` were measured on
+    use_box0, _, segs0 = ctx.debug_boxes(slot_of(0))
+
     if n_gpus == 1 and not args.no_extra_pass:
-        n_x = min(args.steps, 30)
-        out_mb = (eng.R + 1) * eng.S * eng.S * 4 / 1e6
-
-        def rate(sl, steps=n_x):
-            return steps / timed(sl, steps, args.warmup)
-
+        # (0) k_ramp with its calibration planes EVICTED between launches.  Every launch re-reads the same 159 MB of
+        # dark / pixel-flat / sky / linearity planes, which fit the 256 MB Infinity Cache, and FETCH_SIZE counts hits
+        # there (MI355X_MICROARCH.md:297-309): the warm figure above may be a fraction of a more generous ceiling than
+        # HBM's.  Here a 1 GiB fill runs on the stream between an exposure's thrower and its k_ramp (outside the
+        # kernel's own start / stop events): same kernel, same bytes, cold planes.
+        try:
+            ext = torch.cuda.ExternalStream(ctx.stream)        # streams[0]: the stream of every even slot
+            scrub = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % device)
+            ctx.profile_select(["k_ramp"])
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            n_cold = min(args.steps, 24)
+            for j in range(n_cold):
+                ctx.run_front(slot_of(j))
+                with torch.cuda.stream(ext):
+                    scrub.fill_(j & 0xFF)
+                ctx.run_back(slot_of(j))
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            pr = ctx.profile_get()["k_ramp"]
+            ctx.profile_enable(False)
+            ctx.profile_select(None)
+            del scrub
+            extras["ramp_cold"] = {"ms_per_launch": pr["ms"] / max(pr["launches"], 1), "launches_timed": pr["launches"],
+                                   "evicted_by": "1 GiB device fill on the kernel's stream before every launch"}
+        except Exception as e:                               # (a measurement, not the product: say so and go on)
+            extras["ramp_cold"] = {"error": repr(e)}
         # (1) exposures alternating over the context's two HIP streams (prep / ramp of one under the thrower of the next)
         if args.streams == 1:
             upload_all(1, out_dtype, rng_mode)
-            extras["two_streams"] = {"value": rate(lambda j: j % n_res), "unit": "exposures/s",
-                                     "note": "same exposures alternating over two HIP streams"}
-        # (2) float64 reads, the reference's SCI dtype (exposure.py:133-214)
+            n_two = max(args.steps, 40)
+            med, vals = median_rate(lambda j: j % n_res, n_two, warmup=4)
+            extras["two_streams"] = {"value": med, "unit": "exposures/s", "repetitions": vals, "steps_each": n_two,
+                                     "note": "same exposures alternating over two HIP streams; median of 3 passes of %d "
+                                             "after 4 warm-up exposures (bench.timed_pass: the function "
+                                             "scripts/bench_configs.py uses too)" % n_two}
+        # (2) float64 reads, the reference's SCI dtype (exposure.py:133-214) -- a different k_ramp instantiation (fp64
+        # cumulative sum, 8-byte stores) with a roofline block of its own
         if not args.out_f64:
             upload_all(2, np.float64, rng_mode)
-            extras["out_f64"] = {"value": rate(slot_of), "unit": "exposures/s",
+            v64, ms64, n64 = ramp_events_pass(slot_of, n_x)
+            rb64 = ramp_bytes(eng.N, eng.S, eng.R, 8, int(segs0.sum()) if use_box0 else None)
+            extras["out_f64"] = {"value": v64, "unit": "exposures/s",
                                  "note": "float64 reads (%.0f MB written per exposure instead of %.0f), one stream" % (
-                                     2 * out_mb, out_mb)}
+                                     2 * out_mb, out_mb),
+                                 "roofline": {"bound": "hbm", "kernel": ctx.ramp_variant(slot_of(0)),
+                                              "achieved": rb64 / (ms64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": rb64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                              "bytes_per_launch": rb64, "ms_per_launch": ms64, "launches_timed": n64}}
         # (3) every electron thrown one by one, as the reference does (pyparallel_menu.c:87-108)
         if args.thrower == "split":
             upload_all(2, np.float32, _lib.RNG_PHILOX)
-            extras["per_electron"] = {"value": rate(slot_of), "unit": "exposures/s",
+            extras["per_electron"] = {"value": n_x / timed(slot_of, n_x, args.warmup), "unit": "exposures/s",
                                       "note": "rng_mode PHILOX: all %.3g electrons thrown individually, f32 reads, "
                                               "one stream" % (prof["electrons"] / max(n_break, 1))}
             upload_all(2, np.float64, _lib.RNG_PHILOX)
-            extras["per_electron_f64"] = {"value": rate(slot_of), "unit": "exposures/s",
+            extras["per_electron_f64"] = {"value": n_x / timed(slot_of, n_x, args.warmup), "unit": "exposures/s",
                                           "note": "every electron thrown AND float64 reads: the reference's arithmetic "
                                                   "shape, one stream"}
             # (3b) the bit-exact mode: glibc rand_r streams + the reference's OpenMP partition replayed on the device,
             # fp64 Box-Muller and positions -- the thrower whose frames equal the reference C's bit for bit
             # (tests/test_psf_gpu.py, tests/golden/psf_*.npz) -- with float64 reads
             upload_all(2, np.float64, _lib.RNG_REPLAY)
-            extras["replay_bit_exact"] = {"value": rate(slot_of, min(n_x, 10)), "unit": "exposures/s",
+            n_rep = min(n_x, 10)
+            extras["replay_bit_exact"] = {"value": n_rep / timed(slot_of, n_rep, args.warmup), "unit": "exposures/s",
                                           "note": "rng_mode REPLAY (threads_compat 2): the thrower that reproduces the "
                                                   "reference's frames bit for bit, float64 reads, one stream"}
-        # (4) delivered: reads of resident exposures copied to pinned host memory through the VisitRunner pipeline
-        # (4 slots in rotation over both streams, device-to-host copies on the copy stream)
-        runner = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32)
-        upload_all(1, np.float32, _lib.RNG_SPLIT)
-        n_d = max(2 * n_x, 40)
-        runner.run_resident(8)                       # warm-up: pinned buffers are allocated on first use
 
-        def best_of(fn, reps=3):
-            rates = []
+    if not args.no_extra_pass:
+        # (4) + (5): SURVEY 8(d)'s second leg, at EVERY N -- each rank drains its own GPU through its own pinned buffers
+        # and PCIe root; a pass is bracketed by barrier + synchronise and timed by the slowest rank, every rank's own
+        # rate is listed beside it (the host side -- NUMA, thread pools, eight ranks' copies -- is the only place this
+        # path can fail to scale: observation.py:396-413 is the reference's axis)
+        n_d = max(2 * n_x, 40)
+
+        def host_leg(fn, reps=3):
+            vals, own = [], []
             for _ in range(reps):
                 sync_all()
                 t = time.perf_counter()
                 fn()
-                rates.append(n_d / (time.perf_counter() - t))
-            return float(np.median(rates)), rates
+                dt_own = time.perf_counter() - t
+                own.append(n_d / dt_own)
+                dt_max = dt_own
+                if dist is not None:
+                    tt = torch.tensor([dt_own], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt_max = float(tt.item())
+                vals.append(n_d * n_gpus / dt_max)
+            per = {0: own}
+            if dist is not None:
+                got_ = [None] * world
+                dist.all_gather_object(got_, (rank, own))
+                per = {r_: o_ for r_, o_ in got_}
+            med = float(np.median(vals))
+            return {"value": med, "unit": "exposures/s", "GB_per_s": med * out_mb / 1e3,
+                    "frac_of_pcie": med * out_mb / 1e3 / (PCIE_GBS * n_gpus), "repetitions": vals,
+                    "ranks_reported": len(per),
+                    "per_rank_exposures_s": {str(r_): [round(x, 1) for x in per[r_]] for r_ in sorted(per)}}
 
-        med, rates = best_of(lambda: runner.run_resident(n_d))
-        extras["delivered"] = {"value": med, "unit": "exposures/s", "GB_per_s": med * out_mb / 1e3,
-                               "frac_of_pcie": med * out_mb / 1e3 / PCIE_GBS, "repetitions": rates,
-                               "note": "device-resident descriptors; reads copied to pinned host memory (PCIe-inclusive; "
-                                       "%.1f MB per exposure), VisitRunner pipeline, median of 3 passes of %d" % (out_mb, n_d)}
-        # (5) end to end: descriptor build + upload + kernels + fetch per exposure, light curves on the device
+        # delivered: reads of resident exposures copied to pinned host memory through the VisitRunner pipeline
+        # (4 slots in rotation over both streams, device-to-host copies on the slots' own streams)
+        runner = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32)
+        upload_all(1, np.float32, _lib.RNG_SPLIT)
+        runner.run_resident(8)                       # warm-up: pinned buffers are allocated on first use
+        extras["delivered"] = host_leg(lambda: runner.run_resident(n_d))
+        extras["delivered"]["note"] = ("device-resident descriptors; reads copied to pinned host memory (PCIe-inclusive; "
+                                       "%.1f MB per exposure), VisitRunner pipeline on every rank, median of 3 passes of %d "
+                                       "per rank, each timed by the slowest rank" % (out_mb, n_d))
+        # end to end: descriptor build + upload + kernels + fetch per exposure, light curves on the device
         runner_lc = wvisit.VisitRunner(visit, device=device, out_dtype=np.float32, device_lc=True)
-        runner_lc.run([i % visit.n_exposures for i in range(8)])
-        idx = [i % visit.n_exposures for i in range(n_d)]
-        med, rates = best_of(lambda: runner_lc.run(idx))
-        extras["end_to_end"] = {"value": med, "unit": "exposures/s", "GB_per_s": med * out_mb / 1e3,
-                                "frac_of_pcie": med * out_mb / 1e3 / PCIE_GBS, "repetitions": rates,
-                                "note": "per exposure: host descriptor (K-vectors) -> upload -> k_lightcurve + all kernels -> "
+        mine = [(rank + j * n_gpus) % visit.n_exposures for j in range(n_d)]          # this rank's round-robin share
+        runner_lc.run(mine[:8])
+        extras["end_to_end"] = host_leg(lambda: runner_lc.run(mine))
+        extras["end_to_end"]["note"] = ("per exposure: host descriptor (K-vectors) -> upload -> k_lightcurve + all kernels -> "
                                         "reads in pinned host memory; VisitRunner, device light curves (no K x W upload), "
-                                        "median of 3 passes of %d" % n_d}
+                                        "median of 3 passes of %d per rank, each timed by the slowest rank" % n_d)
 
+    if n_gpus == 1 and not args.no_extra_pass:
         # (6) the inner drop-in boundary by itself: wayne_psf_apply (= pyparallel.apply_psf, pyparallel.pyx:14-38) for one
         # sub-sample of this workload -- host arrays in, the frame out, replay mode (the reference's frame bit for bit)
         if rank == 0:
@@ -481,7 +597,7 @@ def main():
         ob = 8 if args.out_f64 else 4
         launches = max(prof["k_ramp"]["launches"], 1)
         ramp_ms = prof["k_ramp"]["ms"] / launches
-        use_box, _, segs = ctx.debug_boxes(slot_of(0))
+        use_box, segs = use_box0, segs0          # (of the timed region's slots: later passes re-upload them)
         rb = ramp_bytes(N, S, R, ob, int(segs.sum()) if use_box else None)
         rb_all = ramp_bytes(N, S, R, ob)
         achieved = rb / (ramp_ms * 1e-3) / 1e9
@@ -500,8 +616,7 @@ def main():
             "value": args.steps * n_gpus / elapsed, "unit": "exposures/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 ramp arithmetic, f32 thrower, int32/int64 accumulation; %s reads" % (
-                "f64" if args.out_f64 else "f32"),
+            "dtype": dtype_label(ramp_variant, args.out_f64),
             "data": "synthetic",
             "ranks_reported": ranks_reported,
             "repetitions": {"n": REPS, "steps_each": args.steps, "values": [args.steps * n_gpus / e for e in reps],
@@ -520,15 +635,21 @@ def main():
                                        "split (wide component per electron, narrow component multinomial)"
                                        if args.thrower == "split" else "per-electron"),
                        "exposures_per_rank": args.steps, "sharding": "round-robin exposures, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_ramp", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": ramp_variant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": rb, "ms_per_launch": ramp_ms,
                          "accumulator_segments_loaded": int(segs.sum()) if use_box else None,
                          "bytes_per_launch_loading_every_accumulator": rb_all,
                          "achieved_loading_every_accumulator": rb_all / (ramp_ms * 1e-3) / 1e9,
-                         "note": "bytes_per_launch counts the int64 accumulators only where the kernel loads them (the "
-                                 "per-read boxes of the thrower's reach); the r01/r02 kernel loaded all of them: that "
-                                 "byte count and the GB/s it would give are listed beside it, not used for `frac`",
+                         "note": "frac = algorithmic bytes / the kernel's own duration in the TIMED REGION, i.e. in the "
+                                 "steady state of whole exposures on one stream: the 159 MB of calibration planes every "
+                                 "launch re-reads (dark SCI / ERR, pixel flat, sky, linearity) may then be served by the "
+                                 "256 MB Infinity Cache rather than HBM -- `cold_cache` is the same kernel timed with those "
+                                 "planes evicted before every launch (1 GiB fill on its stream), same bytes: the "
+                                 "fraction of the 8 TB/s roof that is certainly HBM.  bytes_per_launch counts the int64 "
+                                 "accumulators only where the kernel loads them (the per-read boxes of the thrower's "
+                                 "reach); the r01/r02 kernel loaded all of them: that byte count and the GB/s it would "
+                                 "give are listed beside it, not used for `frac`",
                          "launches_timed": prof_ramp["k_ramp"]["launches"],
                          "timing": "HIP events on the kernel's own stream, every %d-th launch of the timed region" % RAMP_EVENTS_EVERY,
                          "survey_formula_bytes_per_exposure": sb,
@@ -541,6 +662,12 @@ def main():
                         if forked else "k_throw + k_lane (one interval), then k_narrow, on one stream"},
         }
         line["sustained"] = sustained
+        cold = extras.pop("ramp_cold", None)
+        if cold and "ms_per_launch" in cold and cold["ms_per_launch"] > 0:
+            cold["achieved"] = rb / (cold["ms_per_launch"] * 1e-3) / 1e9
+            cold["frac"] = cold["achieved"] / HBM_PEAK_GBS
+            cold["warm_over_cold"] = ramp_ms / cold["ms_per_launch"]
+        line["roofline"]["cold_cache"] = cold
         line.update(extras)
         # numbers that only a rocprofv3 --pmc run can give come from profiles/*.json, which
         # scripts/collect_profiles.sh stamps with the hash of wayne_amd/csrc they were measured on: quoted only

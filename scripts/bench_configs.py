@@ -11,13 +11,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench  # noqa: E402   (timed_pass / median_of_passes: one way of timing a pass for both scripts)
 from wayne_amd import calibration, detector, engine, grism, synthetic, visit  # noqa: E402
 from wayne_amd.exposure_generator import ExposureGenerator  # noqa: E402
 
 cal = calibration.CalibrationSet.synthetic(11)
 det = detector.WFC3_IR()
 out = {}
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2     # 2 = split thrower (default), 1 = every electron
 for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     gr = grism.G141(cal) if synthetic.CONFIGS[name]["grism"] == "G141" else grism.G102(cal)
@@ -27,17 +28,9 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     for j in range(n + 2):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
         ctx.upload(2 * j, eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(j)))
-    for j in range(2):
-        ctx.run(2 * j)
-    ctx.synchronize()
-    dts = []
-    for rep in range(3):                  # (median of three passes: a single pass of 20 is off by 10 % now and then)
-        t0 = time.perf_counter()
-        for j in range(2, n + 2):
-            ctx.run(2 * j)
-        ctx.synchronize()
-        dts.append(time.perf_counter() - t0)
-    dt = sorted(dts)[1]
+    # (median of three passes of n after 4 warm-up exposures: bench.median_of_passes, as bench.py's two_streams)
+    rate_one, _ = bench.median_of_passes(ctx, lambda j: 2 * (j % (n + 2)), n, reps=3, warmup=4)
+    dt = n / rate_one
     # kernel times from a second pass (HIP events around every kernel cost a few per cent of throughput)
     ctx.profile_enable(True)
     ctx.profile_reset()
@@ -49,17 +42,8 @@ for name in ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_g102"]:
     for j in range(n + 2):
         eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed, exposure_index=j)
         ctx.upload(j, eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(j)))
-    for j in range(2):
-        ctx.run(j)
-    ctx.synchronize()
-    dts = []
-    for rep in range(3):
-        t0 = time.perf_counter()
-        for j in range(2, n + 2):
-            ctx.run(j)
-        ctx.synchronize()
-        dts.append(time.perf_counter() - t0)
-    dt_two = sorted(dts)[1]
+    rate_two, _ = bench.median_of_passes(ctx, lambda j: j % (n + 2), n, reps=3, warmup=4)
+    dt_two = n / rate_two
     # end to end: the visit runner (host prep + upload + kernels + copy to pinned host memory), device light curves
     runner = visit.VisitRunner(v, 0, frame_overrides={}, device_lc=True)
     runner.rng_mode = mode

@@ -1,0 +1,164 @@
+"""Extreme-value checks for the stochastic stages: the LARGEST single-pixel deviation against the exact law's tail.
+
+Why: for three rounds a sky draw whose uniform fell into the rounding residue of its float32 cdf walked
+512 steps -- ~500 spurious electrons in ONE pixel per exposure.  Same-counter parity could not see it (the oracle shared
+the flaw) and moment tests could not either: a dispersion index over 10^6 pixels gains 5e3 from such a pixel, its 6 sigma
+band is 8.5e3.  A sum over pixels is blind to one pixel; a maximum is not.
+
+Every check turns a draw x_i with exactly known law F_i into its tail probabilities
+    u_hi = P(X > x_i) + V P(X = x_i),      u_lo = P(X < x_i) + (1 - V) P(X = x_i),        V ~ U(0, 1)
+(the randomised probability integral transform: exactly uniform on (0, 1) under the law, for discrete laws too) and asks
+
+  * family-wise: min_i u >= alpha / n -- the largest deviation of n draws is one the law produces (probability of a
+    false alarm <= alpha per tail, whatever the dependence between draws);
+  * tail frequencies: #(u < q) ~ Binomial(n, q) for q = 1e-4, 1e-5, 1e-6 -- the tail is neither too heavy nor CUT OFF
+    (a capped search, a table that ends too early, a normal generator that never leaves 5 sigma).
+
+Only candidates (|z| beyond a prefilter) need their exact tail; all others provably have u > the largest q.
+Laws: Poisson (sky: exposure_generator.py:488-495; stellar counts: :625-628), normal (dark current, read noise:
+detector.py:185-198), Poisson / gain + normal (a whole read of the background), and -- as a conservative bound -- a sum
+of independent Bernoullis (a pixel's electron count from the thrower, pyparallel_menu.c:87-108) bounded by the Poisson
+law of the same mean (Hoeffding 1956; Anderson & Samuels 1967: both tails of the Poisson law are the heavier).
+"""
+import numpy as np
+from scipy import special, stats
+
+QS = (1e-4, 1e-5, 1e-6)
+
+
+class Tails(object):
+    """u_hi / u_lo of the candidates of n draws (all other draws have u above `floor`)."""
+
+    def __init__(self, n, u_hi, u_lo, floor, where_hi=None, where_lo=None):
+        self.n, self.u_hi, self.u_lo, self.floor = int(n), np.asarray(u_hi), np.asarray(u_lo), float(floor)
+        self.where_hi, self.where_lo = where_hi, where_lo
+
+    def merged(self, other):
+        return Tails(self.n + other.n, np.concatenate([self.u_hi, other.u_hi]), np.concatenate([self.u_lo, other.u_lo]),
+                     min(self.floor, other.floor))
+
+
+def poisson_tails(k, lam, rng, z_pre=2.5):
+    """Randomised tail probabilities of counts k under Poisson(lam), elementwise.  Entries with lam <= 0 must hold 0."""
+    k = np.asarray(k, dtype=np.float64).ravel()
+    lam = np.asarray(lam, dtype=np.float64).ravel()
+    assert k.shape == lam.shape
+    dead = ~(lam > 0)
+    if dead.any():
+        assert not k[dead].any(), "counts where the rate is zero"
+    live = ~dead
+    z = np.zeros_like(k)
+    z[live] = (k[live] - lam[live]) / np.sqrt(lam[live])
+    # candidates: z beyond the prefilter -- and EVERY draw at a rate so small that z says little (at lam << 1 the
+    # randomised u of a zero count is spread over (lam, 1): those draws carry the tail frequencies)
+    hi = live & ((z > z_pre) | (lam < 4.0))
+    lo = live & ((z < -z_pre) | (lam < 4.0))
+    v = rng.random(k.size)
+    u_hi = stats.poisson.sf(k[hi], lam[hi]) + v[hi] * stats.poisson.pmf(k[hi], lam[hi])
+    u_lo = stats.poisson.cdf(k[lo] - 1, lam[lo]) + (1.0 - v[lo]) * stats.poisson.pmf(k[lo], lam[lo])
+    # non-candidates (lam >= 4, |z| <= 2.5): P(K > k) >= 3e-3 (the Poisson upper tail is heavier than the normal one,
+    # 6e-3 there) and P(K < k) >= 1.5e-3 (lam = 10: k = 3, cdf(2) = 2.8e-3; lam = 100: cdf(74) = 3.7e-3; lam = 4..6: no
+    # count lies below -2.5 sigma at all): every u below 1e-3 is among the candidates
+    floor = 1e-3
+    return Tails(int(live.sum()), u_hi, u_lo, floor, np.nonzero(hi)[0], np.nonzero(lo)[0])
+
+
+def normal_tails(x, mean, sigma, z_pre=3.0):
+    x = np.asarray(x, dtype=np.float64).ravel()
+    z = (x - np.asarray(mean, dtype=np.float64).ravel()) / np.asarray(sigma, dtype=np.float64).ravel()
+    hi, lo = z > z_pre, z < -z_pre
+    return Tails(z.size, special.ndtr(-z[hi]), special.ndtr(z[lo]), float(stats.norm.sf(z_pre)), np.nonzero(hi)[0],
+                 np.nonzero(lo)[0])
+
+
+def poisson_plus_normal_tails(x, lam, gain, mean, sigma, z_pre=3.0):
+    """x = Poisson(lam) / gain + N(mean, sigma): exact tails by convolution, for the candidates."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    lam = np.broadcast_to(np.asarray(lam, dtype=np.float64), x.shape).ravel()
+    mean = np.broadcast_to(np.asarray(mean, dtype=np.float64), x.shape).ravel()
+    sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), x.shape).ravel()
+    mu = lam / gain + mean
+    sd = np.sqrt(lam / gain ** 2 + sigma ** 2)
+    z = (x - mu) / sd
+    out = []
+    for sel, upper in ((z > z_pre, True), (z < -z_pre, False)):
+        idx = np.nonzero(sel)[0]
+        u = np.empty(idx.size)
+        # group candidates by (rounded) rate: the Poisson support is shared within a group
+        for lo_ in range(0, idx.size, 4096):
+            j = idx[lo_:lo_ + 4096]
+            l_max = lam[j].max()
+            kk = np.arange(0, int(l_max + 14 * np.sqrt(l_max + 1) + 30))
+            pm = stats.poisson.pmf(kk[None, :], lam[j][:, None])
+            t = (x[j][:, None] - kk[None, :] / gain - mean[j][:, None]) / sigma[j][:, None]
+            tail = special.ndtr(-t) if upper else special.ndtr(t)
+            u[lo_:lo_ + 4096] = (pm * tail).sum(axis=1)
+        out.append((u, idx))
+    return Tails(x.size, out[0][0], out[1][0], float(stats.norm.sf(z_pre)) * 0.3, out[0][1], out[1][1])
+
+
+def bernoulli_sum_tails(k, mean, rng, z_pre=2.5):
+    """A count that is a sum of independent Bernoullis with total mean `mean` (a pixel's electrons from the thrower):
+    tails under Poisson(mean), which bound the true ones from above in both directions beyond mean +- 1 -- so a draw
+    the bound finds impossible IS impossible, while tail frequencies may only fall short (checked one-sidedly)."""
+    return poisson_tails(k, mean, rng, z_pre)
+
+
+def check(t, label, alpha=1e-3, qs=QS, exact_frequencies=True, dependence=1.0):
+    """-> list of failure statements (empty = pass) for one stage's Tails."""
+    bad = []
+    n = t.n
+    bound = alpha / max(n, 1)
+    for side, u in (("high", t.u_hi), ("low", t.u_lo)):
+        if u.size and u.min() < bound:
+            bad.append("%s: the most extreme %s draw of %d has tail probability %.2e (family-wise bound %.2e)" % (
+                label, side, n, u.min(), bound))
+        for q in qs:
+            if q >= t.floor:
+                continue
+            x = int((u < q).sum())
+            e = n * q
+            if e < 3:
+                continue
+            if exact_frequencies:
+                # two-sided binomial, widened for draws that are not independent (`dependence` = variance inflation)
+                sd = np.sqrt(e * dependence)
+                p = 2 * min(stats.norm.sf((x - e) / sd), stats.norm.cdf((x - e) / sd)) if dependence != 1.0 else \
+                    stats.binomtest(x, n, q).pvalue
+                if p < 1e-4:
+                    bad.append("%s: %d %s draws beyond the %.0e tail, expected %.1f" % (label, x, side, q, e))
+            elif x > e + 5 * np.sqrt(e) + 2:
+                bad.append("%s: %d %s draws beyond the (bounding) %.0e tail, at most %.1f expected" % (label, x, side, q, e))
+    return bad
+
+
+def summary(t):
+    out = {"n": t.n, "min_u_hi": float(t.u_hi.min()) if t.u_hi.size else None,
+           "min_u_lo": float(t.u_lo.min()) if t.u_lo.size else None, "family_bound": 1e-3 / max(t.n, 1)}
+    for q in QS:
+        out["hi<%.0e" % q] = int((t.u_hi < q).sum())
+        out["lo<%.0e" % q] = int((t.u_lo < q).sum())
+        out["expect<%.0e" % q] = t.n * q
+    return out
+
+
+def thrower_window_moments(counts, x, y, ratio, sl, sh, x0, x1, y0, y1):
+    """Exact mean of every pixel of the window [y0, y1) x [x0, x1) (frame coordinates) of the reference thrower's
+    frame for FIXED counts (the law of tests/ensemble_stats.analytic_moments, on a window instead of the whole frame:
+    pyparallel_menu.c:87-108).  -> (mean[y1-y0, x1-x0], expected electrons landing in the window)"""
+    counts = np.asarray(counts, dtype=np.float64)
+    n_wide = np.trunc(counts * ratio)
+    n_narrow = counts - n_wide
+    ex = np.arange(x0, x1 + 1, dtype=np.float64)
+    ey = np.arange(y0, y1 + 1, dtype=np.float64)
+
+    def axis(pos, sig, edges, first):
+        cdf = special.ndtr((edges[None, :] - pos[:, None]) / sig[:, None])
+        p = np.diff(cdf, axis=1)
+        if first <= 0:                       # row / column 0 (and anything negative) never receives an electron
+            p[:, :1 - first] = 0.0
+        return p
+
+    mean = (axis(y, sh, ey, y0) * n_wide[:, None]).T @ axis(x, sh, ex, x0)
+    mean += (axis(y, sl, ey, y0) * n_narrow[:, None]).T @ axis(x, sl, ex, x0)
+    return mean

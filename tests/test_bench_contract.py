@@ -46,6 +46,21 @@ def test_bench_line_has_the_contract_keys():
     assert 0 < d["end_to_end"]["frac_of_pcie"] < 1
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 1e8
     assert "traffic_source" in d["roofline"]
+    # the label says what was timed: the k_ramp instantiation the library reports for the timed slots
+    assert r["kernel"] == "k_ramp<float, true, 1, false, true>" and d["dtype"].startswith(r["kernel"])
+    assert "f64 ramp" not in d["dtype"] and "all-f32 per-read chain" in d["dtype"]
+    # float64 reads are another instantiation with a roofline block of its own (8-byte stores)
+    r64 = d["out_f64"]["roofline"]
+    assert r64["kernel"].startswith("k_ramp<double, true, 1, false") and r64["bytes_per_launch"] > r["bytes_per_launch"]
+    assert abs(r64["frac"] - r64["achieved"] / r64["peak"]) < 1e-9 and 0.1 < r64["frac"] < 1.0
+    # the same kernel with its calibration planes evicted before every launch: same bytes, never faster than warm
+    cold = r["cold_cache"]
+    assert cold["launches_timed"] >= 4 and cold["ms_per_launch"] > 0.8 * r["ms_per_launch"]
+    assert abs(cold["frac"] - cold["achieved"] / r["peak"]) < 1e-9 and 0.1 < cold["frac"] < 1.0
+    # SURVEY 8(d)'s second leg carries its rank accounting at every N
+    for key in ("delivered", "end_to_end"):
+        assert d[key]["ranks_reported"] == 1 and list(d[key]["per_rank_exposures_s"]) == ["0"]
+    assert len(d["two_streams"]["repetitions"]) == 3
 
 
 def test_launcher_refuses_a_rank_count_mismatch():
@@ -76,3 +91,43 @@ def test_launcher_starts_n_ranks_and_fails_loudly_without_gpus():
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0
     assert "rank exit codes" in out.stderr and "{" not in out.stdout
+
+
+def test_launcher_fails_fast_when_one_rank_dies_before_the_rendezvous():
+    # CPU: rank 1 of 4 exits with code 3 before init_process_group.  The launcher must end the other three -- which
+    # sit in a rendezvous that can no longer complete -- and report the failure at once, not after gloo's timeout
+    # (the first real SCALE run would otherwise be recorded as a kill at the driver's time limit)
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["WAYNE_DRY_RUN_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    dt = time.time() - t0
+    assert out.returncode != 0 and dt < 30.0, (out.returncode, dt)
+    assert "rank 1 exited with code 3" in out.stderr and "rank exit codes" in out.stderr
+    assert "{" not in out.stdout                        # no line that could be mistaken for a measurement
+
+
+def test_launch_ranks_reports_codes_and_kills_siblings(tmp_path):
+    # the launcher itself: a rank that fails late (after the others have finished) and one that fails while the others
+    # would run forever
+    import time
+    from wayne_amd import launch
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if r == 0: print('hello from rank 0', flush=True)\n"
+                      "if mode == 'ok': sys.exit(0)\n"
+                      "if mode == 'late': time.sleep(0.5 if r == 2 else 0.0); sys.exit(7 if r == 2 else 0)\n"
+                      "if r == 1: time.sleep(0.3); sys.exit(3)\n"
+                      "time.sleep(600)\n")
+    codes, out0 = launch.launch_ranks(3, [sys.executable, str(script), "ok"], capture_rank0=True)
+    assert codes == [0, 0, 0] and out0 == "hello from rank 0\n"
+    codes, _ = launch.launch_ranks(3, [sys.executable, str(script), "late"], capture_rank0=True)
+    assert codes == [0, 0, 7]
+    t0 = time.time()
+    codes, out0 = launch.launch_ranks(3, [sys.executable, str(script), "hang"], capture_rank0=True)
+    assert time.time() - t0 < 15.0
+    assert codes[1] == 3 and codes[0] < 0 and codes[2] < 0 and out0 == "hello from rank 0\n"

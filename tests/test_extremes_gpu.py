@@ -1,0 +1,284 @@
+"""GPU: extreme-value tests of every stochastic stage on FULL frames (cfg4 geometry: 1014^2, NSAMP 16) -- the largest
+single-pixel deviation and the tail frequencies of each stage against the exact law of the reference's statement.
+
+  sky            pixel += np.random.poisson(master_sky * bg_count)            exposure_generator.py:488-495
+  dark, read     N(px + dark, max(err, 1e-5)); N(px, 14.1 / 2.35)             detector.py:185-198, exposure.py:61-80
+  stellar        np.random.poisson(counts) per (bin, sub-sample)              exposure_generator.py:625-628
+  thrower        electrons scattered over pixels                             pyparallel_menu.c:87-108
+
+VERDICT r04 item 1: for three rounds one sky draw per exposure walked its search to the cap -- ~500 spurious electrons in
+one pixel -- and every moment test in the suite was blind to it (tests/test_extremes_cpu.py shows the checkers used here
+catch it, and that the old dispersion index does not).  The instantiations tested are the production ones: the timed
+`k_ramp<float, true, 1, false, true>` (all detector switches on), its run-time-flag sibling `<..., false>` for the stages
+in isolation, `k_prep_sub`'s Poisson draws, `k_lane` + `k_narrow`.  A negative control rebuilds the library with the
+old, unbounded search (-DWAYNE_NEGCTL_SKY_RUNAWAY) and shows the sky test FAIL on it.
+
+The measured figures go to gpurun_out/extremes.json (committed copy under profiles/).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import extreme_stats as xs
+import helpers
+from oracle import wayne_oracle as wo
+from wayne_amd import _lib, calibration, detector, engine, grism, synthetic
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "extremes.json")
+GAIN = 2.35
+READ_SIGMA = 14.1 / 2.35
+PROD_ALLON = "k_ramp<float, true, 1, false, true>"
+PROD_FLAGS = "k_ramp<float, true, 1, false, false>"
+
+STAR_OFF = dict(scale_factor=1e-9, cosmic_rate=None, add_stellar_noise=False)
+ONLY_SKY = dict(STAR_OFF, add_dark=False, add_read_noise=False, add_non_linear=False, clip_values_det_limits=False,
+                add_gain_variations=False, add_flat=False, add_initial_bias=False)
+
+
+def report(key, **figures):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        d = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        d[key] = figures
+        json.dump(d, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+_plain = {}
+
+
+def plain_visit(n_exposures):
+    """cfg4 over a calibration set whose non-linearity is the identity (c1..c4 = 0) and whose gain is the constant 2.35
+    (pixel flat = 1): every detector SWITCH stays on -- the ALLON instantiation runs -- while a read of the background is
+    exactly Poisson(sky) / 2.35 + N(dark, err) + N(0, 14.1 / 2.35)."""
+    if "cal" not in _plain:
+        cal = calibration.CalibrationSet.synthetic(11)
+        cal.lin[:] = 0.0
+        cal.pfl[:] = 1.0
+        _plain["cal"] = cal
+    cal = _plain["cal"]
+    return synthetic.Visit("cfg4", detector.WFC3_IR(), grism.G141(cal), cal, n_exposures=n_exposures)
+
+
+def run_exposure(v, i, want_variant, out_dtype=np.float32, **over):
+    pg = helpers.product_generator(v, i)
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    desc = pg.build_descriptor(eng, out_dtype=out_dtype, **v.frame_kwargs(i, **over))
+    eng.ctx.upload(0, desc)
+    assert eng.ctx.ramp_variant(0) == want_variant
+    eng.ctx.run(0)
+    return eng.ctx.download(0).astype(np.float64)
+
+
+def sky_rates(v, sky_ct_s):
+    """lam[r][y, x] of the interior pixels, in the float32 arithmetic of the reference (master_sky *= bg_count is an
+    in-place float32 multiply, :489-493) and of the kernel."""
+    sky = v.calibration.sky[v.grism.name].astype(np.float32)            # 1014 x 1014: the full array needs no crop
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    return [(sky * np.float32(sky_ct_s * d)).astype(np.float64) for d in dt]
+
+
+def sky_only_tails(v, n_exposures, rng, first=0):
+    t = None
+    k_max = 0
+    for i in range(first, first + n_exposures):
+        reads = run_exposure(v, i, PROD_FLAGS, sky_background=5.0, **ONLY_SKY)
+        assert not reads[0].any() and not reads[:, :5, :].any() and not reads[:, :, -5:].any()
+        lam = sky_rates(v, 5.0)
+        e = np.rint(reads[:, 5:-5, 5:-5] * GAIN)                           # cumulative electrons: integers
+        assert np.abs(reads[:, 5:-5, 5:-5] * GAIN - e).max() < 2e-3
+        for r in range(1, reads.shape[0]):
+            k = e[r] - e[r - 1]
+            assert k.min() >= 0
+            k_max = max(k_max, float((k - lam[r - 1]).max()))
+            tr = xs.poisson_tails(k, lam[r - 1], rng)
+            t = tr if t is None else t.merged(tr)
+    return t, k_max
+
+
+def test_sky_draws_largest_deviation_and_tail_frequencies():
+    # production math (alias tables + integer-threshold remainder, hardware exp), nothing else switched on: every count of
+    # every read interval of every pixel is an integer with a known Poisson law
+    v = helpers.make_visit("cfg4", n_exposures=4)
+    rng = np.random.default_rng(1)
+    t, k_max = sky_only_tails(v, 4, rng)
+    s = xs.summary(t)
+    report("sky/production_math", largest_excess_electrons=k_max, **s)
+    assert t.n == 4 * 15 * 1014 * 1014
+    bad = xs.check(t, "sky")
+    assert not bad, "; ".join(bad) + "\n%r" % s
+    assert k_max < 60.0            # electrons above the mean, at rates of 14-50 per interval: the runaway was +500
+
+
+def background_law(v, sky_ct_s):
+    """Per read r = 1..R of a pixel of the bordered frame: (lam_cum, dark mean, normal sigma)."""
+    S = v.detector.full_size(v.SUBARRAY)
+    lam = sky_rates(v, sky_ct_s)
+    sci, err = v.calibration.dark_frames(v.SUBARRAY, v.SAMPSEQ, v.read_times)
+    err = np.where(err > 0, err, np.float32(1e-5)).astype(np.float64)
+    interior = np.zeros((S, S), dtype=bool)
+    interior[5:-5, 5:-5] = True
+    out, cum = [], np.zeros((S, S))
+    for r in range(len(lam)):
+        cum = cum.copy()
+        cum[5:-5, 5:-5] += lam[r]
+        mean = np.where(interior, sci[r].astype(np.float64), 0.0)
+        sig = np.where(interior, np.sqrt(err[r] ** 2 + READ_SIGMA ** 2), READ_SIGMA)
+        out.append((cum, mean, sig))
+    return out
+
+
+def test_dark_and_read_noise_normals_in_the_benchmarked_instantiation():
+    # k_ramp<float, true, 1, false, true> with the star and (practically) the sky switched off: every read of every pixel
+    # is an independent normal -- N(dark_r, err_r) + N(0, 14.1 / 2.35) inside, the read noise alone in the reference
+    # pixels and the zero read (detector.py:185-198; exposure.py:61-68, 122-131).  Hardware log2 / sqrt / sin / cos.
+    v = plain_visit(3)
+    law = background_law(v, 1e-7)
+    t = None
+    worst = 0.0
+    for i in range(3):
+        reads = run_exposure(v, i, PROD_ALLON, sky_background=1e-7, **STAR_OFF)
+        t0 = xs.normal_tails(reads[0], 0.0, READ_SIGMA)
+        t = t0 if t is None else t.merged(t0)
+        worst = max(worst, float(np.abs(reads[0]).max() / READ_SIGMA))
+        for r, (_, mean, sig) in enumerate(law):
+            tr = xs.normal_tails(reads[r + 1], mean, sig)
+            t = t.merged(tr)
+            worst = max(worst, float((np.abs(reads[r + 1] - mean) / sig).max()))
+    s = xs.summary(t)
+    report("normals/allon", largest_abs_z=worst, **s)
+    assert t.n == 3 * 16 * 1024 * 1024
+    bad = xs.check(t, "dark + read noise")
+    assert not bad, "; ".join(bad) + "\n%r" % s
+    # Box-Muller from a uniform >= 2^-33: nothing beyond 6.77 sigma of either normal, and the tail is not cut short
+    assert 5.0 < worst < 7.0
+
+
+def test_background_reads_of_the_benchmarked_instantiation():
+    # ... and with the sky on (5 e-/s): a read is Poisson(cumulative sky) / 2.35 + the two normals; sky words and normals
+    # come from ONE stream per pixel in the production layout (STAGE_READ).  Exact tails by convolution for the
+    # candidates; reads of a pixel share their cumulative sky, so the frequency bands allow for that dependence
+    v = plain_visit(3)
+    law = background_law(v, 5.0)
+    t = None
+    excess = 0.0
+    for i in range(3):
+        reads = run_exposure(v, i, PROD_ALLON, sky_background=5.0, **STAR_OFF)
+        for r, (cum, mean, sig) in enumerate(law):
+            tr = xs.poisson_plus_normal_tails(reads[r + 1], cum, GAIN, mean, sig)
+            t = tr if t is None else t.merged(tr)
+            excess = max(excess, float((reads[r + 1] - cum / GAIN - mean).max()))
+    s = xs.summary(t)
+    report("background/allon", largest_excess_dn=excess, **s)
+    bad = xs.check(t, "background read", dependence=4.0)
+    assert not bad, "; ".join(bad) + "\n%r" % s
+    assert excess < 110.0          # DN above the mean on a sigma of <= 13 DN; one runaway draw is +213 DN in every later read
+
+
+def test_stellar_counts_largest_deviation_and_tail_frequencies():
+    # k_prep_sub's Poisson draw per (bin, sub-sample) -- fp64 PTRS behind an fp32 squeeze from a mean of 10, inversion
+    # below -- at the benchmarked size (128 x 4494 bins per exposure), against the oracle's counts chain
+    # (exposure_generator.py:602-628)
+    v = helpers.make_visit("cfg4", n_exposures=6)
+    eo = helpers.oracle_generator(v)
+    gr = eo.grism
+    i0, i1 = wo.crop_spectrum_ind(gr.wl_limits[0], gr.wl_limits[1], v.wl.copy())
+    s_wl = v.wl[i0:i1]
+    gr.set_current_wavelength_only_dependent_array(s_wl)
+    rng = np.random.default_rng(2)
+    t = None
+    for i in range(6):
+        # a dimmer star in every other exposure: the edges of the spectrum then fall below a mean of 10 (the inversion sampler)
+        scale = v.scale_factor(i) * (1.0 if i % 2 == 0 else 3e-3)
+        rec = {}
+        pg = helpers.product_generator(v, i)
+        kw = v.frame_kwargs(i, scale_factor=scale, cosmic_rate=None)
+        pg.scanning_frame(out_dtype=np.float32, record=rec, **kw)
+        lam = np.stack([eo.counts_before_noise(s_wl, kw["stellar_flux"][i0:i1] * (1.0 - kw["planet_signal"][k][i0:i1]),
+                                               rec["dur"][k], scale) for k in range(v.K)])
+        assert rec["counts"].shape == lam.shape == (128, 4494)
+        tr = xs.poisson_tails(rec["counts"], lam, rng)
+        t = tr if t is None else t.merged(tr)
+    s = xs.summary(t)
+    report("stellar/k_prep_sub", **s)
+    assert t.n == 6 * 128 * 4494
+    bad = xs.check(t, "stellar counts")
+    assert not bad, "; ".join(bad) + "\n%r" % s
+
+
+def test_thrower_largest_single_pixel_deviation_at_full_size():
+    # k_lane + k_narrow on the benchmarked exposure (10^9 electrons): every accumulator of every read interval against
+    # the exact mean of the reference's law for the counts and positions the device itself reports (flat off: integer
+    # electrons).  A pixel's count is a sum of independent Bernoullis, bounded in both tails by the Poisson law of its
+    # mean: no accumulator may hold a count that bound finds impossible, and none may be touched outside the window.
+    v = helpers.make_visit("cfg4", n_exposures=2)
+    g = v.grism
+    i0, i1 = wo.crop_spectrum_ind(g.wl_limits[0], g.wl_limits[1], v.wl.copy())
+    s_wl = v.wl[i0:i1]
+    ratio, sl, sh = (np.polyval(p.coeffs, s_wl) for p in (g.psf_ratio_poly, g.psf_sigmal_poly, g.psf_sigmah_poly))
+    rng = np.random.default_rng(3)
+    t = None
+    worst_excess = 0.0
+    for i in range(2):
+        rec = {}
+        pg = helpers.product_generator(v, i)
+        pg.scanning_frame(out_dtype=np.float32, record=rec, **v.frame_kwargs(i, add_flat=False, cosmic_rate=None))
+        acc, counts, x, y, read_of = rec["acc"], rec["counts"].astype(np.float64), rec["x"], rec["y"], rec["read"]
+        assert np.abs(acc - np.rint(acc)).max() < 1e-6
+        S = acc.shape[1]
+        total = 0.0
+        for r in range(acc.shape[0]):
+            ks = np.nonzero(read_of == r)[0]
+            # window: the trace of the interval's sub-samples +- 48 px (6.9 sigma_h + a few), frame coordinates
+            x0, x1 = int(np.floor(x[ks].min())) - 48, int(np.floor(x[ks].max())) + 49
+            y0, y1 = int(np.floor(y[ks].min())) - 48, int(np.floor(y[ks].max())) + 49
+            x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, S - 10), min(y1, S - 10)
+            mean = np.zeros((y1 - y0, x1 - x0))
+            for k in ks:
+                mean += xs.thrower_window_moments(counts[k], x[k], y[k], ratio, sl, sh, x0, x1, y0, y1)
+            got = acc[r][5 + y0:5 + y1, 5 + x0:5 + x1]
+            outside = acc[r].sum() - got.sum()
+            assert outside == 0.0, "read %d: %g electrons outside the +-48 px window" % (r, outside)
+            total += got.sum()
+            live = mean > 1e-9
+            assert not got[~live].any()
+            tr = xs.bernoulli_sum_tails(got[live], mean[live], rng)
+            t = tr if t is None else t.merged(tr)
+            worst_excess = max(worst_excess, float(((got - mean) / np.sqrt(mean + 1.0)).max()))
+        assert abs(total - counts.sum()) <= 1e-6 * counts.sum()                 # (the spectrum sits well inside the frame)
+    s = xs.summary(t)
+    report("thrower/cfg4", largest_excess_sigma=worst_excess, **s)
+    bad = xs.check(t, "thrower", exact_frequencies=False)
+    assert not bad, "; ".join(bad) + "\n%r" % s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# negative control: the library with the unbounded search of rounds 1-3
+# ---------------------------------------------------------------------------------------------------------------
+def test_negative_control_the_unbounded_sky_search_is_caught():
+    # the same sky test in a child process whose libwayne_hip.so is the negative-control build: it must report draws no
+    # Poisson law produces (the runaway walks to 512: several hundred electrons in a pixel whose mean is 14-50)
+    from wayne_amd import build as wb
+    lib = wb.build_negctl_sky()          # (hipcc -DWAYNE_NEGCTL_SKY_RUNAWAY; prebuilt by __graft_entry__.build())
+    code = ("import sys, json, numpy as np\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers, extreme_stats as xs, test_extremes_gpu as t\n"
+            "v = helpers.make_visit('cfg4', n_exposures=8)\n"
+            "tails, k_max = t.sky_only_tails(v, 8, np.random.default_rng(1))\n"
+            "print(json.dumps({'bad': xs.check(tails, 'sky'), 'k_max': k_max, 'summary': xs.summary(tails)}))\n"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, WAYNE_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    report("sky/negative_control_unbounded_search", **d)
+    assert d["bad"] and any("most extreme high draw" in b for b in d["bad"]), d
+    assert d["k_max"] > 300.0, d

@@ -294,3 +294,33 @@ def test_orbit_over_one_exposure_by_interpolation():
     t = 5.0 + np.linspace(0, 0.2, 500)
     np.testing.assert_array_equal(lc.planet_orbit_short_span(3.5, 8.8, 0.1, 87.0, 30.0, 5.05, t)[0],
                                   lc.planet_orbit(3.5, 8.8, 0.1, 87.0, 30.0, 5.05, t)[0])
+
+
+def test_orbit_interpolation_at_julian_dates_across_exposures():
+    # at JD-scale times (ulp 4.7e-10 d) the exposures of a visit share their sub-sample OFFSETS exactly, so
+    # the second exposure takes the interpolation matrix cached by the first -- which must have been built around a
+    # centre both share (the offsets' own), with node times that are never rounded to the JD grid
+    from wayne_amd import lightcurve as lc
+    lc._cheb_cache.clear()
+    P, a, e, inc, w = 3.52474859, 8.76, 0.0, 86.71, 0.0
+    mid = 2455000.0 + 0.813
+    off = np.arange(2233) * (124.0 * 2.0 ** -30)              # 10 ms sampling, exactly representable offsets
+    worst = []
+    for start in (2456001.25, 2456001.25 + 273 * 2.0 ** -12, 2456004.0 + 11 * 2.0 ** -12):   # in transit and out of it
+        t = start + off
+        assert np.array_equal(t - t[0], off)                  # the JD grid holds these times exactly
+        n_before = len(lc._cheb_cache)
+        z1, l1 = lc.planet_orbit(P, a, e, inc, w, mid, t)
+        z2, l2 = lc.planet_orbit_short_span(P, a, e, inc, w, mid, t)
+        assert z2 is not z1
+        worst.append(max(float(np.abs(z1 - z2).max()), float(np.abs(l1 - l2).max())))
+        if start != 2456001.25:
+            assert len(lc._cheb_cache) == n_before            # the first exposure's matrix served this one
+    assert max(worst) < 2e-11, worst
+    # ... and offsets that the JD grid does NOT hold exactly (a 95-minute cadence): every exposure then differs in the
+    # last bits of its offsets, takes a matrix of its own, and is as exact
+    for n in range(3):
+        t = 2456001.25 + n * (95.0 / 1440.0) + np.arange(2233) * (0.01 / 86400.0)
+        z1, l1 = lc.planet_orbit(P, a, e, inc, w, mid, t)
+        z2, l2 = lc.planet_orbit_short_span(P, a, e, inc, w, mid, t)
+        assert max(float(np.abs(z1 - z2).max()), float(np.abs(l1 - l2).max())) < 2e-11

@@ -17,7 +17,8 @@ def _worker(rank, world, port, n_exp, out):
     from wayne_amd import visit as wv
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     v = helpers.make_visit("tiny", n_exposures=n_exp)
     runner = wv.VisitRunner(v)
     mine = wv.shard(n_exp, rank, world)
@@ -127,3 +128,12 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 4 and d["ranks_reported"] == 4 and d["scaling"] == "weak"
     assert d["value"] > 50 and abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["config"]["sharding"].startswith("round-robin")
+    # SURVEY 8(d)'s whole metric at N ranks: device-complete (`value`), delivered and end to end, each with every
+    # rank's own rate (four ranks on ONE card share one PCIe link: the figures are a rehearsal, their presence is the test)
+    for key in ("delivered", "end_to_end"):
+        leg = d[key]
+        assert leg["unit"] == "exposures/s" and leg["ranks_reported"] == 4 and leg["value"] > 10
+        assert sorted(leg["per_rank_exposures_s"]) == ["0", "1", "2", "3"]
+        assert all(len(v) == 3 and min(v) > 1 for v in leg["per_rank_exposures_s"].values())
+        assert leg["value"] <= 1.001 * sum(max(v) for v in leg["per_rank_exposures_s"].values())
+    assert "two_streams" not in d and "per_electron" not in d          # the like-for-like passes are N = 1 only

@@ -1,0 +1,80 @@
+"""GPU: include/wayne_hip.h promises "calls on distinct contexts are thread-safe, calls on one are not".  Two contexts on
+device 0, each driven by its own Python thread through upload / run / download, psf_apply and the pipelined
+fetch_async / wait of different exposures at the same time (the ctypes calls release the interpreter lock, so the two
+threads really are inside the library together): every frame must equal, bit for bit, the one a single thread produces.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import helpers
+from conftest import load_golden_psf
+from wayne_amd import _lib, engine
+
+pytestmark = pytest.mark.gpu
+
+N_EXP = 6
+
+
+def work(eng, v, indices, modes, out, errors, barrier=None):
+    """What one thread does with ITS context: whole exposures three ways, and thrower calls in between."""
+    try:
+        g = load_golden_psf("s128_t2")
+        for n, i in enumerate(indices):
+            pg = helpers.product_generator(v, i)
+            desc = pg.build_descriptor(eng, rng_mode=modes[n % len(modes)], out_dtype=np.float32, **v.frame_kwargs(i))
+            if barrier is not None:
+                barrier.wait(timeout=60)              # both threads enter the library together, every round
+            if n % 3 == 0:
+                reads = eng.ctx.synthesize(desc)
+            elif n % 3 == 1:
+                eng.ctx.upload(2, desc)
+                eng.ctx.run_front(2)
+                eng.ctx.run_back(2)
+                reads = eng.ctx.download(2)
+            else:
+                eng.ctx.upload(5, desc)
+                eng.ctx.run(5)
+                eng.ctx.fetch_async(5)
+                reads = np.array(eng.ctx.wait(5))
+            frame = eng.ctx.psf_apply(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], g["nr"], g["nc"],
+                                      g["test"] + i, g["threads"], rng_mode=_lib.RNG_REPLAY)
+            out[i] = (reads.copy(), frame.copy())
+    except BaseException as e:      # surfaced by the test
+        errors.append(e)
+
+
+def test_two_contexts_on_two_threads_equal_the_serial_frames():
+    v = helpers.make_visit("small256", n_exposures=2 * N_EXP)
+    modes = [_lib.RNG_SPLIT, _lib.RNG_PHILOX, _lib.RNG_REPLAY]
+    mine = [list(range(0, 2 * N_EXP, 2)), list(range(1, 2 * N_EXP, 2))]
+    # serial: one context, one thread
+    serial, errors = {}, []
+    eng0 = engine.Engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    try:
+        for idx in mine:
+            work(eng0, v, idx, modes, serial, errors)
+    finally:
+        eng0.close()
+    assert not errors, errors
+    # two contexts, two threads, at the same time
+    engs = [engine.Engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY) for _ in range(2)]
+    got, errors = {}, []
+    barrier = threading.Barrier(2)
+    try:
+        threads = [threading.Thread(target=work, args=(engs[t], v, mine[t], modes, got, errors, barrier)) for t in range(2)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=600)
+            assert not th.is_alive()
+    finally:
+        for e in engs:
+            e.close()
+    assert not errors, errors
+    assert sorted(got) == sorted(serial) == list(range(2 * N_EXP))
+    for i in serial:
+        np.testing.assert_array_equal(got[i][0], serial[i][0], err_msg="exposure %d" % i)
+        np.testing.assert_array_equal(got[i][1], serial[i][1], err_msg="thrower call %d" % i)
+    assert np.abs(serial[0][0] - serial[1][0]).max() > 1.0          # (different exposures: the comparison means something)

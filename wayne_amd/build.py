@@ -47,6 +47,28 @@ def build(force=False, verbose=True):
     return LIB
 
 
+# Negative-control library of tests/test_extremes_gpu.py: the sky draw's sequential search WITHOUT its stop (the defect
+# of rounds 1-3, k_ramp.h sky_draw_count_int).  Test infrastructure: built next to the CPU harnesses, loaded only through
+# WAYNE_HIP_LIB by a test's child process, never by the product.
+NEGCTL_SKY_LIB = os.path.join(ROOT, "tests", "native", "_build", "libwayne_hip_negctl_sky.so")
+
+
+def build_variant(extra_flags, out, force=False, verbose=False):
+    """The library with extra compiler flags, written to `out` (rebuilt when a source is newer)."""
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + SOURCES
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_negctl_sky(force=False, verbose=False):
+    return build_variant(["-DWAYNE_NEGCTL_SKY_RUNAWAY"], NEGCTL_SKY_LIB, force, verbose)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -116,9 +116,11 @@ def uniform_overlap_fraction(z, p):
     return out
 
 
-def planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array):
+def planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, time_array,
+                    time_origin=0.0):
     """The planet's position in stellar radii at each time: (X, Y) on the sky, Z along the line of sight (> 0: in
-    front of the star)."""
+    front of the star).  Times are time_origin + time_array; the sum is never formed (at JD-scale origins it would
+    round small offsets to 4.7e-10 d: planet_orbit_short_span hands in an exposure's start and offsets from it)."""
     t = np.asarray(time_array, dtype=float)
     e = float(eccentricity)
     inc = np.radians(inclination_deg)
@@ -126,7 +128,7 @@ def planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastr
     f_tr = 0.5 * np.pi - w                                    # true anomaly at mid-transit
     E_tr = 2.0 * np.arctan(np.sqrt((1 - e) / (1 + e)) * np.tan(0.5 * f_tr))
     t_peri = mid_time - period * (E_tr - e * np.sin(E_tr)) / (2 * np.pi)
-    M = 2 * np.pi * (((t - t_peri) / period) % 1.0)
+    M = 2 * np.pi * (((t + (time_origin - t_peri)) / period) % 1.0)
     E = M.copy()
     for _ in range(60):                                       # Kepler: Newton
         dE = (E - e * np.sin(E) - M) / (1 - e * np.cos(E))
@@ -185,20 +187,27 @@ def planet_orbit_short_span(period, sma_over_rs, eccentricity, inclination_deg, 
     half = 0.5 * (t_hi - t_lo)
     if not (0.0 < half <= 0.002 * period):
         return planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, t)
-    mid = 0.5 * (t_hi + t_lo)
-    # the sub-sample times of every exposure of a visit are the same offsets from its start: one matrix serves them all
+    # the sub-sample times of every exposure of a visit are the same offsets from its start: one matrix serves them all.
+    # Abscissae AND node times are built from the offsets and ONE centre, t[0] + off_mid: at JD-scale times (ulp 4.7e-10
+    # d) a centre taken as (t_hi + t_lo) / 2 rounds differently from exposure to exposure, and a cached matrix built
+    # around the first exposure's centre would then sit up to 1e-6 of the span off the nodes of the others.
     off = t - t[0]
+    off_lo, off_hi = float(off.min()), float(off.max())
+    half = 0.5 * (off_hi - off_lo)
+    off_mid = 0.5 * (off_hi + off_lo)
+    if not half > 0.0:
+        return planet_orbit(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time, t)
     key = (t.size, off[1], off[-1], half)
     hit = _cheb_cache.get(key)
     if hit is None or not np.array_equal(hit[0], off):
-        x = (t - mid) / half
+        x = (off - off_mid) / half
         nodes, B = _cheb_matrix(x)
         if len(_cheb_cache) > 64:
             _cheb_cache.clear()
         hit = _cheb_cache[key] = (off.copy(), nodes, B)
     _, nodes, B = hit
     X, Y, Zlos = planet_position(period, sma_over_rs, eccentricity, inclination_deg, periastron_deg, mid_time,
-                                 mid + half * nodes)
+                                 off_mid + half * nodes, time_origin=float(t[0]))
     P = B @ np.stack([X, Y, Zlos], axis=1)
     return np.sqrt(P[:, 0] * P[:, 0] + P[:, 1] * P[:, 1]), P[:, 2]
 

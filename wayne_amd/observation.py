@@ -226,16 +226,38 @@ class Observation(object):
         import threading
         ahead = queue.Queue(maxsize=depth + 1)
         mine = list(range(rank, len(self.exp_start_times), world))
+        stop = threading.Event()            # set by this thread when it leaves the loop, for whatever reason
+        # The context is created HERE, on the thread that will use it (upload / launch / collect): the producer's
+        # prepare() then finds the engine in the cache instead of building the context, uploading grism and calibration,
+        # on its own thread.
+        from . import engine as _engine
+        opts = dict(self.frame_options)
+        _engine.get_engine(self.device, self.grism, self.detector, self.calibration, self.NSAMP, self.SAMPSEQ,
+                           self.SUBARRAY, opts.get("add_initial_bias", self.add_initial_bias),
+                           g102_flat_quirk=bool(opts.get("reference_quirks", False)))
+
+        def put(item):
+            """Queue.put that gives up when the consumer has gone (returns False)."""
+            while not stop.is_set():
+                try:
+                    ahead.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 for i in mine:
-                    ahead.put((i, self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False,
-                                                          prepare_only=True)))
+                    if stop.is_set():
+                        return
+                    if not put((i, self._generate_exposure(self.exp_start_times[i], i + 1, write_fits=False,
+                                                           prepare_only=True))):
+                        return
             except BaseException as e:          # surfaced in the consuming thread
-                ahead.put(e)
+                put(e)
                 return
-            ahead.put(None)
+            put(None)
 
         producer = threading.Thread(target=produce, daemon=True)
         sys.setswitchinterval(min(old_interval, 2e-4))
@@ -256,12 +278,8 @@ class Observation(object):
             while in_flight:
                 finish_oldest()
         finally:
-            while producer.is_alive():          # (after an error: let the producer run out instead of blocking on put)
-                try:
-                    ahead.get(timeout=0.05)
-                except queue.Empty:
-                    pass
-            producer.join()
+            stop.set()                          # an error or Ctrl-C here: the producer stops after the exposure it is
+            producer.join()                     # preparing, not after the rest of the visit's host work
             if pool is not None:
                 pool.close()
             sys.setswitchinterval(old_interval)

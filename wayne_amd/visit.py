@@ -126,18 +126,32 @@ class VisitRunner(object):
         # upload's 0.08 ms of table building overlap the other thread's Python: on the reference's example-visit shape
         # the pipeline is then paced by the device, not by the host.
         ahead = queue.Queue(maxsize=self.DEPTH)
+        stop = threading.Event()            # set by this thread when it leaves the loop, for whatever reason
+
+        def put(item):
+            """Queue.put that gives up when the consumer has gone (returns False)."""
+            while not stop.is_set():
+                try:
+                    ahead.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 for n, i in enumerate(indices):
+                    if stop.is_set():
+                        return
                     gen = self.generator(i)
                     desc = gen.build_descriptor(eng, out_dtype=self.out_dtype, rng_mode=self.rng_mode,
                                                 **self.frame_kwargs(i))
-                    ahead.put((n, i, gen, desc))
+                    if not put((n, i, gen, desc)):
+                        return
             except BaseException as e:      # surfaced in the consuming thread
-                ahead.put(e)
+                put(e)
                 return
-            ahead.put(None)
+            put(None)
 
         producer = threading.Thread(target=produce, daemon=True)
         old_interval = sys.getswitchinterval()
@@ -162,13 +176,8 @@ class VisitRunner(object):
                 self._finish(ctx, pending.pop(0), results, keep, on_reads)
         finally:
             sys.setswitchinterval(old_interval)
-            # (an error on this side: let the producer run out against a drained queue rather than block on put)
-            while producer.is_alive():
-                try:
-                    ahead.get(timeout=0.05)
-                except queue.Empty:
-                    pass
-            producer.join()
+            stop.set()              # an error or Ctrl-C on this side: the producer stops after the descriptor it is
+            producer.join()         # building, not after the rest of the visit's host work
 
     def _finish(self, ctx, pending, results, keep, on_reads=None):
         i, slot, gen = pending
