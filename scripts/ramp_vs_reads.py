@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """k_ramp's time against the number of reads it works through (GPU only): t(R) = t0 + R t1 separates what a launch pays
 once per pixel (launch, alias tables -> LDS, stream seeding, once-per-pixel planes, zero read) from what it pays per
-read.  Same exposure (cfg4), same kernel instantiation, R = 1 ... 15 through the measurement knob WAYNE_RAMP_READS
-(wayne_hip.hip; timing only: the accumulators of the reads left out stay uncleared).
+read.  Same exposure (cfg4), same kernel instantiation, R = 1 ... 15 through the measurement knob WAYNE_RAMP_READS --
+which only a TIMING BUILD of the library looks at (-DWAYNE_TIMING_KNOBS: the reads left out keep stale planes and
+uncleared accumulators, so the shipped library ignores the variable).  This script builds that library
+(ab/timing_knobs.so, hipcc, ~25 s) and loads it through WAYNE_HIP_LIB.
 
     python scripts/ramp_vs_reads.py [launches per point = 30]
 
@@ -17,6 +19,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from wayne_amd import build as _wb  # noqa: E402
+os.environ["WAYNE_HIP_LIB"] = _wb.build_variant(["-DWAYNE_TIMING_KNOBS"] + os.environ.get("WAYNE_CXXFLAGS", "").split(),
+                                                os.path.join(ROOT, "ab", "timing_knobs.so"))
 from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
 from wayne_amd.exposure_generator import ExposureGenerator  # noqa: E402
 

@@ -64,8 +64,8 @@ def poisson_tails(k, lam, rng, z_pre=2.5):
 
 
 def normal_tails(x, mean, sigma, z_pre=3.0):
-    x = np.asarray(x, dtype=np.float64).ravel()
-    z = (x - np.asarray(mean, dtype=np.float64).ravel()) / np.asarray(sigma, dtype=np.float64).ravel()
+    x = np.asarray(x, dtype=np.float64)
+    z = ((x - np.asarray(mean, dtype=np.float64)) / np.asarray(sigma, dtype=np.float64)).ravel()
     hi, lo = z > z_pre, z < -z_pre
     return Tails(z.size, special.ndtr(-z[hi]), special.ndtr(z[lo]), float(stats.norm.sf(z_pre)), np.nonzero(hi)[0],
                  np.nonzero(lo)[0])
@@ -73,10 +73,11 @@ def normal_tails(x, mean, sigma, z_pre=3.0):
 
 def poisson_plus_normal_tails(x, lam, gain, mean, sigma, z_pre=3.0):
     """x = Poisson(lam) / gain + N(mean, sigma): exact tails by convolution, for the candidates."""
-    x = np.asarray(x, dtype=np.float64).ravel()
+    x = np.asarray(x, dtype=np.float64)
     lam = np.broadcast_to(np.asarray(lam, dtype=np.float64), x.shape).ravel()
     mean = np.broadcast_to(np.asarray(mean, dtype=np.float64), x.shape).ravel()
     sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), x.shape).ravel()
+    x = x.ravel()
     mu = lam / gain + mean
     sd = np.sqrt(lam / gain ** 2 + sigma ** 2)
     z = (x - mu) / sd

@@ -30,6 +30,13 @@ def test_checker_passes_on_the_exact_laws():
     lam = np.full(N_PIX, 700.0)
     y = rng.poisson(lam) / 2.35 + rng.normal(7.0, 6.0, N_PIX)
     bad += xs.check(xs.poisson_plus_normal_tails(y, lam, 2.35, 7.0, 6.0), "read")
+    # (two-dimensional frames with per-pixel planes of rates, means and sigmas, as the GPU tests hand them in)
+    lam2 = np.full((1014, 1014), 300.0)
+    lam2[:5] = 0.0
+    sig2 = np.full((1014, 1014), 6.0)
+    y2 = rng.poisson(lam2) / 2.35 + rng.normal(1.0, sig2)
+    bad += xs.check(xs.poisson_plus_normal_tails(y2, lam2, 2.35, np.full((1014, 1014), 1.0), sig2), "read 2-d")
+    bad += xs.check(xs.normal_tails(y2[:5], np.full((5, 1014), 1.0), sig2[:5]), "normal 2-d", qs=())
     assert not bad, "; ".join(bad)
 
 

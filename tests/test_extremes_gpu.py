@@ -86,7 +86,19 @@ def sky_rates(v, sky_ct_s):
     return [(sky * np.float32(sky_ct_s * d)).astype(np.float64) for d in dt]
 
 
-def sky_only_tails(v, n_exposures, rng, first=0):
+def on_level_pixels(v):
+    """Interior pixels whose master-sky value IS one of the levels of the sky plan (host_plan.h plan_sky: the l / L
+    quantiles of the positive pixels, L = 15 // number of distinct read intervals): their remainder mean is exactly 0,
+    e^-0 = 1 -- every threshold of the integer search saturates (k_ramp.h SkyRem::thr; ADVICE r04)."""
+    sky = v.calibration.sky[v.grism.name].astype(np.float32)
+    pos = np.sort(sky[sky > 0].ravel())
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    L = max(1, 15 // np.unique((5.0 * dt).astype(np.float32)).size)
+    levels = np.array([pos[l * pos.size // L] for l in range(L)], dtype=np.float32)
+    return np.isin(sky, levels)
+
+
+def sky_only_tails(v, n_exposures, rng, first=0, on_level=None):
     t = None
     k_max = 0
     for i in range(first, first + n_exposures):
@@ -99,6 +111,9 @@ def sky_only_tails(v, n_exposures, rng, first=0):
             k = e[r] - e[r - 1]
             assert k.min() >= 0
             k_max = max(k_max, float((k - lam[r - 1]).max()))
+            if on_level is not None:
+                on_level["dev"].append((k - lam[r - 1])[on_level["mask"]])
+                on_level["var"].append(lam[r - 1][on_level["mask"]])
             tr = xs.poisson_tails(k, lam[r - 1], rng)
             t = tr if t is None else t.merged(tr)
     return t, k_max
@@ -109,8 +124,16 @@ def test_sky_draws_largest_deviation_and_tail_frequencies():
     # every read interval of every pixel is an integer with a known Poisson law
     v = helpers.make_visit("cfg4", n_exposures=4)
     rng = np.random.default_rng(1)
-    t, k_max = sky_only_tails(v, 4, rng)
+    lvl = {"mask": on_level_pixels(v), "dev": [], "var": []}
+    t, k_max = sky_only_tails(v, 4, rng, on_level=lvl)
     s = xs.summary(t)
+    # pixels that sit exactly ON their level: remainder mean 0, cdf = 1 from the first term -- all four integer
+    # thresholds saturate and the count is the table's alone.  Thresholds of 0 instead (an unsaturated conversion of
+    # 2^32) would add 4 electrons to every one of these draws
+    dev, var = np.concatenate(lvl["dev"]), np.concatenate(lvl["var"])
+    z_level = float(dev.sum() / np.sqrt(var.sum()))
+    s["on_level_draws"], s["on_level_mean_z"] = int(dev.size), z_level
+    assert dev.size >= 7 * 15 * 4 and abs(z_level) < 5.0, (dev.size, z_level, float(dev.mean()))
     report("sky/production_math", largest_excess_electrons=k_max, **s)
     assert t.n == 4 * 15 * 1014 * 1014
     bad = xs.check(t, "sky")

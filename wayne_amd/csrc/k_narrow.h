@@ -249,6 +249,13 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       float n_col = 0.f;
       if (n_rem > 0.f && (c >= 0 || pool)) {
         const float pc = (c < 0) ? P : fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
+#ifdef WAYNE_TIMING_COLPOOL
+        // TIMING BUILD (wrong frames; DESIGN.md section 9, "column chains pooled over 4 bins"): what the kernel would cost
+        // if three of four column chains did not exist -- the chains of waves 2..7 are replaced by a rounding (whole
+        // waves, so the issue slots really go), their thinning draw and everything downstream stays
+        if (c >= 0 && (tid >> 6) >= 2) n_col = fminf(floorf(fmaf(n_rem, pc, 0.5f)), n_rem);
+        else
+#endif
         n_col = binomial<M>(n_rem, pc, rng, s_fc);
         if (c < 0) { res = (int)(n_rem - n_col); n_rem = n_col; n_col = 0.f; }
         else n_rem -= n_col;

@@ -339,6 +339,11 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
     return (long long)(((unsigned long long)w.y << 32) | w.x);
   };
   auto ld_f32 = [&](const __amdgpu_buffer_rsrc_t& rs, int r) -> float {
+#ifdef WAYNE_TIMING_RAMP_NO_DARK
+    // TIMING BUILD (wrong frames; DESIGN.md section 9, "two exposures per launch"): the dark planes for free -- what the
+    // second exposure of a pair that shared its partner's dark loads would cost
+    return 0.02f + 1e-9f * (float)(r + (int)off4);
+#endif
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off4, (uint32_t)r * f32_plane, kNT));
   };
   auto st_out = [&](int plane, OutT v) {
@@ -359,10 +364,18 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   // (scripts/ramp_vs_reads.py).
   const int lane_r = min(tid & 63, kMaxReads);
   const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
+#ifdef WAYNE_TIMING_RAMP_NO_ONCE
+  // TIMING BUILD (wrong frames): the once-per-pixel planes for free -- what a second exposure in
+  // the same launch would save on them
+  const float t_sky = (interior && do_sky) ? 1.0f + 1e-4f * (float)(p & 255) : 0.f;
+  const float t_pfl = 1.0f + 1e-5f * (float)(p & 127);
+  float c1 = 0, c2 = 7e-7f + 1e-12f * (float)(p & 63), c3 = 0, c4 = 0;
+#else
   const float t_sky = (interior && do_sky) ? a.sky[p] : 0.f;
   const float t_pfl = (interior && gainvar) ? a.pfl[p] : 1.0f;
   float c1 = 0, c2 = 0, c3 = 0, c4 = 0;
   if (do_lin && valid) { c1 = a.lin[0][p]; c2 = a.lin[1][p]; c3 = a.lin[2][p]; c4 = a.lin[3][p]; }
+#endif
   const double t_zero = (valid && a.zero_read && (a.flags & (1u << 7))) ? a.zero_read[p] : 0.;
   const int v_bg = __float_as_int(a.bg[lane_r]), v_tab0 = a.tab0[lane_r];
   const int v_lvl = __float_as_int(a.sky_level[lane_r]);
