@@ -22,4 +22,6 @@ python3 scripts/thrower_vs_electrons.py 20 > $OUT/thrower_vs_electrons.txt 2>&1
 python3 scripts/profile_host_path.py cfg1 1000 > $OUT/host_path_cfg1.txt 2>&1
 python3 scripts/run_example_visit.py 3000 > $OUT/example_visit.txt 2>&1
 python3 scripts/time_fits_pipeline.py > $OUT/fits_full_array.txt 2>&1
+# the 4-ranks-on-one-card rehearsal of `bench.py --gpus N` (delivered / end_to_end per rank; not a scaling figure)
+WAYNE_BENCH_SHARE_GPU=1 python3 bench.py --gpus 4 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_4ranks_one_gpu.json 2> $OUT/bench_4ranks_one_gpu.err
 ls $OUT
