@@ -283,6 +283,61 @@ def test_thrower_largest_single_pixel_deviation_at_full_size():
     assert not bad, "; ".join(bad) + "\n%r" % s
 
 
+@pytest.mark.parametrize("path", ["k_prep_sub", "k_lane_fused"])
+def test_cosmic_ray_hits_follow_their_three_laws(path, monkeypatch):
+    # MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139): per read interval Poisson(rate N^2 / 1024^2 dt)
+    # hits, each with energy randint(10000, 35000) (upper bound exclusive) at a pixel randint(0, N)^2, hits on one pixel
+    # adding.  Star off: the accumulators hold the hits and nothing else -- 8 exposures x 15 intervals, ~12 000 hits.
+    # The hits ride in the first workgroups of k_prep_sub (the benchmarked sequence) or, on a thin exposure -- which a
+    # star this dim is -- of k_lane_fused: both, the first forced with WAYNE_NO_FUSE.
+    from scipy import stats
+    if path == "k_prep_sub":
+        monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+    v = helpers.make_visit("cfg5", n_exposures=8)
+    rate, N = 11.0, 1014
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    lam = rate * (N * N) / 1024.0 ** 2 * dt
+    rng = np.random.default_rng(5)
+    counts, energies, xs_, ys_ = [], [], [], []
+    doubles = 0
+    for i in range(8):
+        rec = {}
+        pg = helpers.product_generator(v, i)
+        pg.scanning_frame(out_dtype=np.float32, record=rec, **v.frame_kwargs(i, cosmic_rate=rate, add_flat=False, **{
+            k_: v_ for k_, v_ in STAR_OFF.items() if k_ != "cosmic_rate"}))
+        acc = rec["acc"]
+        assert not acc[:, :5, :].any() and not acc[:, :, :5].any() and not acc[:, -5:, :].any() and not acc[:, :, -5:].any()
+        for r in range(acc.shape[0]):
+            yy, xx = np.nonzero(acc[r])
+            e = acc[r][yy, xx]
+            assert np.all(e == np.rint(e)) and e.min() >= 10000
+            two = e >= 35000                                   # two hits on one pixel add (:134-139): counted as two
+            doubles += int(two.sum())
+            counts.append(e.size + int(two.sum()))
+            energies.append(e[~two])
+            xs_.append(xx - 5)
+            ys_.append(yy - 5)
+    counts = np.array(counts, dtype=float)
+    e = np.concatenate(energies)
+    x, y = np.concatenate(xs_), np.concatenate(ys_)
+    lam_all = np.tile(lam, 8)
+    t = xs.poisson_tails(counts, lam_all, rng)
+    z_total = (counts.sum() - lam_all.sum()) / np.sqrt(lam_all.sum())
+    # energies: discrete uniform on 10000 .. 34999
+    ks = stats.kstest(e + rng.random(e.size), stats.uniform(loc=10000, scale=25000).cdf)
+    # positions: uniform on the light-sensitive N x N pixels (chi-square on an 8 x 8 grid) and both axes use all of it
+    grid = np.histogram2d(y, x, bins=8, range=[[0, N], [0, N]])[0]
+    chi2 = ((grid - x.size / 64.0) ** 2 / (x.size / 64.0)).sum()
+    report("cosmic/cfg5/" + path, hits=int(counts.sum()), expected=float(lam_all.sum()), z_total=float(z_total), doubles=doubles,
+           energy_ks_p=float(ks.pvalue), energy_min=float(e.min()), energy_max=float(e.max()), position_chi2=float(chi2),
+           min_u_hi=float(t.u_hi.min()) if t.u_hi.size else None, min_u_lo=float(t.u_lo.min()) if t.u_lo.size else None)
+    assert abs(z_total) < 5.0 and not xs.check(t, "hits per interval", qs=())
+    assert ks.pvalue > 1e-4 and e.min() <= 10100 and 34900 <= e.max() <= 34999
+    assert chi2 < 63 + 6 * np.sqrt(2 * 63.0)
+    assert x.min() == 0 and y.min() == 0 and x.max() == N - 1 and y.max() == N - 1 or (x.max() >= N - 3 and y.max() >= N - 3)
+    assert doubles <= 6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # negative control: the library with the unbounded search of rounds 1-3
 # ---------------------------------------------------------------------------------------------------------------
