@@ -10,6 +10,7 @@
 //   2 PLAN       i32 S sub_scale rng_mode W K R; f64 scale_factor; f64 wl[W] flux[W] x_ref[K] y_ref[K] dur_ms[K]; i32 sample_read[K]
 //   3 SKY        f64 sky_ct_s; i32 R; f64 read_dt[R]; i32 has_sky n_sorted; f32 sky_sorted[n]
 //   4 ALIAS      f64 lam
+//   5 PSF        i32 size N rng_mode threads_compat margin; i32 counts[size]; f64 x[size] y[size] ratio[size] sigl[size]
 // Results: see the write_* calls below (tests/plan_harness.py decodes them).
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +119,29 @@ int main(int argc, char** argv) {
       put1<int32_t>(4);
       put1<int32_t>(plan::sky_alias_fits(lam) ? 1 : 0);
       put(tab, (size_t)kSkyAlias);
+    } else if (code == 5) {
+      int32_t h[5];
+      if (!get(h, 5)) bad("psf header");
+      const int size = h[0];
+      if (size < 0 || size > (1 << 22)) bad("psf size");
+      std::vector<int32_t> counts((size_t)size);
+      std::vector<double> x((size_t)size), y((size_t)size), ratio((size_t)size), sigl((size_t)size);
+      if (!get(counts.data(), (size_t)size) || !get(x.data(), (size_t)size) || !get(y.data(), (size_t)size) ||
+          !get(ratio.data(), (size_t)size) || !get(sigl.data(), (size_t)size)) bad("psf arrays");
+      plan::PsfPlan pp;
+      const int rc = plan::plan_psf_apply(counts.data(), size, x.data(), y.data(), ratio.data(), sigl.data(), h[1], h[2], h[3],
+                                          h[4], &pp);
+      put1<int32_t>(5);
+      put1<int32_t>(rc);
+      put1<int64_t>((int64_t)pp.total);
+      if (rc == 0) {
+        put(pp.prefix.data(), pp.prefix.size());
+        put(pp.nwide.data(), pp.nwide.size()); put(pp.nsplit.data(), pp.nsplit.size()); put(pp.nlane.data(), pp.nlane.size());
+        put1<int32_t>(pp.any_split ? 1 : 0); put1<int32_t>(pp.any_lane ? 1 : 0);
+        put1<uint32_t>(pp.run);
+        int32_t rect[4] = {pp.tx0, pp.ty0, pp.tw, pp.th};
+        put(rect, 4);
+      }
     } else {
       bad("operation code");
     }

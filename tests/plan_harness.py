@@ -71,6 +71,14 @@ class Batch(object):
         self.kinds.append(("alias",))
         return len(self.ops) - 1
 
+    def psf(self, counts, x, y, ratio, sigl, N, rng_mode, threads_compat=1, margin=30):
+        counts = np.ascontiguousarray(counts, dtype="<i4")
+        n = counts.size
+        self.ops.append(struct.pack("<i5i", 5, n, N, rng_mode, threads_compat, margin) + counts.tobytes() + _f64(x) + _f64(y) +
+                        _f64(ratio) + _f64(sigl))
+        self.kinds.append(("psf", n))
+        return len(self.ops) - 1
+
     def run(self, variant="", timeout=600):
         exe = binary(variant)
         if not os.path.exists(exe):
@@ -139,6 +147,20 @@ class Batch(object):
                 r["keys"] = arr("<u4", n)
                 (r["n_bg"],) = take("i")
                 r["tables"] = arr("<u4", n * K_SKY_ALIAS).reshape(n, K_SKY_ALIAS) if r["alias_on"] else None
+                out.append(r)
+            elif kind[0] == "psf":
+                assert code == 5
+                (rc,) = take("i")
+                (total,) = take("q")
+                r = {"rc": rc, "total": total}
+                if rc == 0:
+                    n = kind[1]
+                    r["prefix"] = arr("<u4", n + 1)
+                    r["nwide"], r["nsplit"], r["nlane"] = arr("<i4", n), arr("<i4", n), arr("<i4", n)
+                    a_s, a_l = take("2i")
+                    r["any_split"], r["any_lane"] = bool(a_s), bool(a_l)
+                    (r["run"],) = take("I")
+                    r["rect"] = arr("<i4", 4)
                 out.append(r)
             else:
                 assert code == 4

@@ -398,3 +398,97 @@ def test_alias_tables_are_the_poisson_law():
         assert abs(pmf.sum() - 1.0) < 1e-12                     # a table is a distribution whatever came in
         if want_fit:
             assert np.abs(pmf - stats.poisson.pmf(np.arange(256), lam)).max() < 1.5e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the host half of wayne_psf_apply (pyparallel.pyx:14-38 -> pyparallel_menu.c:10-113)
+# ---------------------------------------------------------------------------------------------------------------
+def test_psf_apply_routes_every_electron_exactly_once():
+    rng = np.random.default_rng(21)
+    batch, cases = ph.Batch(), []
+    for trial in range(200):
+        n = int(rng.choice([0, 1, 2, 63, 64, 65, 600, 4494]))
+        N = int(rng.choice([64, 256, 1014]))
+        mode = int(rng.choice([0, 1, 2, 2]))
+        scale = float(rng.choice([1, 40, 3000, 200000]))
+        counts = rng.poisson(scale * np.abs(rng.normal(1, 0.5, n))).astype(np.int64)
+        counts = np.minimum(counts, 2 ** 31 - 1)
+        if n and rng.random() < 0.3:
+            counts[rng.integers(0, n)] = int(rng.choice([0, 31, 32, 33, 4096, 4097, 2 ** 24 + 40, 2 ** 26]))
+        ratio = np.clip(rng.normal(0.2, 0.05, n), 0, 1)
+        sigl = rng.uniform(0.4, 0.95, n)
+        x = rng.uniform(-20, N + 20, n)
+        y = rng.uniform(-20, N + 20, n)
+        if n and rng.random() < 0.4:           # hostile values in every array
+            j = rng.integers(0, n)
+            ratio[j] = rng.choice([np.nan, np.inf, -np.inf, -3.0, 7.5, 1e300])
+            sigl[rng.integers(0, n)] = rng.choice([np.nan, 0.0, 0.05, 0.9231, 1e9, -1.0])
+            x[rng.integers(0, n)] = rng.choice([np.nan, np.inf, -1e300])
+            y[rng.integers(0, n)] = rng.choice([np.nan, -np.inf, 1e300])
+        if counts.sum() > 2 ** 32 - 1:
+            counts = counts // 64
+        threads = int(rng.choice([1, 2, 4, 64, 4096]))
+        cases.append((counts, x, y, ratio, sigl, N, mode, threads,
+                      batch.psf(counts, x, y, ratio, sigl, N, mode, threads)))
+    out = batch.run()
+    seen = {"ok": 0, "overflow": 0, "split": 0, "lane": 0, "thrown": 0}
+    for counts, x, y, ratio, sigl, N, mode, threads, i in cases:
+        r = out[i]
+        total = int(counts.sum())
+        assert r["total"] == total
+        if mode == 0 and total * threads > 2 ** 31 - 1:
+            assert r["rc"] == 2                 # the reference's int arithmetic would have overflowed (pyparallel_menu.c:12,48)
+            seen["overflow"] += 1
+            continue
+        assert r["rc"] == 0
+        seen["ok"] += 1
+        c = counts.astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            nw = c * ratio
+        want = np.where(np.isnan(nw), -2.0 ** 31, np.clip(np.trunc(np.nan_to_num(nw, nan=0.0, posinf=1e300, neginf=-1e300)),
+                                                         -2.0 ** 31, 2.0 ** 31 - 1))
+        assert np.array_equal(r["nwide"].astype(np.float64), want)          # the C cast, with its corners spelled out
+        thrown = np.diff(r["prefix"].astype(np.int64))
+        assert r["prefix"][0] == 0 and r["run"] == r["prefix"][-1] == thrown.sum()
+        assert np.array_equal(r["nsplit"].astype(np.int64) + r["nlane"] + thrown, counts), "an electron routed twice or lost"
+        if mode == 2:
+            wide = np.clip(r["nwide"].astype(np.int64), 0, counts)
+            narrow = counts - wide
+            with np.errstate(invalid="ignore"):
+                split = (narrow >= 32) & (narrow <= 2 ** 24) & (sigl > 0.05) & (sigl * 6.5 <= 6)
+            ind = np.where(split, wide, counts)
+            lane = ind <= 4096
+            assert np.array_equal(r["nsplit"], np.where(split, narrow, 0))
+            assert np.array_equal(r["nlane"], np.where(lane, ind, 0))
+            assert np.array_equal(thrown, np.where(lane, 0, ind))
+            assert r["any_split"] == bool((r["nsplit"] > 0).any()) and r["any_lane"] == bool((r["nlane"] > 0).any())
+            seen["split"] += int(split.sum())
+            seen["lane"] += int((r["nlane"] > 0).sum())
+            seen["thrown"] += int((thrown > 0).sum())
+        else:
+            assert not r["nsplit"].any() and not r["nlane"].any() and np.array_equal(thrown, counts)
+        # the clip rectangle holds the pixel of every populated bin with a finite position, +- the margin, inside [1, N)
+        tx0, ty0, tw, th = r["rect"]
+        ok = (counts > 0) & np.isfinite(x) & np.isfinite(y)
+        if ok.any():
+            x0, x1 = max(np.floor(x[ok].min()) - 30, 1), min(np.floor(x[ok].max()) + 31, N)
+            y0, y1 = max(np.floor(y[ok].min()) - 30, 1), min(np.floor(y[ok].max()) + 31, N)
+            if x1 > x0 and y1 > y0:
+                assert (tx0, ty0, tx0 + tw, ty0 + th) == (x0, y0, x1, y1)
+            else:
+                assert tw == 0 and th == 0
+        else:
+            assert tw == 0 and th == 0
+    assert seen["ok"] > 100 and seen["overflow"] >= 2 and seen["split"] > 1000 and seen["lane"] > 1000 and seen["thrown"] > 10
+
+
+def test_psf_apply_errors():
+    batch = ph.Batch()
+    one = np.ones(3)
+    ids = [batch.psf([5, -1, 2], one, one, one * 0.2, one * 0.7, 64, 2),
+           batch.psf([2 ** 31 - 1, 2 ** 31 - 1, 2 ** 31 - 1], one, one, one * 0.2, one * 0.7, 64, 1),
+           batch.psf([2 ** 30, 2 ** 30, 0], one, one, one * 0.2, one * 0.7, 64, 0, threads_compat=1),
+           batch.psf([2 ** 30, 2 ** 30 - 1, 0], one, one, one * 0.2, one * 0.7, 64, 0, threads_compat=1),
+           batch.psf([2 ** 29, 0, 0], one, one, one * 0.2, one * 0.7, 64, 0, threads_compat=4)]
+    rc = [r["rc"] for r in (batch.run()[i] for i in ids)]
+    assert rc == [1, 3, 2, 0, 2]

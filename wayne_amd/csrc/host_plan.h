@@ -8,6 +8,7 @@
 //   SpectrumEstimate     per-bin factors that depend on (grism, wavelengths, stellar flux) alone, cached on their content
 //   estimate_thrown      expected electrons per k_lane / k_narrow chunk -> launch order, batches, what k_throw is sized for
 //   accumulator_boxes    per read interval: where the thrower's electrons can land (k_ramp loads accumulators only there)
+//   plan_psf_apply       the host half of wayne_psf_apply: count reduction, N = (int)(counts ratio), routing, clip rectangle
 //   plan_sky             levels of the master sky, alias-table keys, which reads fit a table (k_ramp's sky draw)
 //   build_sky_alias      one Walker / Vose table of Poisson(lam)
 //
@@ -230,6 +231,74 @@ inline bool accumulator_boxes(SpectrumEstimate& e, int W, const double* wl_um, c
     box[r][1] = std::min(box[r][1], S); box[r][3] = std::min(box[r][3], S);
   }
   return true;
+}
+
+// The host half of wayne_psf_apply (the inner drop-in boundary: pyparallel.pyx:14-38 -> pyparallel_menu.c:10-113): the
+// count reduction A1 with the reference's silent int overflows turned into errors, N = (int)(counts * ratio) per bin
+// (:89, with the C cast's behaviour at NaN and beyond int spelled out), the split mode's routing of every bin -- the rule
+// of k_prep_sub -- and the clip rectangle of the throwers' tiles.  Every electron of the input must be routed exactly
+// once: nsplit + nlane + (prefix[i + 1] - prefix[i]) == counts[i].
+struct PsfPlan {
+  std::vector<uint32_t> prefix;                  // [size + 1] exclusive prefix of the electrons k_throw shares out
+  std::vector<int32_t> nwide, nsplit, nlane;     // [size]
+  bool any_split = false, any_lane = false;
+  uint32_t run = 0;                              // electrons for k_throw
+  long long total = 0;                           // sum(counts)
+  int tx0 = 0, ty0 = 0, tw = 0, th = 0;          // clip region of the tiles (frame coordinates); tw = 0: none
+};
+enum PsfPlanError { PSF_OK = 0, PSF_NEGATIVE = 1, PSF_OVERFLOW_REPLAY = 2, PSF_OVERFLOW_TOTAL = 3 };
+
+inline int plan_psf_apply(const int32_t* counts, int size, const double* x_pos, const double* y_pos, const double* psf_ratio,
+                          const double* psf_sigmal, int N, int rng_mode, int threads_compat, int margin, PsfPlan* out) {
+  *out = PsfPlan();
+  long long total = 0;
+  for (int i = 0; i < size; ++i) {
+    if (counts[i] < 0) return PSF_NEGATIVE;
+    total += counts[i];
+  }
+  out->total = total;
+  if (rng_mode == 0 && total * (long long)threads_compat > 2147483647LL) return PSF_OVERFLOW_REPLAY;   // (pyparallel_menu.c:12,48)
+  if (total > 0xFFFFFFFFLL) return PSF_OVERFLOW_TOTAL;
+  out->prefix.assign((size_t)size + 1, 0u);
+  out->nwide.assign((size_t)size, 0); out->nsplit.assign((size_t)size, 0); out->nlane.assign((size_t)size, 0);
+  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  uint32_t run = 0;
+  for (int i = 0; i < size; ++i) {
+    out->prefix[(size_t)i] = run;
+    const double nw = (double)counts[i] * psf_ratio[i];  // N = counts*ratio (:89)
+    out->nwide[(size_t)i] = (nw >= 2147483647.) ? 2147483647
+                            : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1)
+                            : (!(nw == nw))        ? (int32_t)(-2147483647 - 1)
+                                                   : (int32_t)nw;
+    uint32_t thrown = (uint32_t)counts[i];
+    if (rng_mode == RNG_SPLIT) {      // same rule as k_prep_sub
+      const uint32_t wide = (uint32_t)std::min<int64_t>(std::max(out->nwide[(size_t)i], 0), counts[i]);
+      const uint32_t narrow = (uint32_t)counts[i] - wide;
+      const bool split = narrow >= (uint32_t)kSplitMin && narrow <= kSplitMaxNarrow && psf_sigmal[i] > 0.05 &&
+                         psf_sigmal[i] * 6.5 <= (double)kNarrowR;
+      const uint32_t ind = split ? wide : (uint32_t)counts[i];
+      const bool lane = ind <= (uint32_t)kLaneMax;
+      out->nsplit[(size_t)i] = split ? (int32_t)narrow : 0;
+      out->nlane[(size_t)i] = lane ? (int32_t)ind : 0;
+      thrown = lane ? 0u : ind;
+      if (out->nsplit[(size_t)i] > 0) out->any_split = true;
+      if (out->nlane[(size_t)i] > 0) out->any_lane = true;
+    }
+    run += thrown;
+    if (counts[i] > 0 && std::isfinite(x_pos[i]) && std::isfinite(y_pos[i])) {
+      xmin = std::min(xmin, x_pos[i]); xmax = std::max(xmax, x_pos[i]);
+      ymin = std::min(ymin, y_pos[i]); ymax = std::max(ymax, y_pos[i]);
+    }
+  }
+  out->prefix[(size_t)size] = run;
+  out->run = run;
+  if (xmax >= xmin) {
+    auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
+    const int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
+    const int y0 = std::max(clampi(std::floor(ymin)) - margin, 1), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
+    if (x1 > x0 && y1 > y0) { out->tx0 = x0; out->ty0 = y0; out->tw = x1 - x0; out->th = y1 - y0; }   // clip region of the tiles
+  }
+  return PSF_OK;
 }
 
 // Does Poisson(lam) fit an alias table of kSkyAlias entries (mass beyond the table < 1e-14)?

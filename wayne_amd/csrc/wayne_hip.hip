@@ -582,64 +582,31 @@ int wayne_psf_apply_ex(wayne_ctx* c, const int32_t* counts, int size, const doub
   (void)hipSetDevice(c->device);
   c->stream = c->streams[0];
 
-  // A1: ssum, with the reference's silent int overflows turned into errors
-  long long total = 0;
-  for (int i = 0; i < size; ++i) {
-    if (counts[i] < 0) return fail(c, WAYNE_E_NEGATIVE, "psf_apply: negative count");
-    total += counts[i];
+  // A1 (ssum, with the reference's silent int overflows turned into errors), N = (int)(counts * ratio), the split mode's
+  // routing and the tiles' clip rectangle: plan::plan_psf_apply (host_plan.h: host-only code, under sanitizers in tests/native)
+  const int margin = 30;
+  plan::PsfPlan pp;
+  switch (plan::plan_psf_apply(counts, size, x_pos, y_pos, psf_ratio, psf_sigmal, N, rng_mode, threads_compat, margin, &pp)) {
+    case plan::PSF_NEGATIVE: return fail(c, WAYNE_E_NEGATIVE, "psf_apply: negative count");
+    case plan::PSF_OVERFLOW_REPLAY: return fail(c, WAYNE_E_OVERFLOW, "psf_apply: sum(counts)*threads >= 2^31 (pyparallel_menu.c:12,48)");
+    case plan::PSF_OVERFLOW_TOTAL: return fail(c, WAYNE_E_OVERFLOW, "psf_apply: more than 2^32-1 electrons");
+    default: break;
   }
-  if (rng_mode == WAYNE_RNG_REPLAY && total * (long long)threads_compat > 2147483647LL)
-    return fail(c, WAYNE_E_OVERFLOW, "psf_apply: sum(counts)*threads >= 2^31 (pyparallel_menu.c:12,48)");
-  if (total > 0xFFFFFFFFLL) return fail(c, WAYNE_E_OVERFLOW, "psf_apply: more than 2^32-1 electrons");
+  const long long total = pp.total;
 
   HIP_TRY(c, c->pa_frame.reserve((size_t)N * N * sizeof(int32_t)));
   HIP_TRY(c, hipMemsetAsync(c->pa_frame.p, 0, (size_t)N * N * sizeof(int32_t), c->stream));  // A3
 
   if (total > 0) {
-    std::vector<uint32_t> prefix((size_t)size + 1);
-    std::vector<int32_t> nwide((size_t)size), nsplit((size_t)size, 0), nlane((size_t)size, 0);
-    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
-    uint32_t run = 0;
-    bool any_split = false, any_lane = false;
-    for (int i = 0; i < size; ++i) {
-      prefix[i] = run;
-      const double nw = (double)counts[i] * psf_ratio[i];  // N = counts*ratio (:89)
-      nwide[i] = (nw >= 2147483647.) ? 2147483647
-                 : (nw <= -2147483648.) ? (int32_t)(-2147483647 - 1)
-                 : (!(nw == nw))        ? (int32_t)(-2147483647 - 1)
-                                        : (int32_t)nw;
-      uint32_t thrown = (uint32_t)counts[i];
-      if (rng_mode == WAYNE_RNG_SPLIT) {      // same rule as k_prep_sub
-        const uint32_t wide = (uint32_t)std::min<int64_t>(std::max(nwide[i], 0), counts[i]);
-        const uint32_t narrow = (uint32_t)counts[i] - wide;
-        const bool split = narrow >= (uint32_t)kSplitMin && narrow <= kSplitMaxNarrow && psf_sigmal[i] > 0.05 &&
-                           psf_sigmal[i] * 6.5 <= (double)kNarrowR;
-        const uint32_t ind = split ? wide : (uint32_t)counts[i];
-        const bool lane = ind <= (uint32_t)kLaneMax;
-        nsplit[i] = split ? (int32_t)narrow : 0;
-        nlane[i] = lane ? (int32_t)ind : 0;
-        thrown = lane ? 0u : ind;
-        if (nsplit[i] > 0) any_split = true;
-        if (nlane[i] > 0) any_lane = true;
-      }
-      run += thrown;
-      if (counts[i] > 0 && std::isfinite(x_pos[i]) && std::isfinite(y_pos[i])) {
-        xmin = std::min(xmin, x_pos[i]); xmax = std::max(xmax, x_pos[i]);
-        ymin = std::min(ymin, y_pos[i]); ymax = std::max(ymax, y_pos[i]);
-      }
-    }
-    prefix[size] = run;
+    const std::vector<uint32_t>& prefix = pp.prefix;
+    const std::vector<int32_t>&nwide = pp.nwide, &nsplit = pp.nsplit, &nlane = pp.nlane;
+    const uint32_t run = pp.run;
+    const bool any_split = pp.any_split, any_lane = pp.any_lane;
     SubInfo si{};
     si.electrons = run;
     si.read = 0;
     si.replay_seed = (int)seed;
-    const int margin = 30;
-    if (xmax >= xmin) {
-      auto clampi = [](double v) { return (int)std::min(std::max(v, -1e6), 1e6); };
-      int x0 = std::max(clampi(std::floor(xmin)) - margin, 1), x1 = std::min(clampi(std::floor(xmax)) + margin + 1, N);
-      int y0 = std::max(clampi(std::floor(ymin)) - margin, 1), y1 = std::min(clampi(std::floor(ymax)) + margin + 1, N);
-      if (x1 > x0 && y1 > y0) { si.tx0 = x0; si.ty0 = y0; si.tw = x1 - x0; si.th = y1 - y0; }   // clip region of the tiles
-    }
+    si.tx0 = pp.tx0; si.ty0 = pp.ty0; si.tw = pp.tw; si.th = pp.th;   // clip region of the tiles
     int rc;
     {
       // one pinned arena, one host-to-device copy (nine pageable copies cost ~0.1 ms of a 0.35 ms call)
