@@ -285,3 +285,41 @@ def test_random_exposures_against_the_oracle():
         assert ok, "case %d %r: %d of %d pixels off, median %.2e, max %.2f" % (j, c, bad, size, med, worst)
         modes.add((c["mode"][0], c["exact"], c["f64"]))
     assert len(modes) >= 10          # the stretch visits nearly every (rng mode, samplers, dtype) combination
+
+
+def test_not_a_number_in_the_descriptor_throws_nothing_and_corrupts_nothing():
+    # hostile VALUES through the real upload path (the CPU harness of the host planner -- tests/test_host_plan.py --
+    # covers the planner alone): a NaN wavelength poisons its own bin (position, PSF, sensitivity) and the widths of its
+    # two neighbours; a NaN or negative flux its own bin.  The reference would cast those counts to C ints; here such a
+    # bin throws nothing (k_prep.h plan_bin), the host takes the load-everything path for k_ramp (no bound can be built
+    # on a NaN), and every other bin draws what it drew before: the reads equal, bit for bit, those of the clean
+    # descriptor with the affected bins' flux set to zero -- and the accumulators are left clean
+    from wayne_amd import _lib, engine
+    for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX, _lib.RNG_REPLAY):
+        reads = []
+        for hostile in (True, False):
+            v = helpers.make_visit("small256")       # (a fresh one per pass: the descriptor's arrays are views of the visit's)
+            pg = helpers.product_generator(v, 0)
+            eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+            desc = pg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float64, **v.frame_kwargs(0, cosmic_rate=None))
+            wl, flux = desc._keep[0], desc._keep[1]
+            W = wl.size
+            j, a, b = W // 3, W // 2, (2 * W) // 3
+            if hostile:
+                wl[j] = np.nan
+                flux[a] = np.nan
+                flux[b] = -flux[b]
+            else:
+                flux[j - 1:j + 2] = 0.0
+                flux[a] = 0.0
+                flux[b] = 0.0
+            ctx = eng.ctx
+            reads.append(ctx.synthesize(desc))
+            use_box, _, _ = ctx.debug_boxes(0)
+            assert use_box == (not hostile)
+            _, _, _, acc_after = ctx.debug_fetch(0, acc=True)
+            assert not acc_after.any(), "accumulators left dirty: %g electrons" % acc_after.sum()
+            assert ctx.status(0) == 0
+        assert np.isfinite(reads[0]).all()
+        np.testing.assert_array_equal(reads[0], reads[1], err_msg="rng_mode %d" % mode)
+        assert (reads[0][-1] - reads[0][0]).max() > 50              # the star is there
