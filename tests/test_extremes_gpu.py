@@ -68,10 +68,10 @@ def plain_visit(n_exposures):
     return synthetic.Visit("cfg4", detector.WFC3_IR(), grism.G141(cal), cal, n_exposures=n_exposures)
 
 
-def run_exposure(v, i, want_variant, out_dtype=np.float32, **over):
+def run_exposure(v, i, want_variant, out_dtype=np.float32, exact_samplers=False, **over):
     pg = helpers.product_generator(v, i)
     eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
-    desc = pg.build_descriptor(eng, out_dtype=out_dtype, **v.frame_kwargs(i, **over))
+    desc = pg.build_descriptor(eng, out_dtype=out_dtype, exact_samplers=exact_samplers, **v.frame_kwargs(i, **over))
     eng.ctx.upload(0, desc)
     assert eng.ctx.ramp_variant(0) == want_variant
     eng.ctx.run(0)
@@ -139,6 +139,65 @@ def test_sky_draws_largest_deviation_and_tail_frequencies():
     bad = xs.check(t, "sky")
     assert not bad, "; ".join(bad) + "\n%r" % s
     assert k_max < 60.0            # electrons above the mean, at rates of 14-50 per interval: the runaway was +500
+
+
+SKY_VARIANTS = {
+    #            sky e-/s  exact   out        the instantiation it must run
+    "exact_f64": (5.0,     True,   np.float64, "k_ramp_wide<double, false, 1, false>"),
+    "direct":    (20.0,    False,  np.float32, "k_ramp_wide<float, true, 0, false>"),
+    "pieces":    (5.0,     False,  np.float32, "k_ramp<float, true, 2, false, false>"),
+}
+
+
+def hot_sky_visit(n_exposures):
+    """cfg4 over a master sky with hot pixels (x 3 ... x 50 of their neighbours): such a pixel lies far above its level,
+    its remainder mean is tens to thousands of electrons, and the host selects the sampler that draws the remainder in
+    pieces of mean <= 16 (k_ramp.h sky_draw, PIECES; host_plan.h plan_sky)."""
+    if "hot" not in _plain:
+        cal = calibration.CalibrationSet.synthetic(11)
+        rng = np.random.default_rng(77)
+        sky = cal.sky["G141"]
+        yy, xx = rng.integers(0, 1014, 40), rng.integers(0, 1014, 40)
+        sky[yy, xx] *= np.repeat(np.float32([3.0, 10.0, 25.0, 50.0]), 10)
+        _plain["hot"] = (cal, (yy, xx))
+    cal, where = _plain["hot"]
+    return synthetic.Visit("cfg4", detector.WFC3_IR(), grism.G141(cal), cal, n_exposures=n_exposures), where
+
+
+@pytest.mark.parametrize("name", list(SKY_VARIANTS))
+def test_sky_draws_of_the_other_samplers(name):
+    # the same two questions of the sky's other samplers: the exact-math alias path with float64 reads (parity runs),
+    # the DIRECT per-pixel sampler a bright sky falls back to (rates that fit no alias table: Knuth below 10, PTRS above,
+    # lane-asynchronously into LDS), and the alias path whose remainder is drawn in PIECES (hot pixels of the master sky)
+    rate, exact, out_dtype, variant = SKY_VARIANTS[name]
+    if name == "pieces":
+        v, (hy, hx) = hot_sky_visit(3)
+    else:
+        v, (hy, hx) = helpers.make_visit("cfg4", n_exposures=3), (None, None)
+    rng = np.random.default_rng(11)
+    lam = sky_rates(v, rate)
+    t, k_max, hot = None, 0.0, []
+    for i in range(3):
+        reads = run_exposure(v, i, variant, out_dtype=out_dtype, sky_background=rate, exact_samplers=exact, **ONLY_SKY)
+        e = np.rint(reads[:, 5:-5, 5:-5] * GAIN)
+        assert np.abs(reads[:, 5:-5, 5:-5] * GAIN - e).max() < 0.05        # (float32 reads of up to 4e4 electrons)
+        for r in range(1, reads.shape[0]):
+            k = e[r] - e[r - 1]
+            assert k.min() >= 0
+            k_max = max(k_max, float(((k - lam[r - 1]) / np.sqrt(lam[r - 1])).max()))
+            tr = xs.poisson_tails(k, lam[r - 1], rng)
+            t = tr if t is None else t.merged(tr)
+            if hy is not None:
+                hot.append(((k - lam[r - 1]) / np.sqrt(lam[r - 1]))[hy, hx])
+    s = xs.summary(t)
+    s["largest_excess_sigma"] = k_max
+    if hot:
+        z = np.concatenate(hot)               # 40 hot pixels x 15 intervals x 3 exposures, means of 40 ... 2600 electrons
+        s["hot_pixel_draws"], s["hot_pixel_z_mean"], s["hot_pixel_z_std"] = int(z.size), float(z.mean()), float(z.std())
+        assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1.0) < 5 / np.sqrt(2.0 * z.size)
+    report("sky/" + name, **s)
+    bad = xs.check(t, "sky " + name)
+    assert not bad, "; ".join(bad) + "\n%r" % s
 
 
 def background_law(v, sky_ct_s):
