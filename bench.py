@@ -167,9 +167,10 @@ def cpu_baseline(visit, budget_s=20.0):
             "thrower_electrons_per_s": electrons / float(np.sum(t_sub))}
 
 
-def timed_pass(ctx, slot_of, steps, warmup, sync=None, events_every=0):
+def timed_pass(ctx, slot_of, steps, warmup, sync=None, events_every=0, device_sync=None):
     """One rank's timed pass: `warmup` untimed exposures, synchronise (`sync`: the caller's barrier + device
-    synchronise; default the context's own), exactly `steps` exposures, synchronise -> elapsed seconds by this
+    synchronise; default the context's own), exactly `steps` exposures, synchronise (the context's streams, then
+    `device_sync` -- bench.py passes torch.cuda.synchronize, the contract's bracket) -> elapsed seconds by this
     process's clock.  Every device-complete rate of bench.py AND of scripts/bench_configs.py goes through here."""
     sync = sync or ctx.synchronize
     for j in range(warmup):
@@ -181,6 +182,8 @@ def timed_pass(ctx, slot_of, steps, warmup, sync=None, events_every=0):
             ctx.profile_enable((j - warmup) % events_every == 0)
         ctx.run(slot_of(j))
     ctx.synchronize()
+    if device_sync is not None:
+        device_sync()
     return time.perf_counter() - t0
 
 
@@ -346,7 +349,7 @@ def main():
         """Exactly `steps` exposures after `warmup` untimed ones, bracketed by barrier + synchronise;
         returns the elapsed seconds (max over ranks).  events_every = n: the selected kernels' HIP events are
         recorded on every n-th exposure only (an event pair costs the stream ~5 us either side of the kernel)."""
-        elapsed = timed_pass(ctx, slot_of, steps, warmup, sync_all, events_every)
+        elapsed = timed_pass(ctx, slot_of, steps, warmup, sync_all, events_every, device_sync=torch.cuda.synchronize)
         own_rates.append(steps / elapsed if (steps and elapsed > 0) else 0.0)    # this rank's own exposures/s
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64)
