@@ -236,12 +236,12 @@ def dry_run(rank, world):
     """`--dry-run`: the rendezvous of the N-rank path without any GPU work (gloo barrier, max-reduce, gather), so
     that the launcher and the ranks' meeting can be rehearsed at any N on a CPU.  Prints a line that cannot be
     mistaken for a measurement."""
+    if os.environ.get("WAYNE_DRY_RUN_FAIL_RANK") == str(rank):     # rehearsal of a rank that dies before the rendezvous
+        raise SystemExit(3)                                       # (tests/test_bench_contract.py: the launcher must fail fast)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     from wayne_amd import launch
-    if os.environ.get("WAYNE_DRY_RUN_FAIL_RANK") == str(rank):     # rehearsal of a rank that dies before the rendezvous
-        raise SystemExit(3)                                       # (tests/test_bench_contract.py: the launcher must fail fast)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=launch.rendezvous_timeout())
     dist.barrier()
     t = torch.tensor([float(rank)], dtype=torch.float64)
