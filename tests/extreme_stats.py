@@ -144,9 +144,9 @@ def summary(t):
 
 
 def thrower_window_moments(counts, x, y, ratio, sl, sh, x0, x1, y0, y1):
-    """Exact mean of every pixel of the window [y0, y1) x [x0, x1) (frame coordinates) of the reference thrower's
-    frame for FIXED counts (the law of tests/ensemble_stats.analytic_moments, on a window instead of the whole frame:
-    pyparallel_menu.c:87-108).  -> (mean[y1-y0, x1-x0], expected electrons landing in the window)"""
+    """Exact mean and sum of squared cell probabilities of every pixel of the window [y0, y1) x [x0, x1) (frame
+    coordinates) of the reference thrower's frame for FIXED counts (the law of tests/ensemble_stats.analytic_moments, on
+    a window instead of the whole frame: pyparallel_menu.c:87-108).  -> (mean, second): variance = mean - second."""
     counts = np.asarray(counts, dtype=np.float64)
     n_wide = np.trunc(counts * ratio)
     n_narrow = counts - n_wide
@@ -160,6 +160,101 @@ def thrower_window_moments(counts, x, y, ratio, sl, sh, x0, x1, y0, y1):
             p[:, :1 - first] = 0.0
         return p
 
-    mean = (axis(y, sh, ey, y0) * n_wide[:, None]).T @ axis(x, sh, ex, x0)
-    mean += (axis(y, sl, ey, y0) * n_narrow[:, None]).T @ axis(x, sl, ex, x0)
-    return mean
+    pyh, pxh, pyl, pxl = axis(y, sh, ey, y0), axis(x, sh, ex, x0), axis(y, sl, ey, y0), axis(x, sl, ex, x0)
+    mean = (pyh * n_wide[:, None]).T @ pxh + (pyl * n_narrow[:, None]).T @ pxl
+    second = ((pyh ** 2) * n_wide[:, None]).T @ (pxh ** 2) + ((pyl ** 2) * n_narrow[:, None]).T @ (pxl ** 2)
+    return mean, second
+
+
+def thrower_pixel_terms(counts, x, y, ratio, sl, sh, X, Y, p_min=1e-13):
+    """The binomials whose sum is the count of pixel (Y, X) (frame coordinates, both >= 1): for every bin of every
+    sub-sample handed in (counts, x, y: [sub-samples][bins]) the wide component Binomial(N_b, P_h) and the narrow one
+    Binomial(n_b - N_b, P_l), N_b = (int)(n_b ratio_b) (pyparallel_menu.c:89-107).  -> (n[], p[]) with p > p_min."""
+    counts = np.asarray(counts, dtype=np.float64)
+    n_wide = np.trunc(counts * ratio[None, :])
+    n_narrow = counts - n_wide
+
+    def cell(pos, sig, c):
+        return special.ndtr((c + 1.0 - pos) / sig[None, :]) - special.ndtr((c - pos) / sig[None, :])
+
+    ph = cell(x, sh, float(X)) * cell(y, sh, float(Y))
+    pl = cell(x, sl, float(X)) * cell(y, sl, float(Y))
+    n = np.concatenate([n_wide.ravel(), n_narrow.ravel()])
+    p = np.concatenate([ph.ravel(), pl.ravel()])
+    keep = (p > p_min) & (n > 0)
+    return n[keep], p[keep]
+
+
+def pb_pmf_fft(n, p):
+    """Exact pmf of S = sum_i Binomial(n_i, p_i) on 0 .. M-1 by the FFT of its characteristic function (M holds the mean
+    + 14 sigma).  The yardstick of pb_tail_saddle in tests/test_extremes_cpu.py -- too slow for a million pixels."""
+    n = np.asarray(n, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    mean = (n * p).sum()
+    sd = np.sqrt((n * p * (1 - p)).sum())
+    M = 1 << int(np.ceil(np.log2(max(64.0, mean + 14 * sd + 64))))
+    e = np.exp(2j * np.pi * np.arange(M) / M) - 1
+    logphi = np.zeros(M, dtype=complex)
+    for i0 in range(0, n.size, 1024):
+        logphi += (n[i0:i0 + 1024, None] * np.log1p(p[i0:i0 + 1024, None] * e[None, :])).sum(axis=0)
+    return np.maximum(np.real(np.fft.fft(np.exp(logphi))) / M, 0.0)
+
+
+def pb_tail_saddle(k, n, p, upper=True):
+    """P(S >= k) (upper) or P(S <= k) (lower) of S = sum_i Binomial(n_i, p_i): the Lugannani-Rice saddlepoint formula
+    with Daniels' lattice correction (u = (1 - e^-s) sqrt(K''(s))), applied to S or to -S; exact at the edge of the
+    support (k <= 1 from below).  Relative error ~1e-3 (upper tails) .. 6e-2 (lower tails a few counts from zero) beyond 3 sigma for means of 20 .. 5000 (against
+    pb_pmf_fft: tests/test_extremes_cpu.py) -- ample for tail probabilities compared with bounds decades away."""
+    n = np.asarray(n, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    mean = (n * p).sum()
+    var = (n * p * (1 - p)).sum()
+    if upper and k <= 0:
+        return 1.0
+    if not upper:
+        if k < 0:
+            return 0.0
+        if k <= 1:
+            p0 = np.exp((n * np.log1p(-p)).sum())
+            return float(p0 if k == 0 else p0 * (1.0 + (n * p / (1 - p)).sum()))
+    sgn = 1.0 if upper else -1.0
+    kk = sgn * k
+    if sgn * mean >= kk:                 # not in this tail at all: the normal value does (callers only ask beyond 3 sigma)
+        return float(stats.norm.sf((kk - sgn * mean - 0.5) / np.sqrt(var)))
+
+    def K012(s):
+        es = np.exp(sgn * s)
+        d = 1 - p + p * es
+        q = p * es / d
+        return (n * np.log(d)).sum(), sgn * (n * q).sum(), (n * q * (1 - q)).sum()
+
+    s = (kk - sgn * mean) / var
+    for _ in range(60):
+        K0, K1, K2 = K012(s)
+        ds = (kk - K1) / K2
+        s += ds
+        if abs(ds) < 1e-12 * max(1.0, abs(s)):
+            break
+    K0, K1, K2 = K012(s)
+    w = np.sqrt(max(2 * (s * kk - K0), 0.0))
+    u = (1 - np.exp(-s)) * np.sqrt(K2)
+    return float(stats.norm.sf(w) + stats.norm.pdf(w) * (1 / u - 1 / w))
+
+
+def poisson_binomial_tails(k, z, terms_of, rng, z_pre=3.0):
+    """Randomised tail probabilities of the counts k[i] whose law is a sum of binomials: `terms_of(i)` -> (n[], p[]);
+    z[i] = (k - mean) / sigma of that law selects the candidates.  -> Tails over all of k."""
+    k = np.asarray(k, dtype=np.float64)
+    z = np.asarray(z, dtype=np.float64)
+    hi, lo = np.nonzero(z > z_pre)[0], np.nonzero(z < -z_pre)[0]
+    v = rng.random(k.size)
+    u_hi, u_lo = np.empty(hi.size), np.empty(lo.size)
+    for j, i in enumerate(hi):
+        n, p = terms_of(i)
+        a, b = pb_tail_saddle(k[i] + 1, n, p, True), pb_tail_saddle(k[i], n, p, True)      # P(S > k), P(S >= k)
+        u_hi[j] = a + v[i] * max(b - a, 0.0)
+    for j, i in enumerate(lo):
+        n, p = terms_of(i)
+        a, b = pb_tail_saddle(k[i] - 1, n, p, False), pb_tail_saddle(k[i], n, p, False)     # P(S < k), P(S <= k)
+        u_lo[j] = a + (1.0 - v[i]) * max(b - a, 0.0)
+    return Tails(k.size, u_hi, u_lo, float(stats.norm.sf(z_pre)) * 0.5, hi, lo)

@@ -111,8 +111,55 @@ def test_window_moments_agree_with_the_whole_frame_law():
     g = load_golden_psf("s64_t3")
     n = g["nr"]
     mean, _, _, total = es.analytic_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], n)
-    win = xs.thrower_window_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], 0, n, 0, n)
+    _, var, _, _ = es.analytic_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], n)
+    win, second = xs.thrower_window_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], 0, n, 0, n)
     np.testing.assert_allclose(win, mean, rtol=1e-12, atol=1e-14)
-    sub = xs.thrower_window_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], 5, 40, 3, 33)
+    np.testing.assert_allclose(win - second, var, rtol=1e-10, atol=1e-14)
+    sub, _ = xs.thrower_window_moments(g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], 5, 40, 3, 33)
     np.testing.assert_allclose(sub, mean[3:33, 5:40], rtol=1e-12, atol=1e-14)
     assert mean[0].sum() == 0 and mean[:, 0].sum() == 0 and abs(mean.sum() - total) < 1e-9
+    # the binomials of ONE pixel add up to that pixel's moments
+    Y, X = np.unravel_index(np.argmax(mean), mean.shape)
+    nn, pp = xs.thrower_pixel_terms(g["counts"][None, :], g["x"][None, :], g["y"][None, :], g["ratio"], g["sl"], g["sh"], X, Y)
+    assert abs((nn * pp).sum() - mean[Y, X]) < 1e-9 * mean[Y, X] and abs((nn * pp * (1 - pp)).sum() - var[Y, X]) < 1e-9 * var[Y, X]
+
+
+def test_saddlepoint_tails_of_a_sum_of_binomials_against_the_exact_pmf():
+    # a pixel's electron count is a sum of thousands of binomials (one per bin, component and sub-sample): its exact
+    # tails by the lattice saddlepoint formula, against the pmf from the FFT of the characteristic function and, for a
+    # single binomial, against scipy -- over means of 20 ... 5000 electrons and 3 ... 6 sigma on both sides
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for trial in range(24):
+        m = int(rng.integers(50, 3000))
+        n = rng.integers(1, 2000, m).astype(float)
+        p = np.concatenate([rng.uniform(0, 0.4, m // 3), 10 ** rng.uniform(-8, -2, m - m // 3)])
+        if trial % 3 == 0:
+            n = n // 50 + 1
+        p = p * min(1.0, 10 ** rng.uniform(1.3, 3.7) / (n * p).sum())
+        pmf = xs.pb_pmf_fft(n, p)
+        mean, sd = (n * p).sum(), np.sqrt((n * p * (1 - p)).sum())
+        ge, le = np.cumsum(pmf[::-1])[::-1], np.cumsum(pmf)
+        for zz in (3.0, 4.0, 5.0, 6.0):
+            k = int(round(mean + zz * sd))
+            if ge[k] > 1e-10:
+                worst = max(worst, abs(xs.pb_tail_saddle(k, n, p, True) / ge[k] - 1.0))
+            k = int(round(mean - zz * sd))
+            if k >= 0 and le[k] > 1e-10:
+                worst = max(worst, abs(xs.pb_tail_saddle(k, n, p, False) / le[k] - 1.0))
+    assert worst < 0.08, worst          # (the worst cases are lower tails of means near 20, a few counts from zero)
+    for N, P, k in [(5000, 0.3, 1650), (5000, 0.3, 1350), (200, 0.02, 15), (100000, 0.001, 150), (300, 0.1, 0), (300, 0.1, 1)]:
+        if k > N * P:
+            assert abs(xs.pb_tail_saddle(k, [N], [P], True) / stats.binom.sf(k - 1, N, P) - 1) < 2e-3
+        else:
+            assert abs(xs.pb_tail_saddle(k, [N], [P], False) / stats.binom.cdf(k, N, P) - 1) < 2e-3
+    # and as a test of a SAMPLER: binomial sums drawn by numpy pass; the same sums with 6 % extra spread do not
+    n = np.full(100, 160.0)
+    p = rng.uniform(0.01, 0.3, 100)
+    mean, sd = (n * p).sum(), np.sqrt((n * p * (1 - p)).sum())
+    S = rng.binomial(n.astype(int)[None, :], p[None, :], size=(200000, 100)).sum(axis=1).astype(float)
+    t = xs.poisson_binomial_tails(S, (S - mean) / sd, lambda i: (n, p), rng)
+    assert not xs.check(t, "binomial sums")
+    S2 = np.rint(mean + (S - mean) * 1.06)
+    t2 = xs.poisson_binomial_tails(S2, (S2 - mean) / sd, lambda i: (n, p), rng)
+    assert xs.check(t2, "6 % too wide")

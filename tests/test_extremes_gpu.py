@@ -298,16 +298,20 @@ def test_stellar_counts_largest_deviation_and_tail_frequencies():
 
 def test_thrower_largest_single_pixel_deviation_at_full_size():
     # k_lane + k_narrow on the benchmarked exposure (10^9 electrons): every accumulator of every read interval against
-    # the exact mean of the reference's law for the counts and positions the device itself reports (flat off: integer
-    # electrons).  A pixel's count is a sum of independent Bernoullis, bounded in both tails by the Poisson law of its
-    # mean: no accumulator may hold a count that bound finds impossible, and none may be touched outside the window.
+    # the EXACT law of the reference's thrower for the counts and positions the device itself reports (flat off: integer
+    # electrons).  A pixel's count is a sum of independent binomials -- per bin, component and sub-sample,
+    # pyparallel_menu.c:87-108 -- whose tails come from the lattice saddlepoint formula (extreme_stats.pb_tail_saddle,
+    # pinned to the exact pmf on the CPU); pixels with fewer than 20 expected electrons (cell probabilities < 3e-4: the
+    # law is Poisson to that precision) take the Poisson tails.  Asked of every accumulator: the largest deviation is one
+    # the law produces, the tails at 1e-4 / 1e-5 are populated as the law says (the binomial samplers of k_narrow and
+    # the Box-Muller of k_lane, in production math, far from their means), and nothing lands outside +-48 px of the trace.
     v = helpers.make_visit("cfg4", n_exposures=2)
     g = v.grism
     i0, i1 = wo.crop_spectrum_ind(g.wl_limits[0], g.wl_limits[1], v.wl.copy())
     s_wl = v.wl[i0:i1]
     ratio, sl, sh = (np.polyval(p.coeffs, s_wl) for p in (g.psf_ratio_poly, g.psf_sigmal_poly, g.psf_sigmah_poly))
     rng = np.random.default_rng(3)
-    t = None
+    t_dim = t_bright = None
     worst_excess = 0.0
     for i in range(2):
         rec = {}
@@ -324,22 +328,37 @@ def test_thrower_largest_single_pixel_deviation_at_full_size():
             y0, y1 = int(np.floor(y[ks].min())) - 48, int(np.floor(y[ks].max())) + 49
             x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, S - 10), min(y1, S - 10)
             mean = np.zeros((y1 - y0, x1 - x0))
+            second = np.zeros_like(mean)
             for k in ks:
-                mean += xs.thrower_window_moments(counts[k], x[k], y[k], ratio, sl, sh, x0, x1, y0, y1)
+                m_, s_ = xs.thrower_window_moments(counts[k], x[k], y[k], ratio, sl, sh, x0, x1, y0, y1)
+                mean += m_
+                second += s_
             got = acc[r][5 + y0:5 + y1, 5 + x0:5 + x1]
             outside = acc[r].sum() - got.sum()
             assert outside == 0.0, "read %d: %g electrons outside the +-48 px window" % (r, outside)
             total += got.sum()
             live = mean > 1e-9
             assert not got[~live].any()
-            tr = xs.bernoulli_sum_tails(got[live], mean[live], rng)
-            t = tr if t is None else t.merged(tr)
-            worst_excess = max(worst_excess, float(((got - mean) / np.sqrt(mean + 1.0)).max()))
+            dim = live & (mean < 20.0)
+            tr = xs.poisson_tails(got[dim], mean[dim], rng)
+            t_dim = tr if t_dim is None else t_dim.merged(tr)
+            # the bright pixels: exact tails for the candidates (|z| > 3 of the exact variance)
+            by, bx = np.nonzero(mean >= 20.0)
+            kb, mb = got[by, bx], mean[by, bx]
+            zb = (kb - mb) / np.sqrt(mb - second[by, bx])
+
+            def terms_of(j):
+                return xs.thrower_pixel_terms(counts[ks], x[ks], y[ks], ratio, sl, sh, x0 + bx[j], y0 + by[j])
+
+            tb = xs.poisson_binomial_tails(kb, zb, terms_of, rng)
+            t_bright = tb if t_bright is None else t_bright.merged(tb)
+            worst_excess = max(worst_excess, float(np.abs(zb).max()))
         assert abs(total - counts.sum()) <= 1e-6 * counts.sum()                 # (the spectrum sits well inside the frame)
-    s = xs.summary(t)
-    report("thrower/cfg4", largest_excess_sigma=worst_excess, **s)
-    bad = xs.check(t, "thrower", exact_frequencies=False)
-    assert not bad, "; ".join(bad) + "\n%r" % s
+    sd, sb = xs.summary(t_dim), xs.summary(t_bright)
+    report("thrower/cfg4", largest_abs_z_exact_variance=worst_excess, dim_pixels=sd, bright_pixels=sb)
+    bad = xs.check(t_dim, "thrower, pixels below 20 e-") + xs.check(t_bright, "thrower, pixels from 20 e-", qs=(1e-4, 1e-5))
+    assert not bad, "; ".join(bad) + "\n%r\n%r" % (sd, sb)
+    assert t_bright.n > 2e5 and t_dim.n > 2e5 and 4.0 < worst_excess < 6.5
 
 
 @pytest.mark.parametrize("path", ["k_prep_sub", "k_lane_fused"])
