@@ -103,14 +103,18 @@ def device_ensemble(ctx, name, mode):
                                    rng_mode=mode, exposure=m, subsample=m % 5).reshape(n, n) for m in range(m_dev)])
 
 
-def extreme_figures(A, mean, s, label, frames=64):
+def extreme_figures(A, mean, var, s, label, inputs, frames=64):
     """The LARGEST deviations of an ensemble against the exact law (`z_max` was computed by
     ensemble_stats and never asserted): (a) the largest standardised pixel mean, against the normal extreme-value law of
     n_bright pixels -- with room for the skewness of a mean of M counts whose sum is >= 400 (Cornish-Fisher: +0.2 at 5
-    sigma); (b) every pixel count of the first `frames` frames, one by one, against the Poisson law of its exact mean --
-    an upper bound of both tails of the true law (a sum of independent Bernoullis): no count may be one that bound finds
-    impossible (family-wise 1e-3), and the tails may not be heavier than it allows."""
+    sigma); (b) every pixel count of the first `frames` frames, one by one, against the law of that pixel: a sum of
+    independent binomials, one per bin and component (pyparallel_menu.c:87-108) -- exact tails by the lattice saddlepoint
+    formula for the pixels with at least 20 expected electrons (extreme_stats.poisson_binomial_tails): no count may be one the
+    law does not produce (family-wise 1e-3) and the tails at 1e-4 / 1e-5 must be populated as the law says, on both sides;
+    below 20 electrons the Poisson law of the pixel's mean, which bounds both tails of the true one.  The reference's
+    own frames are put through the same function: what pins the law's restatement, tails included, to the reference."""
     from scipy import stats
+    k_in, counts = inputs
     bad = []
     n = max(s["n_bright"], 1)
     z_bound = float(stats.norm.isf(1e-3 / (2.0 * n))) + 0.35
@@ -121,9 +125,29 @@ def extreme_figures(A, mean, s, label, frames=64):
     if F[:, ~live].any():
         bad.append("%s: electrons where the law puts none" % label)
     rng = np.random.default_rng(12)
-    t = xs.bernoulli_sum_tails(F[:, live], np.broadcast_to(mean[live], F[:, live].shape), rng)
-    bad += xs.check(t, label + " (per frame and pixel)", exact_frequencies=False)
-    return bad, dict(z_max=s["z_max"], z_max_bound=z_bound, **xs.summary(t))
+    dim = live & (mean < 20.0)
+    t_dim = xs.poisson_tails(F[:, dim], np.broadcast_to(mean[dim], F[:, dim].shape), rng)
+    by, bx = np.nonzero(mean >= 20.0)
+    kb = F[:, by, bx]                                         # [frame][bright pixel]
+    zb = (kb - mean[by, bx]) / np.sqrt(var[by, bx])
+    cache = {}
+
+    def terms_of(j):
+        px = j % by.size
+        if px not in cache:
+            cache[px] = xs.thrower_pixel_terms(counts[None, :].astype(np.float64), k_in["x"][None, :], k_in["y"][None, :],
+                                               k_in["ratio"], k_in["sl"], k_in["sh"], bx[px], by[px])
+        return cache[px]
+
+    t_bright = xs.poisson_binomial_tails(kb.ravel(), zb.ravel(), terms_of, rng)
+    # (below 20 e- a thinly populated bin can still put a third of its electrons into one pixel: there the Poisson law
+    # is the BOUND of both tails it always is, not the law -- impossible draws and too-heavy tails only)
+    bad += xs.check(t_dim, label + " (per frame and pixel, below 20 e-)", exact_frequencies=False)
+    bad += xs.check(t_bright, label + " (per frame and pixel, from 20 e-)")
+    fig = dict(z_max=s["z_max"], z_max_bound=z_bound, largest_abs_z_per_frame=float(np.abs(zb).max()) if zb.size else 0.0)
+    fig.update({"dim_" + k_: v_ for k_, v_ in xs.summary(t_dim).items()})
+    fig.update({"bright_" + k_: v_ for k_, v_ in xs.summary(t_bright).items()})
+    return bad, fig
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -137,7 +161,7 @@ def test_reference_ensemble_follows_the_exact_moments(name):
     report("psf/%s/reference_vs_exact_moments" % name, **dict(s, **w))
     bad = es.check_moments(s) + es.check_wings_against_moments(w)
     # the extreme-value figures of the REFERENCE's own frames: the yardstick the device's are held to below
-    bad_x, fig = extreme_figures(A, mean, s, "reference C")
+    bad_x, fig = extreme_figures(A, mean, var, s, "reference C", case_inputs(name)[:2])
     report("psf/%s/reference_extremes" % name, **fig)
     assert not bad + bad_x, "; ".join(bad + bad_x)
 
@@ -160,7 +184,7 @@ def test_production_thrower_against_reference_ensemble(gpu_ctx, name, mode):
     report("psf/%s/%s_vs_reference" % (name, tag), **two)
     report("psf/%s/%s_vs_exact_moments" % (name, tag), **one)
     # the largest single-pixel deviations, held to the same bounds as the reference's own frames
-    bad_x, fig = extreme_figures(B, mean, one, tag)
+    bad_x, fig = extreme_figures(B, mean, var, one, tag, (k, counts))
     report("psf/%s/%s_extremes" % (name, tag), **fig)
     bad += bad_x
     if name == "bright":

@@ -340,6 +340,7 @@ def test_thrower_largest_single_pixel_deviation_at_full_size():
             live = mean > 1e-9
             assert not got[~live].any()
             dim = live & (mean < 20.0)
+            assert (second[dim] / mean[dim]).max() < 3e-3      # (the electron-weighted cell probability: Poisson to that)
             tr = xs.poisson_tails(got[dim], mean[dim], rng)
             t_dim = tr if t_dim is None else t_dim.merged(tr)
             # the bright pixels: exact tails for the candidates (|z| > 3 of the exact variance)
