@@ -60,15 +60,18 @@ def reads_of(v, out_dtype, **over):
 
 @pytest.mark.parametrize("out_dtype", [np.float64, np.float32], ids=["f64", "f32"])
 def test_non_linearity_solves_the_references_quartic(out_dtype):
-    v = lin_visit("cfg4", E=8e9)                      # up to ~30 000 DN in the last read: the quartic terms matter
+    v = lin_visit("cfg4", E=4e9)                      # up to ~77 000 DN in the last read: the detector's whole range
     S = v.detector.full_size(v.SUBARRAY)
-    lin = [np.asarray(p, dtype=np.float64)[512 - S // 2:512 + S // 2, 512 - S // 2:512 + S // 2] for p in v.calibration.lin]
+    # the coefficient planes stay float32, as the reference's are: `1 + c1`, `2 * c2` ... are then float32 sums and
+    # products in numpy, and only meet the float64 pixel values afterwards (detector.py:340-341, evaluated as written)
+    lin = [np.asarray(p, dtype=np.float32)[512 - S // 2:512 + S // 2, 512 - S // 2:512 + S // 2] for p in v.calibration.lin]
     px = reads_of(v, out_dtype, add_non_linear=False, clip_values_det_limits=False)
     u = reads_of(v, out_dtype, add_non_linear=True, clip_values_det_limits=False)
-    assert px[-1].max() > 2.5e4 and not u[0].any() and not px[0].any()
+    assert 6e4 < px[-1].max() < 1.2e5 and not u[0].any() and not px[0].any()
     c1, c2, c3, c4 = lin
-    forward = u * (1 + c1 + u * (c2 + u * (c3 + u * c4)))                       # detector.py:340
-    slope = 1 + c1 + u * (2 * c2 + u * (3 * c3 + u * 4 * c4))                   # its derivative (:341)
+    forward = u * (1 + c1 + u * (c2 + u * (c3 + c4 * u)))                       # detector.py:340
+    slope = 1 + c1 + 2 * c2 * u + 3 * c3 * u * u + 4 * c4 * u * u * u           # its derivative (:341)
+    assert forward.dtype == np.float64 and (1 + c1).dtype == np.float32
     # Newton's stop |du| < 1e-3 in u is |f(u) - px| < 1e-3 f'(u) in px; float32 reads add their own rounding
     tol = 1e-3 * np.abs(slope) + (2e-7 * np.abs(px) + 0.02 if out_dtype == np.float32 else 1e-9 * np.abs(px) + 1e-9)
     err = np.abs(forward - px)
