@@ -125,3 +125,52 @@ def test_initial_bias_is_added_to_every_read_of_a_256_subarray():
     v128 = helpers.make_visit("tiny128")
     np.testing.assert_array_equal(reads_of(v128, np.float64, add_initial_bias=True),
                                   reads_of(v128, np.float64, add_initial_bias=False))
+
+
+@pytest.mark.parametrize("name", ["cfg2", "stare_g102"])
+def test_flat_field_is_the_references_cubic_in_the_pixel_wavelength(name):
+    # G141.get_flat_field (grism.py:349-409): where a sub-sample's frame holds electrons it is multiplied by
+    #   f0 + f1 t + f2 t^2 + f3 t^3,   t = (wl_px - WMIN) / (WMAX - WMIN),   wl_px = a_w d + b_w
+    # with d the distance of the pixel along the trace of THAT sub-sample's star position -- `get_pixel_wl`, which the
+    # reference's own test values pin (tests/test_reference_goldens.py) -- evaluated into a float32 array (np.ones_like of
+    # a float32 plane).  A staring exposure has one sub-sample per read: with the pointing jitter ON every read has its
+    # own star position, and accumulators(flat on) = accumulators(flat off) x that read's flat, pixel by pixel -- the
+    # thrower's integers are the same in both runs.
+    if name == "stare_g102":
+        cal = helpers.calibration_set()
+        v = synthetic.Visit("cfg2", detector.WFC3_IR(), grism.G102(cal), cal, E=2.5e7)
+    else:
+        v = helpers.make_visit(name)
+    v.x_jitter, v.y_jitter = 0.3, 0.2                      # (pixels: every read's flat is visibly its own)
+    g = v.grism
+    rec_on, rec_off = {}, {}
+    pg = helpers.product_generator(v, 0)
+    for rec, flat in ((rec_on, True), (rec_off, False)):
+        pg.scanning_frame(out_dtype=np.float64, record=rec, **v.frame_kwargs(0, add_flat=flat, **QUIET))
+    on, off = rec_on["acc"], rec_off["acc"]
+    assert np.array_equal(rec_on["counts"], rec_off["counts"]) and np.abs(off - np.rint(off)).max() < 1e-6
+    assert v.K == on.shape[0] and np.array_equal(rec_on["read"], np.arange(v.K))       # one sub-sample per read
+    assert np.ptp(rec_on["x_ref"]) > 0.2 and np.ptp(rec_on["y_ref"]) > 0.1
+    cube = np.asarray(v.calibration.flat[g.name], dtype=np.float32)                    # (4, 1014, 1014)
+    wmin, wmax = v.calibration.flat_wl[g.name]
+    worst = 0.0
+    flats = []
+    for r in range(v.K):
+        wl_px = g.get_pixel_wl_whole_detector(rec_on["x_ref"][r], rec_on["y_ref"][r])
+        t = (wl_px - wmin) / (wmax - wmin)
+        flat = (cube[0] + (cube[1] * t) + (cube[2] * (t * t)) + (cube[3] * (t * t * t))).astype(np.float32).astype(np.float64)
+        flats.append(flat)
+        n = off[r][5:-5, 5:-5]
+        got = on[r][5:-5, 5:-5]
+        hit = n > 0
+        assert hit.sum() > 5000 and not got[~hit].any()
+        # (accumulators are fixed point, 2^-28 e-: one rounding per tile flush that touches the pixel -- a handful)
+        err = np.abs(got[hit] - n[hit] * flat[hit])
+        tight = 64 * 2.0 ** -28 + 1e-12 * n[hit]
+        worst = max(worst, float((err / n[hit]).max()))
+        # (a last-bit difference of the fp64 wavelength can move the float32 rounding of the flat by one ulp, 6e-8, in a
+        # pixel or two of a hundred thousand: allowed there, nowhere else)
+        assert (err <= tight + 1.3e-7 * n[hit]).all(), (r, float(err.max()))
+        assert int((err > tight).sum()) <= 2 + 1e-4 * hit.sum(), (r, int((err > tight).sum()))
+    # and the reads' flats really differ from one another where the star moved
+    assert max(float(np.abs(flats[0] - f).max()) for f in flats[1:]) > 1e-4
