@@ -174,3 +174,33 @@ def test_flat_field_is_the_references_cubic_in_the_pixel_wavelength(name):
         assert int((err > tight).sum()) <= 2 + 1e-4 * hit.sum(), (r, int((err > tight).sum()))
     # and the reads' flats really differ from one another where the star moved
     assert max(float(np.abs(flats[0] - f).max()) for f in flats[1:]) > 1e-4
+
+
+def test_order_of_the_post_ramp_stages():
+    # _post_exposure_reductions (exposure_generator.py:407-444): dark current -> non-linearity -> clip -> reference
+    # pixels -> + zero read -> read noise.  Two places where the ORDER shows in the numbers:
+    #  (1) the dark current goes in BEFORE the non-linearity: switching it on moves a read by f'(u)^-1 x dark, not by dark
+    #      (0.75 of it at 50 000 DN with these planes) -- its noise (err 0.02 DN) averages out over 10^4 pixels;
+    #  (2) the read noise goes on AFTER the clip: saturated pixels scatter about 78 000 DN with the read noise's sigma
+    #      instead of sitting on the limit.
+    v = lin_visit("cfg4", E=4e9)
+    S = v.detector.full_size(v.SUBARRAY)
+    c = [np.asarray(p, dtype=np.float64)[512 - S // 2:512 + S // 2, 512 - S // 2:512 + S // 2] for p in v.calibration.lin]
+    sci, _ = v.calibration.dark_frames(v.SUBARRAY, v.SAMPSEQ, v.read_times)
+    base = reads_of(v, np.float64, add_non_linear=True, clip_values_det_limits=False)
+    dark = reads_of(v, np.float64, add_non_linear=True, clip_values_det_limits=False, add_dark=True)
+    u = base[-1]
+    slope = 1 + c[0] + u * (2 * c[1] + u * (3 * c[2] + u * 4 * c[3]))
+    sel = (u > 3e4) & (u < 6e4)
+    assert sel.sum() > 3000
+    moved = (dark[-1] - base[-1])[sel]
+    want = (sci[-1].astype(np.float64) / slope)[sel]
+    se = 0.02 / np.sqrt(sel.sum())
+    assert abs(moved.mean() - want.mean()) < 6 * se + 1e-4, (float(moved.mean()), float(want.mean()))
+    assert want.mean() < 0.9 * float(sci[-1][sel].mean())                       # (the two orders are 10 % apart here)
+    # (2)
+    sat = reads_of(lin_visit("cfg4", E=3e10), np.float64, add_non_linear=False, clip_values_det_limits=True,
+                   add_read_noise=True)[-1]
+    top = sat[sat > 77000.0]
+    assert top.size > 1000 and top.max() > 78010.0 and top.min() < 77990.0
+    assert abs(np.median(top) - 78000.0) < 1.0 and abs(top.std() - 14.1 / 2.35) < 0.5
