@@ -180,7 +180,7 @@ def test_order_of_the_post_ramp_stages():
     # _post_exposure_reductions (exposure_generator.py:407-444): dark current -> non-linearity -> clip -> reference
     # pixels -> + zero read -> read noise.  Two places where the ORDER shows in the numbers:
     #  (1) the dark current goes in BEFORE the non-linearity: switching it on moves a read by f'(u)^-1 x dark, not by dark
-    #      (0.75 of it at 50 000 DN with these planes) -- its noise (err 0.02 DN) averages out over 10^4 pixels;
+    #      (0.95 of it at 30 000 - 60 000 DN with these planes) -- its noise (err 0.02 DN) averages out over 10^4 pixels;
     #  (2) the read noise goes on AFTER the clip: saturated pixels scatter about 78 000 DN with the read noise's sigma
     #      instead of sitting on the limit.
     v = lin_visit("cfg4", E=4e9)
@@ -197,7 +197,7 @@ def test_order_of_the_post_ramp_stages():
     want = (sci[-1].astype(np.float64) / slope)[sel]
     se = 0.02 / np.sqrt(sel.sum())
     assert abs(moved.mean() - want.mean()) < 6 * se + 1e-4, (float(moved.mean()), float(want.mean()))
-    assert want.mean() < 0.9 * float(sci[-1][sel].mean())                       # (the two orders are 10 % apart here)
+    assert want.mean() < 0.97 * float(sci[-1][sel].mean())                      # (the two orders are 5 % apart here: 0.35 DN)
     # (2)
     sat = reads_of(lin_visit("cfg4", E=3e10), np.float64, add_non_linear=False, clip_values_det_limits=True,
                    add_read_noise=True)[-1]
