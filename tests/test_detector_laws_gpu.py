@@ -198,9 +198,10 @@ def test_order_of_the_post_ramp_stages():
     se = 0.02 / np.sqrt(sel.sum())
     assert abs(moved.mean() - want.mean()) < 6 * se + 1e-4, (float(moved.mean()), float(want.mean()))
     assert want.mean() < 0.97 * float(sci[-1][sel].mean())                      # (the two orders are 5 % apart here: 0.35 DN)
-    # (2)
-    sat = reads_of(lin_visit("cfg4", E=3e10), np.float64, add_non_linear=False, clip_values_det_limits=True,
-                   add_read_noise=True)[-1]
-    top = sat[sat > 77000.0]
+    # (2) which pixels saturate is read off a run without clip and without noise
+    hot = lin_visit("cfg4", E=3e10)
+    free = reads_of(hot, np.float64, add_non_linear=False, clip_values_det_limits=False)[-1]
+    noisy = reads_of(hot, np.float64, add_non_linear=False, clip_values_det_limits=True, add_read_noise=True)[-1]
+    top = noisy[free > 79000.0]
     assert top.size > 1000 and top.max() > 78010.0 and top.min() < 77990.0
-    assert abs(np.median(top) - 78000.0) < 1.0 and abs(top.std() - 14.1 / 2.35) < 0.5
+    assert abs(top.mean() - 78000.0) < 6 * 6.0 / np.sqrt(top.size) and abs(top.std() - 14.1 / 2.35) < 0.3
