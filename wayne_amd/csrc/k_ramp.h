@@ -518,6 +518,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
       const float inv_gf = !interior ? 0.f : (gainvar ? 1.0f / g32 : (float)(1.0 / kGain));
       const float c1p = (1.0f + c1) - 1.0f;
       const float zf = (float)z;
+      const bool has_sky_px = skyv > 0.f;                  // (the pixel's own half of `skyv * bg > 0`: constant over the reads)
       uint32_t bg_prev = 0xFFFFFFFFu;                      // bits of the previous read's bg (a scalar, like bg)
       unsigned long long Q = 0ull;
       int ksum = 0;
@@ -556,7 +557,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
           Q += (unsigned long long)q;
           q_any = true;
         }
-        if (skyv * bg > 0.f) ksum += sky_draw_count_int(s_tab[tab + sky_lvl], sr, rn);   // (skyv = 0 off the sky)
+        if (has_sky_px && bg > 0.f) ksum += sky_draw_count_int(s_tab[tab + sky_lvl], sr, rn);   // (skyv = 0 off the sky; bg is the wave's)
         float zd = 0.f, zr = 0.f;
         uint32_t w0, w1;
         rn.next2(w0, w1);
@@ -567,7 +568,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
           e = fmaf((float)(int)(Q >> 32), 16.0f, fmaf((float)(uint32_t)Q, 3.725290298461914e-09f, e));
         }
         float v = e * inv_gf;
-        if (f_dark) v = v + fmaf((de > 0.f) ? de : 0.00001f, zd, ds);
+        if (f_dark) v = v + fmaf(de, zd, ds);              // (de: already max(err, 1e-5), see wayne_ctx_set_calibration)
         if (f_lin) v = nonlinear_gap_f32(v, c1p, c2, c3, c4, nl);
         if (f_clip) v = __builtin_amdgcn_fmed3f(v, (float)kMinCounts, (float)kMaxCounts);
         if (!interior) v = 0.f;                            // reference pixels (exposure.py:122-131)

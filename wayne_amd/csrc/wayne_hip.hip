@@ -758,7 +758,14 @@ int wayne_ctx_set_calibration(wayne_ctx* c, const wayne_calibration* k) {
   c->has_dark = k->dark_sci && k->dark_err;
   if (c->has_dark) {
     if ((rc = upload(c, c->dark_sci, k->dark_sci, SS * k->n_reads))) return rc;
-    if ((rc = upload(c, c->dark_err, k->dark_err, SS * k->n_reads))) return rc;
+    {
+      // `err <= 0 -> 1e-5` (detector.py:189-190) once, here, instead of a compare and a select per pixel and read in
+      // k_ramp: the plane in HBM already holds what the reference's np.where would hand to np.random.normal
+      std::vector<float> e(k->dark_err, k->dark_err + SS * k->n_reads);
+      for (float& x : e) if (!(x > 0.f)) x = 0.00001f;
+      if ((rc = upload(c, c->dark_err, e.data(), e.size()))) return rc;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the copy reads a local vector)
+    }
   }
   c->has_zero = k->zero_read != nullptr;
   if (c->has_zero)
