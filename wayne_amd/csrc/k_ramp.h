@@ -162,15 +162,24 @@ __device__ __forceinline__ float sky_draw(const uint32_t* tab, float lam_level, 
 __device__ __forceinline__ float nonlinear_gap_f32(float px, float c1p, float c2, float c3, float c4, NlState& st) {
   const float d1 = 1.0f + c1p, d2 = 2.0f * c2, d3 = 3.0f * c3, d4 = 4.0f * c4;
   float g = fmaf(px - st.v_prev, st.bend, st.gap);
-  float rinv = 1.0f;
-  for (int it = 0; it < 64; ++it) {
+  float rinv = 1.0f, step = 0.f;
+  auto newton = [&]() {
     const float u = px - g;
     const float h = fmaf(u, fmaf(u, fmaf(u, c4, c3), c2), c1p);
     const float fp_ = fmaf(u, fmaf(u, fmaf(u, d4, d3), d2), d1);
     rinv = __builtin_amdgcn_rcpf(fp_);
-    const float step = fmaf(u, h, -g) * rinv;
+    step = fmaf(u, h, -g) * rinv;
     g = g + step;
-    if (fabsf(step) < 1e-3f) break;
+  };
+  // The first evaluation stands outside the loop: from the warm start it is the only one practically every pixel needs,
+  // and as the first trip of a counted loop it paid for the loop's counter (a vector register, one v_subrev per trip)
+  // and its exec-mask bookkeeping on every read.  Same iterates, same stop, same cap of 64 evaluations.
+  newton();
+  if (!(fabsf(step) < 1e-3f)) {
+    for (int it = 1; it < 64; ++it) {
+      newton();
+      if (fabsf(step) < 1e-3f) break;
+    }
   }
   st.v_prev = px;
   st.gap = g;
