@@ -78,3 +78,38 @@ def test_two_contexts_on_two_threads_equal_the_serial_frames():
         np.testing.assert_array_equal(got[i][0], serial[i][0], err_msg="exposure %d" % i)
         np.testing.assert_array_equal(got[i][1], serial[i][1], err_msg="thrower call %d" % i)
     assert np.abs(serial[0][0] - serial[1][0]).max() > 1.0          # (different exposures: the comparison means something)
+
+
+def test_apply_psf_drop_in_from_several_python_threads():
+    """`pyparallel.apply_psf` keeps ONE context per device for the whole process; the reference's Cython function holds
+    the interpreter lock through its C call (pyparallel.pyx:14-38), the ctypes call does not -- the shim serialises its
+    callers instead.  Four threads, sixteen calls each with their own `test` seed, started together: every frame equals the
+    one a single thread gets."""
+    from wayne_amd import pyparallel
+    g = load_golden_psf("s128_t2")
+    args = (g["counts"], g["x"], g["y"], g["ratio"], g["sl"], g["sh"], g["nr"], g["nc"])
+    n_threads, n_calls = 4, 16
+    serial = {s: pyparallel.apply_psf(*args, g["test"] + s, g["threads"]) for s in range(n_threads * n_calls)}
+    got, errors = {}, []
+    barrier = threading.Barrier(n_threads)
+
+    def caller(t):
+        try:
+            barrier.wait(timeout=60)
+            for s in range(t, n_threads * n_calls, n_threads):
+                got[s] = pyparallel.apply_psf(*args, g["test"] + s, g["threads"])
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=caller, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+        assert not th.is_alive()
+    assert not errors, errors
+    assert sorted(got) == sorted(serial)
+    for s in serial:
+        np.testing.assert_array_equal(got[s], serial[s], err_msg="call %d" % s)
+    assert np.abs(serial[0] - serial[1]).max() > 0
+    np.testing.assert_array_equal(serial[0], np.asarray(g["frame"], dtype=np.float64).ravel())   # and seed 0 is the reference's golden frame

@@ -6,6 +6,7 @@ context is requested, this raises -- there is no CPU fallback.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -463,10 +464,14 @@ def host_sample_draws(seed, exposure, n_samples):
 
 
 _default_ctx = {}
+_default_ctx_lock = threading.Lock()
 
 
 def default_context(device=0):
-    """Process-wide context per device (created on first use)."""
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    """Process-wide context per device (created on first use; creation is serialised)."""
+    with _default_ctx_lock:
+        if device not in _default_ctx:
+            ctx = Context(device)
+            ctx.call_lock = threading.Lock()   # for callers that share it between threads (pyparallel.apply_psf)
+            _default_ctx[device] = ctx
+        return _default_ctx[device]

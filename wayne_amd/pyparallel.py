@@ -24,7 +24,11 @@ def apply_psf(counts, pos_x, pos_y, ratio_psf, sigmal_psf, sigmah_psf, NR, NC, t
     counts = np.asarray(counts)
     if counts.dtype.kind == "f":
         counts = np.trunc(counts)
+    # One process-wide context per device, and calls on one context are not thread-safe (include/wayne_hip.h): the
+    # reference's Cython function holds the interpreter lock for the whole call, the ctypes call releases it, so callers
+    # on several Python threads are serialised here instead.
     ctx = _lib.default_context(device)
-    frame = ctx.psf_apply(counts.astype(np.int32), pos_x, pos_y, ratio_psf, sigmal_psf, sigmah_psf,
-                          NR, NC, test, threads, rng_mode, exposure, subsample)
+    with ctx.call_lock:
+        frame = ctx.psf_apply(counts.astype(np.int32), pos_x, pos_y, ratio_psf, sigmal_psf, sigmah_psf,
+                              NR, NC, test, threads, rng_mode, exposure, subsample)
     return frame.astype(np.float64)  # pyparallel.pyx:31-34
