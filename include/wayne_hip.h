@@ -126,8 +126,8 @@ typedef struct wayne_grism_desc {
   double psf_sigmal_poly[4]; /*   (grism.py:85-90)                          */
   double psf_sigmah_poly[4];
   int n_sens;                /* sensitivity table (grism.py:97-106)         */
-  const double *sens_wl_um;  /* increasing, micron                          */
-  const double *sens_val;
+  const double *sens_wl_um;  /* micron; finite and non-decreasing (np.interp's precondition), */
+  const double *sens_val;    /* finite values: otherwise WAYNE_E_INVALID and nothing changes     */
   double flat_wmin, flat_wmax; /* WMIN / WMAX of the flat cube (grism.py:71-72), angstrom */
 } wayne_grism_desc;
 

@@ -6,7 +6,7 @@
 //   plan_harness <in> <out>
 //
 // Operations (little-endian; i32 code first):
-//   1 SET_GRISM  f64 trace[9] wlsol[9] p_ratio[4] p_sigl[4] p_sigh[4]; i32 n_sens; f64 sens_wl[n] sens_val[n]
+//   1 SET_GRISM  f64 trace[9] wlsol[9] p_ratio[4] p_sigl[4] p_sigh[4]; i32 n_sens; f64 sens_wl[n] sens_val[n]   -> i32 table_ok
 //   2 PLAN       i32 S sub_scale rng_mode W K R; f64 scale_factor; f64 wl[W] flux[W] x_ref[K] y_ref[K] dur_ms[K]; i32 sample_read[K]
 //   3 SKY        f64 sky_ct_s; i32 R; f64 read_dt[R]; i32 has_sky n_sorted; f32 sky_sorted[n]
 //   4 ALIAS      f64 lam
@@ -49,8 +49,12 @@ int main(int argc, char** argv) {
       std::vector<double> swl((size_t)n), sval((size_t)n);
       if (!get(swl.data(), (size_t)n) || !get(sval.data(), (size_t)n)) bad("sensitivity");
       g.n_sens = n;
+      // what wayne_ctx_set_grism answers (a table that fails is refused there) -- and the planner takes the table either
+      // way: whatever it holds, the interpolation must stay inside it
+      const bool ok = plan::sens_table_ok(swl.data(), sval.data(), n);
       est.set_grism(g, swl.data(), sval.data(), n);
       put1<int32_t>(1);
+      put1<int32_t>(ok ? 1 : 0);
     } else if (code == 2) {
       int32_t h[6];
       double scale = 1.;

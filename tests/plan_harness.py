@@ -116,7 +116,8 @@ class Batch(object):
             (code,) = take("i")
             if kind[0] == "grism":
                 assert code == 1
-                out.append({})
+                (ok,) = take("i")
+                out.append({"table_ok": bool(ok)})
             elif kind[0] == "plan":
                 assert code == 2
                 r = {}

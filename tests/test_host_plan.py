@@ -191,6 +191,63 @@ def test_negative_control_nan_wavelength_read_past_the_sensitivity_table():
         bad.run("nan")
 
 
+def test_malformed_sensitivity_tables_are_refused_and_never_read_past():
+    # np.interp's precondition (grism.py:116-118) is wayne_ctx_set_grism's: finite values at finite, non-decreasing
+    # wavelengths, or WAYNE_E_INVALID (plan::sens_table_ok).  And whatever a table holds, the planner's interpolation stays
+    # inside it: the same batch under AddressSanitizer with the refused tables in place.
+    rng = np.random.default_rng(11)
+    d = random_descriptor(rng)
+    d["wl"] = np.sort(d["wl"])
+    n = d["ga"]["sens_wl"].size
+    tables = {"good": (d["ga"]["sens_wl"], d["ga"]["sens_val"])}
+    for name, (i, v) in {"nan_last": (n - 1, np.nan), "nan_first": (0, np.nan), "nan_middle": (n // 2, np.nan),
+                         "inf_last": (n - 1, np.inf), "minus_inf_first": (0, -np.inf)}.items():
+        w = d["ga"]["sens_wl"].copy()
+        w[i] = v
+        tables[name] = (w, d["ga"]["sens_val"])
+    tables["decreasing"] = (d["ga"]["sens_wl"][::-1].copy(), d["ga"]["sens_val"])
+    tables["one_step_back"] = (np.concatenate([d["ga"]["sens_wl"][:5], d["ga"]["sens_wl"][3:]]),
+                               np.concatenate([d["ga"]["sens_val"][:5], d["ga"]["sens_val"][3:]]))
+    tables["shuffled"] = (rng.permutation(d["ga"]["sens_wl"]), d["ga"]["sens_val"])
+    v = d["ga"]["sens_val"].copy()
+    v[7] = np.nan
+    tables["nan_value"] = (d["ga"]["sens_wl"], v)
+    tables["repeated_wavelengths"] = (np.repeat(d["ga"]["sens_wl"][::2], 2), d["ga"]["sens_val"])      # allowed: non-decreasing
+    tables["one_entry"] = (d["ga"]["sens_wl"][:1], d["ga"]["sens_val"][:1])
+    tables["empty"] = (np.zeros(0), np.zeros(0))
+    batch, where = ph.Batch(), {}
+    for name, (w, val) in tables.items():
+        dd = dict(d, ga=dict(d["ga"], sens_wl=w, sens_val=val))
+        where[name] = add_plan(batch, dd)
+    res = batch.run()
+    for name, i in where.items():
+        assert res[i - 1]["table_ok"] == (name in ("good", "repeated_wavelengths", "one_entry", "empty")), name
+        assert res[i]["use_box"], name          # (the boxes do not depend on the sensitivity)
+    # the tables the ABI accepts give np.interp's rates
+    for name in ("good", "repeated_wavelengths", "one_entry"):
+        w, val = tables[name]
+        sens = np.interp(d["wl"], w, val)
+        rate = d["flux"] * sens * wo.bin_centers_to_widths(d["wl"]) * 1e4 * 1e-3
+        np.testing.assert_allclose(res[where[name]]["rate"], rate, rtol=1e-12, err_msg=name)
+
+
+def test_negative_control_nan_at_the_end_of_the_sensitivity_table():
+    # without the bracket's clamp (the harness variant that brings the round-1-4 interpolation back), a table ending in NaN
+    # sends the bisection to end() for every wavelength above its last finite entry: sens_val[n], reported here.
+    rng = np.random.default_rng(12)
+    d = random_descriptor(rng)
+    d["wl"] = np.sort(d["wl"])
+    w = np.linspace(d["wl"][0] - 0.3, d["wl"][0] - 0.1, d["ga"]["sens_wl"].size)   # (every bin lies above the last finite entry ...)
+    w[-1] = np.nan                                                                  # (... and the table's end is not a number)
+    dd = dict(d, ga=dict(d["ga"], sens_wl=w))
+    good, bad = ph.Batch(), ph.Batch()
+    i = add_plan(good, dd)
+    add_plan(bad, dd)
+    assert not good.run()[i - 1]["table_ok"]
+    with pytest.raises(ph.HarnessError, match="heap-buffer-overflow"):
+        bad.run("nan")
+
+
 def test_launch_order_follows_the_expected_electrons():
     rng = np.random.default_rng(3)
     batch = ph.Batch()

@@ -269,6 +269,41 @@ def test_a_new_grism_on_a_live_context_forgets_the_old_spectrum_estimates():
             fresh.close()
 
 
+def test_a_malformed_sensitivity_table_is_refused_and_the_context_keeps_its_grism():
+    # np.interp's precondition (grism.py:116-118) is the ABI's: wayne_ctx_set_grism answers WAYNE_E_INVALID to a table with a
+    # NaN / infinite entry or wavelengths that step back (tests/test_host_plan.py holds the planner's side under
+    # AddressSanitizer), changes nothing, and the context goes on producing the frames of the grism it had
+    from wayne_amd import _lib, engine
+    v = helpers.make_visit("small256")
+    pg = helpers.product_generator(v, 0)
+    kw = v.frame_kwargs(0, cosmic_rate=None)
+    g = v.grism
+    sens_wl, sens_val = (np.asarray(a, dtype=float) for a in v.calibration.sensitivity(g.name))
+    wmin, wmax = v.calibration.flat_wl.get(g.name, (0.0, 1.0))
+    eng = engine.Engine(0, g, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    try:
+        desc = pg.build_descriptor(eng, rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, **kw)
+        before = eng.ctx.synthesize(desc)
+        bad = {}
+        w = sens_wl.copy(); w[-1] = np.nan; bad["nan_last"] = (w, sens_val)
+        w = sens_wl.copy(); w[0] = -np.inf; bad["inf_first"] = (w, sens_val)
+        bad["decreasing"] = (sens_wl[::-1].copy(), sens_val)
+        w = sens_wl.copy(); w[5] = w[3]; bad["one_step_back"] = (w, sens_val)
+        x = sens_val.copy(); x[len(x) // 2] = np.nan; bad["nan_value"] = (sens_wl, x)
+        for name, (w, x) in bad.items():
+            with pytest.raises(_lib.WayneError) as e:
+                eng.ctx.set_grism(g.trace_coeff, g.wl_solution, g.psf_ratio_poly.coeffs, g.psf_sigmal_poly.coeffs,
+                                  g.psf_sigmah_poly.coeffs, w, x, wmin, wmax)
+            assert e.value.status == _lib.E_INVALID and "sensitivity" in str(e.value), name
+            np.testing.assert_array_equal(eng.ctx.synthesize(desc), before, err_msg=name)
+        # repeated wavelengths are within the precondition
+        eng.ctx.set_grism(g.trace_coeff, g.wl_solution, g.psf_ratio_poly.coeffs, g.psf_sigmal_poly.coeffs,
+                          g.psf_sigmah_poly.coeffs, np.repeat(sens_wl[::2], 2)[:sens_wl.size], sens_val, wmin, wmax)
+        assert np.isfinite(eng.ctx.synthesize(desc)).all()
+    finally:
+        eng.close()
+
+
 def test_random_exposures_against_the_oracle():
     # a fixed-seed stretch of scripts/soak_exposure.py: random small configuration, brightness, detector switches, sky,
     # cosmic rays, rng mode, exact / production samplers, float32 / float64 reads -- whole exposures against the numpy

@@ -137,7 +137,7 @@ def test_rebin_spec_against_the_oracle():
     e = tools.bin_centers_to_edges(new)
     inside = (wl >= e[0]) & (wl <= e[-1])
     grid = np.concatenate([[e[0]], wl[inside], [e[-1]]])
-    total = np.trapz(np.interp(grid, wl, sp), grid)
+    total = np.trapezoid(np.interp(grid, wl, sp), grid)
     assert abs((tools.rebin_spec(wl, sp, new) * np.diff(e)).sum() - total) < 1e-10 * total
 
 

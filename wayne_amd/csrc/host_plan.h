@@ -33,6 +33,17 @@ namespace plan {
 
 constexpr int RNG_SPLIT = 2;   // WAYNE_RNG_SPLIT (include/wayne_hip.h)
 
+// np.interp's precondition on the sensitivity table (grism.py:116-118: "xp must be increasing"; numpy does not check and
+// returns nonsense otherwise): finite, non-decreasing wavelengths and finite values.  wayne_ctx_set_grism refuses a table
+// that fails it (WAYNE_E_INVALID) -- a bisection over unordered or NaN abscissae has no bracket to find.
+inline bool sens_table_ok(const double* swl, const double* sval, int n) {
+  for (int i = 0; i < n; ++i) {
+    if (!std::isfinite(swl[i]) || !std::isfinite(sval[i])) return false;
+    if (i > 0 && swl[i] < swl[i - 1]) return false;
+  }
+  return true;
+}
+
 struct SpectrumEstimate {
   // the grism the factors were worked out with
   GrismDev g{};
@@ -82,7 +93,12 @@ struct SpectrumEstimate {
 #endif
         else if (x >= sens_wl.back()) sens = sens_val.back();
         else {                                                  // ... and upper_bound(NaN) is end(): sens_val[n], one past the table
-          const size_t hi = (size_t)(std::upper_bound(sens_wl.begin(), sens_wl.end(), x) - sens_wl.begin());
+          size_t hi = (size_t)(std::upper_bound(sens_wl.begin(), sens_wl.end(), x) - sens_wl.begin());
+#ifndef WAYNE_PLAN_NEGCTL_NAN_INTERP
+          // (front < x < back, so 1 <= hi <= n - 1 on any table sens_table_ok() passes; a table that does not -- NaN at its
+          // end, say -- can send the bisection to either end: the bracket stays inside the table whatever it holds)
+          hi = std::min(std::max(hi, (size_t)1), sens_wl.size() - 1);
+#endif
           const size_t lo = hi - 1;
           sens = sens_val[lo] + (sens_val[hi] - sens_val[lo]) * (x - sens_wl[lo]) / (sens_wl[hi] - sens_wl[lo]);
         }

@@ -693,6 +693,8 @@ int wayne_ctx_set_grism(wayne_ctx* c, const wayne_grism_desc* g) {
   if (!c || !g) return WAYNE_E_INVALID;
   if (g->n_sens < 0 || (g->n_sens > 0 && (!g->sens_wl_um || !g->sens_val)))
     return fail(c, WAYNE_E_INVALID, "set_grism: sensitivity table");
+  if (!plan::sens_table_ok(g->sens_wl_um, g->sens_val, g->n_sens))
+    return fail(c, WAYNE_E_INVALID, "set_grism: sensitivity table must have finite values at finite, non-decreasing wavelengths");
   (void)hipSetDevice(c->device);
   c->stream = c->streams[0];
   int rc;
