@@ -112,6 +112,20 @@ def test_crop_central_box():
         assert mod.crop_central_box(a, 10) is a      # the reference returns an EMPTY array here (tools.py:322-324)
 
 
+def test_gaussian_cell_masses_known_answer():           # tests/test_models.py:99-103
+    # The reference's own known answer for "a gaussian integrated over bins" (GaussianModel1D.integrate, models.py:124-147:
+    # differences of the normal cdf; mean 5, sigma 0.5, flux 3 over the limits 4.3 | 4.7 | 5.2 | 6 -> 0.5805, 1.1435, 0.9655
+    # to four decimals).  The module is not on the reference's own path, but the formula is exactly what the split
+    # thrower's multinomial uses for its cell masses (differences of the upper tail P(Z > t), k_narrow.h / the oracle's
+    # wayne_oracle_upper_tail): the fit the kernel evaluates is held to that vector here.
+    from oracle import clib
+    mean, sigma, flux = 5.0, 0.5, 3.0
+    limits = np.array([4.3, 4.7, 5.2, 6.0])
+    t = (limits - mean) / sigma
+    tail = np.where(t >= 0, clib.upper_tail(np.abs(t)), 1.0 - clib.upper_tail(np.abs(t)))    # P(Z > t) for either sign
+    np.testing.assert_almost_equal(flux * (tail[:-1] - tail[1:]), [0.5805, 1.1435, 0.9655], 4)
+
+
 def test_hook_and_long_term_ramp():                    # tests/trend_generators/test_visit_trends.py:38-52
     t = np.array([6, 9, 12, 95, 98, 101]) / 60. / 24.
     vt = visit_trends.HookAndLongTermRamp({"exp_start_times": t, "orbit_start_index": [0, 3]},
