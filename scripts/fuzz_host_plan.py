@@ -8,7 +8,8 @@ Per seed: 150 random descriptors (a third of them hostile, some with NaN / negat
 factors on top), 40 sky plans and 40 thrower calls made of junk values -- all through tests/native/plan_harness (the
 SAME host_plan.h the library includes).  A sanitizer report stops the run; the box property (every position the
 oracle's trace computes, +- 6.9 sigma, inside box[read], or "load everything") is checked on every clean descriptor.
-Round 5: seeds 0-11 (1800 plans, 480 sky plans, 480 thrower calls): no report, 0 violations.
+Round 5: seeds 0-11 (1800 plans -- 160 of them with a sensitivity table the ABI refuses -- 480 sky plans, 480 thrower
+calls): no report, 0 violations.
 """
 import os
 import sys
@@ -33,6 +34,21 @@ for seed in range(first, last):
     for d in cases[::7]:
         d["dur"][rng.integers(0, d["dur"].size)] = rng.choice([np.nan, -5.0, np.inf, 0.0])
         d["scale"] = float(rng.choice([np.nan, 0.0, -1.0, 1e300, 1.0]))
+    # sensitivity tables the ABI refuses (the planner must still stay inside them): junk entries, steps back, shuffles
+    for d in cases[3::11]:
+        w, v = d["ga"]["sens_wl"].copy(), d["ga"]["sens_val"].copy()
+        how = rng.choice(["junk", "reverse", "shuffle", "short"])
+        if how == "junk":
+            for a in (w, v):
+                a[rng.integers(0, a.size, 3)] = rng.choice([np.nan, np.inf, -np.inf, 1e300, -1.0], size=3)
+        elif how == "reverse":
+            w = w[::-1].copy()
+        elif how == "shuffle":
+            w = rng.permutation(w)
+        else:
+            w, v = w[:2].copy(), v[:2].copy()
+            w[rng.integers(0, 2)] = np.nan
+        d["ga"] = dict(d["ga"], sens_wl=w, sens_val=v)
     b = ph.Batch()
     idx = [t.add_plan(b, d) for d in cases]
     # sky ops with random junk
