@@ -1,0 +1,362 @@
+"""GPU: are the random streams of the production kernels DISTINCT and UNCORRELATED -- across pixels, reads, sub-samples,
+bins, exposures and visit seeds?
+
+Every other statistical test of the suite looks at marginal laws: moments over many pixels (tests/test_ensemble_gpu.py),
+the largest deviation and the tail frequencies of each stage (tests/test_extremes_gpu.py).  All of them are blind to a
+defect of the KEYING: two pixels (or two bins, or exposure e and e + 1) that draw from the same stream have perfectly
+good marginals and are copies of each other; a key that mixes (exposure, sub-sample) as a sum gives (0, 1) and (1, 0) the
+same electrons.  The reference draws everything from one global Mersenne Twister (exposure_generator.py:327-329, 495,
+626; detector.py:191, 198) and `rand_r` seeds drawn from it (pyparallel_menu.c:40-64): independence is what its law
+says, and what the counter-keyed streams here have to reproduce.
+
+  * collisions: with CONSTANT calibration planes a pixel's sixteen float32 reads are a function of its stream alone --
+    no two pixels of three exposures and two visit seeds (4 x 10^6 streams) may hold the same sixteen numbers; isolated
+    bins of a thrower call each leave their own blob of electrons -- no two blobs of 144 bins x 9 (exposure, sub-sample)
+    pairs may be equal, in each thrower mode and for the narrow and the wide component alone;
+  * correlations: standardised reads / sky counts / stellar counts multiplied at spatial lags (neighbours, the wave's 64,
+    the workgroup's 1024 = one row, powers of two), across reads, exposures and seeds, also diagonally
+    ((e, p) against (e + 1, p + 1)): every mean product within 5 standard errors of 0 (~10^-4).
+  * the checkers are shown to see what they look for: the same exposure twice IS all collisions and correlation 1.
+
+Production instantiations: `k_ramp<float, true, 1, false, true>` (normals; sky words from the same stream),
+`<..., false>` (sky alone), `k_prep_sub` (stellar counts), `k_lane` / `k_narrow` / `k_throw` (thrower).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from wayne_amd import _lib, calibration, detector, engine, grism, synthetic
+from wayne_amd.exposure_generator import ExposureGenerator
+
+pytestmark = pytest.mark.gpu
+
+GAIN = 2.35
+READ_SIGMA = 14.1 / 2.35
+DARK_RATE, DARK_ERR = 0.05, 0.02
+PROD_ALLON = "k_ramp<float, true, 1, false, true>"
+PROD_FLAGS = "k_ramp<float, true, 1, false, false>"
+STAR_OFF = dict(scale_factor=1e-9, cosmic_rate=None, add_stellar_noise=False)
+ONLY_SKY = dict(STAR_OFF, add_dark=False, add_read_noise=False, add_non_linear=False, clip_values_det_limits=False,
+                add_gain_variations=False, add_flat=False, add_initial_bias=False)
+
+# (dy, dx): neighbours; the wave (64 consecutive pixels) and its edges; powers of two; one row = one workgroup of k_ramp
+# (1024 pixels at the full array); a few with both
+LAGS = [(0, 1), (1, 0), (1, 1), (1, -1), (0, 2), (0, 3), (0, 4), (0, 8), (0, 16), (0, 32), (0, 63), (0, 64), (0, 65),
+        (0, 128), (0, 256), (0, 512), (2, 0), (4, 0), (16, 0), (64, 0), (512, 0), (64, 64), (3, 7)]
+N_SIGMA = 5.0
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "independence.json")
+
+
+def report(key, **figures):
+    """The measured figures next to their bands (gpurun_out/independence.json -> profiles/rNN/)."""
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        d = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        d[key] = figures
+        json.dump(d, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def row_hashes(reads):
+    """One 64-bit hash per pixel of its column of float32 reads (bit patterns, not values)."""
+    u = np.ascontiguousarray(reads, dtype=np.float32).view(np.uint32).reshape(reads.shape[0], -1).astype(np.uint64)
+    h = np.full(u.shape[1], 0x243F6A8885A308D3, dtype=np.uint64)
+    for r in range(u.shape[0]):
+        h = (h ^ u[r]) * np.uint64(0x9E3779B97F4A7C15)
+        h ^= h >> np.uint64(29)
+    return h
+
+
+def lag_product(a, b, dy, dx):
+    """sum and count of a[y, x] * b[y + dy, x + dx] over the last two axes (any leading axes)."""
+    S = a.shape[-1]
+    ya, yb = (slice(0, S - dy), slice(dy, S)) if dy >= 0 else (slice(-dy, S), slice(0, S + dy))
+    xa, xb = (slice(0, S - dx), slice(dx, S)) if dx >= 0 else (slice(-dx, S), slice(0, S + dx))
+    p = a[..., ya, xa] * b[..., yb, xb]
+    return float(p.sum(dtype=np.float64)), p.size
+
+
+def assert_uncorrelated(pairs, what):
+    """pairs: {name: (sum of products, n)} of standardised, supposedly independent variables: mean product 0 +- 1 / sqrt(n)."""
+    worst, bad = ("", 0.0), []
+    for name, (s, n) in pairs.items():
+        z = (s / n) * np.sqrt(n)
+        if abs(z) > abs(worst[1]):
+            worst = (name, z)
+        if abs(z) > N_SIGMA:
+            bad.append("%s: mean product %.2e = %.1f standard errors (n = %d)" % (name, s / n, z, n))
+    assert not bad, what + ": " + "; ".join(bad)
+    report("correlations/" + what, products=len(pairs), band_standard_errors=N_SIGMA, worst=worst[0],
+           worst_standard_errors=round(float(worst[1]), 3),
+           smallest_n=int(min(n for _, n in pairs.values())), largest_n=int(max(n for _, n in pairs.values())),
+           largest_abs_mean_product=float(max(abs(s_ / n) for s_, n in pairs.values())))
+    return worst
+
+
+_cache = {}
+
+
+def constant_planes_visit(n_exposures):
+    """cfg4 over calibration planes that are the SAME in every pixel: dark 0.05 DN/s with error 0.02, gain 2.35 (pixel flat
+    1), identity non-linearity, no initial bias at the full array.  Every detector switch stays on -- the benchmarked
+    ALLON instantiation runs -- and with star and sky (practically) off a read is
+    float32(dark_r + 0.02 z_d) + float32(6 z_r): a function of the pixel's stream and nothing else."""
+    if "cal" not in _cache:
+        cal = calibration.CalibrationSet.synthetic(11)
+        cal.lin[:] = 0.0
+        cal.pfl[:] = 1.0
+        det = detector.WFC3_IR()
+        v0 = synthetic.Visit("cfg4", det, grism.G141(cal), cal, n_exposures=1)
+        times = det.modes_exp_table[v0.SUBARRAY][v0.SAMPSEQ]
+        S = 1024
+        hdus = [None]
+        for t in [0.0] + list(times[:15]):               # the layout of CalibrationSet.super_dark_hdus: last read first
+            hdus[1:1] = [np.full((S, S), DARK_RATE * t, dtype=np.float32), np.full((S, S), DARK_ERR, dtype=np.float32),
+                         None, None, None]
+        cal.dark[(v0.SUBARRAY, v0.SAMPSEQ)] = hdus
+        _cache["cal"] = cal
+    cal = _cache["cal"]
+    return synthetic.Visit("cfg4", detector.WFC3_IR(), grism.G141(cal), cal, n_exposures=n_exposures)
+
+
+def run(v, i, want_variant, seed=None, **over):
+    pg = ExposureGenerator(v.detector, v.grism, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=v.calibration, device=0,
+                           seed=v.seed if seed is None else seed, exposure_index=i)
+    eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    desc = pg.build_descriptor(eng, out_dtype=np.float32, **v.frame_kwargs(i, **over))
+    eng.ctx.upload(0, desc)
+    assert eng.ctx.ramp_variant(0) == want_variant
+    eng.ctx.run(0)
+    return eng.ctx.download(0)
+
+
+def test_noise_streams_of_the_benchmarked_kernel_neither_collide_nor_correlate():
+    v = constant_planes_visit(3)
+    sci, err = v.calibration.dark_frames(v.SUBARRAY, v.SAMPSEQ, v.read_times)
+    assert np.ptp(sci[3]) == 0 and np.ptp(err) == 0
+    S = 1024
+    interior = np.zeros((S, S), dtype=bool)
+    interior[5:-5, 5:-5] = True
+    mean = np.stack([np.zeros((S, S))] + [np.where(interior, float(sci[r][0, 0]), 0.0) for r in range(15)])
+    sig = np.where(interior, np.sqrt(float(err[0][0, 0]) ** 2 + READ_SIGMA ** 2), READ_SIGMA)
+    sig = np.stack([np.full((S, S), READ_SIGMA)] + [sig] * 15)
+    # three exposures of one visit seed, and exposures 0 and 1 of the next seed ((seed, e) against (seed + 1, e - 1) is
+    # the classic additive-key collision)
+    runs = [(v.seed, 0), (v.seed, 1), (v.seed, 2), (v.seed + 1, 0), (v.seed + 1, 1)]
+    z, hashes = [], []
+    for seed, e in runs:
+        reads = run(v, e, PROD_ALLON, seed=seed, sky_background=1e-7, **STAR_OFF)
+        assert reads.shape == (16, S, S) and reads.dtype == np.float32
+        hashes.append(row_hashes(reads))
+        z.append(((reads - mean) / sig).astype(np.float32))
+    z = np.stack(z)                                            # (5, 16, S, S)
+    assert abs(float(z.mean())) < 5 / np.sqrt(z.size) and abs(float(z.std()) - 1.0) < 1e-3
+
+    # --- collisions: 5 x 2^20 streams, sixteen float32 numbers each
+    h = np.concatenate(hashes)
+    assert np.unique(h).size == h.size, "%d pixels share their sixteen reads with another pixel" % (h.size - np.unique(h).size)
+    # (the detector sees what it looks for: the same exposure once more is 2^20 collisions)
+    again = row_hashes(run(v, 0, PROD_ALLON, seed=v.seed, sky_background=1e-7, **STAR_OFF))
+    assert np.array_equal(again, hashes[0])
+    report("collisions/k_ramp streams", streams=int(h.size), reads_per_stream=16, repeated=0,
+           runs=["seed %d, exposure %d" % r for r in runs])
+
+    # --- correlations
+    pairs = {}
+    for dy, dx in LAGS:
+        pairs["pixel lag (%d, %d)" % (dy, dx)] = lag_product(z, z, dy, dx)
+    for lag in (1, 2, 5):
+        p = z[:, :-lag] * z[:, lag:]
+        pairs["read lag %d" % lag] = (float(p.sum(dtype=np.float64)), p.size)
+    for a, b, name in ((0, 1, "exposure e, e + 1"), (1, 2, "exposure e + 1, e + 2"), (0, 2, "exposure e, e + 2"),
+                       (0, 3, "seed s, s + 1"), (1, 3, "(s, e + 1), (s + 1, e)"), (0, 4, "(s, e), (s + 1, e + 1)")):
+        p = z[a] * z[b]
+        pairs[name] = (float(p.sum(dtype=np.float64)), p.size)
+        for dy, dx in ((0, 1), (0, -1), (1, 0)):
+            pairs[name + ", pixel lag (%d, %d)" % (dy, dx)] = lag_product(z[a], z[b], dy, dx)
+    # the two normals of a read come from ONE Box-Muller pair (dark: cosine, read noise: sine), and the zero read's pair
+    # precedes them: read r against read r + 1 above covers the pairs' order; here the checker on a planted copy
+    assert lag_product(z[0], z[0], 0, 0)[0] / z[0].size > 0.99
+    worst = assert_uncorrelated(pairs, "dark + read-noise normals")
+    print("normals: %d products, worst %s at %.2f standard errors" % (len(pairs), worst[0], worst[1]))
+
+
+def test_sky_counts_neither_collide_nor_correlate():
+    # the table-driven sky draw of the production chain, nothing else switched on: integer counts per read interval
+    v = helpers.make_visit("cfg4", n_exposures=3)
+    sky = v.calibration.sky[v.grism.name].astype(np.float32)
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    lam = np.stack([(sky * np.float32(5.0 * d)).astype(np.float64) for d in dt])           # (15, 1014, 1014)
+    z = []
+    for e in range(3):
+        reads = run(v, e, PROD_FLAGS, sky_background=5.0, **ONLY_SKY).astype(np.float64)
+        el = np.rint(reads[:, 5:-5, 5:-5] * GAIN)
+        k = np.diff(el, axis=0)
+        assert k.min() >= 0
+        z.append(((k - lam) / np.sqrt(lam)).astype(np.float32))
+    z = np.stack(z)                                                                          # (3, 15, 1014, 1014)
+    assert abs(float(z.mean())) < 5 / np.sqrt(z.size) and abs(float(z.std()) - 1.0) < 2e-3
+    pairs = {}
+    for dy, dx in LAGS:
+        pairs["pixel lag (%d, %d)" % (dy, dx)] = lag_product(z, z, dy, dx)
+    for lag in (1, 2, 5):
+        p = z[:, :-lag] * z[:, lag:]
+        pairs["interval lag %d" % lag] = (float(p.sum(dtype=np.float64)), p.size)
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        p = z[a] * z[b]
+        pairs["exposures %d, %d" % (a, b)] = (float(p.sum(dtype=np.float64)), p.size)
+        pairs["exposures %d, %d, pixel lag (0, 1)" % (a, b)] = lag_product(z[a], z[b], 0, 1)
+        pairs["exposures %d, %d, pixel lag (0, -1)" % (a, b)] = lag_product(z[a], z[b], 0, -1)
+    worst = assert_uncorrelated(pairs, "sky counts")
+    print("sky: %d products, worst %s at %.2f standard errors" % (len(pairs), worst[0], worst[1]))
+    # no two pixels with the same fifteen counts AND the same rates (a shared stream under the same tables)
+    key = np.concatenate([z[e].reshape(15, -1) for e in range(3)], axis=1)
+    h = row_hashes(key)
+    n_dup = h.size - np.unique(h).size
+    assert n_dup == 0, "%d pixels repeat another pixel's fifteen standardised sky counts" % n_dup
+
+
+def test_stellar_counts_neither_collide_nor_correlate():
+    # k_prep_sub's Poisson draw per (bin, sub-sample): one Philox block per pair, keyed by (bin, sub-sample, exposure)
+    from oracle import wayne_oracle as wo
+    v = helpers.make_visit("cfg4", n_exposures=4)
+    eo = helpers.oracle_generator(v)
+    gr = eo.grism
+    i0, i1 = wo.crop_spectrum_ind(gr.wl_limits[0], gr.wl_limits[1], v.wl.copy())
+    s_wl = v.wl[i0:i1]
+    gr.set_current_wavelength_only_dependent_array(s_wl)
+    z = []
+    for e in range(4):
+        rec = {}
+        kw = v.frame_kwargs(e, cosmic_rate=None)
+        helpers.product_generator(v, e).scanning_frame(out_dtype=np.float32, record=rec, **kw)
+        lam = np.stack([eo.counts_before_noise(s_wl, kw["stellar_flux"][i0:i1] * (1.0 - kw["planet_signal"][k][i0:i1]),
+                                               rec["dur"][k], v.scale_factor(e)) for k in range(v.K)])
+        assert rec["counts"].shape == lam.shape == (128, 4494) and np.median(lam) > 100.0
+        z.append(np.where(lam > 0, (rec["counts"] - lam) / np.sqrt(np.maximum(lam, 1e-300)), 0.0))
+    z = np.stack(z)                                                                          # (4, K, W)
+    assert abs(float(z.std()) - 1.0) < 5e-3
+    pairs = {}
+    for dw in (1, 2, 3, 16, 63, 64, 65, 512, 1024):                                         # (64: the wave; 512: the workgroup)
+        p = z[:, :, :-dw] * z[:, :, dw:]
+        pairs["bin lag %d" % dw] = (float(p.sum()), p.size)
+    for dk in (1, 2, 64):
+        p = z[:, :-dk] * z[:, dk:]
+        pairs["sub-sample lag %d" % dk] = (float(p.sum()), p.size)
+    p = z[:, :-1, :-1] * z[:, 1:, 1:]
+    pairs["(k, w), (k + 1, w + 1)"] = (float(p.sum()), p.size)
+    p = z[:, :-1, 1:] * z[:, 1:, :-1]
+    pairs["(k, w + 1), (k + 1, w)"] = (float(p.sum()), p.size)
+    for a, b in ((0, 1), (1, 2), (0, 3)):
+        p = z[a] * z[b]
+        pairs["exposures %d, %d" % (a, b)] = (float(p.sum()), p.size)
+        p = z[a][:-1] * z[b][1:]
+        pairs["(e, k + 1), (e + 1, k)" if b == a + 1 else "exposures %d, %d, sub-sample lag 1" % (a, b)] = (float(p.sum()), p.size)
+    worst = assert_uncorrelated(pairs, "stellar counts")
+    print("stellar: %d products, worst %s at %.2f standard errors" % (len(pairs), worst[0], worst[1]))
+
+
+GRID, PITCH, HALF = 12, 80, 40
+BLOB_COUNT = 400
+
+
+def thrower_blobs(ctx, mode, ratio, exposure, subsample, seed=4242):
+    """One thrower call with 144 ISOLATED bins -- a 12 x 12 grid 80 px apart, every bin at the same sub-pixel position, with
+    the same count and the same PSF -- cut into the bins' own 80 x 80 windows (6.9 sigma_h = 38 px: an electron cannot
+    leave its bin's window).  What distinguishes two blobs is their stream and nothing else."""
+    gx, gy = np.meshgrid(np.arange(GRID), np.arange(GRID))
+    x = (60.37 + PITCH * gx).ravel().astype(np.float64)
+    y = (60.81 + PITCH * gy).ravel().astype(np.float64)
+    n = x.size
+    counts = np.full(n, BLOB_COUNT, dtype=np.int32)
+    frame = ctx.psf_apply(counts, x, y, np.full(n, ratio), np.full(n, 0.7), np.full(n, 5.5), 1014, 1014, seed, 1,
+                          rng_mode=mode, exposure=exposure, subsample=subsample)
+    f = np.asarray(frame).reshape(1014, 1014)
+    assert int(f.sum()) == n * BLOB_COUNT
+    lo = 60 - HALF
+    blobs = f[lo:lo + GRID * PITCH, lo:lo + GRID * PITCH].reshape(GRID, PITCH, GRID, PITCH).transpose(0, 2, 1, 3)
+    blobs = np.ascontiguousarray(blobs).reshape(n, PITCH * PITCH)
+    assert (blobs.sum(axis=1) == BLOB_COUNT).all(), "an electron left its bin's window"
+    return blobs
+
+
+THROWER_CASES = [
+    (_lib.RNG_SPLIT, 0.0, "narrow component alone: one multinomial per bin (k_narrow)"),
+    (_lib.RNG_SPLIT, 1.0, "wide component alone: a bin's own lane throws it (k_lane)"),
+    (_lib.RNG_SPLIT, 0.2, "the production split"),
+    (_lib.RNG_PHILOX, 0.2, "every electron one by one, streams per block of 128 electrons (k_throw)"),
+]
+
+
+@pytest.mark.parametrize("mode,ratio,what", THROWER_CASES)
+def test_thrower_streams_of_bins_subsamples_and_exposures_are_distinct(gpu_ctx, mode, ratio, what):
+    seen = {}
+    n_blobs = 0
+    for exposure in range(3):
+        for subsample in range(3):
+            blobs = thrower_blobs(gpu_ctx, mode, ratio, exposure, subsample)
+            n_blobs += len(blobs)
+            for b, blob in enumerate(blobs):
+                key = blob.tobytes()
+                assert key not in seen, "%s: bin %d of (exposure %d, sub-sample %d) repeats bin %d of %r" % (
+                    what, b, exposure, subsample, seen[key][1], seen[key][0])
+                seen[key] = ((exposure, subsample), b)
+    assert n_blobs == len(seen) == 9 * GRID * GRID
+    report("collisions/thrower: " + what, blobs=n_blobs, electrons_per_blob=BLOB_COUNT, repeated=0)
+    # another visit seed: new blobs again
+    for b, blob in enumerate(thrower_blobs(gpu_ctx, mode, ratio, 0, 0, seed=4243)):
+        assert blob.tobytes() not in seen
+    # ... and the checker sees a repeat when there is one: the same call again is 144 known blobs
+    again = thrower_blobs(gpu_ctx, mode, ratio, 1, 2)
+    assert all(seen[blob.tobytes()] == ((1, 2), b) for b, blob in enumerate(again))
+    # the blobs are not copies shifted by chance either: pixel by pixel, two bins' electrons are uncorrelated
+    a = thrower_blobs(gpu_ctx, mode, ratio, 0, 0).astype(np.float64)
+    mean = a.mean(axis=0)
+    d = a - mean
+    var = (d ** 2).sum()
+    cross = (d[:-1] * d[1:]).sum() / var * len(a) / (len(a) - 1)             # neighbouring bins, normalised to a copy = 1
+    assert abs(cross) < 0.15, cross             # (a copy is 1; the narrow component alone scatters by 0.03)
+
+
+def test_negative_control_additive_stream_keys_are_caught():
+    # The same tests in a child process whose libwayne_hip.so was built with -DWAYNE_NEGCTL_ADDITIVE_KEY (philox.h: element,
+    # sub-sample / read and exposure index ADDED into one counter word -- the classic keying mistake): every marginal law
+    # stays what it was (tests/test_extremes_gpu.py passes on such a library by construction) and pixel p of exposure
+    # e + 1 draws what pixel p + 1 of exposure e drew.  Each stage's test above must FAIL on it.
+    import subprocess
+    import sys
+    from wayne_amd import build as wb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = wb.build_negctl_key()          # (prebuilt by __graft_entry__.build())
+    code = ("import sys, json\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_independence_gpu as t\n"
+            "from wayne_amd import _lib\n"
+            "res = {}\n"
+            "def attempt(name, fn, *a):\n"
+            "    try:\n"
+            "        fn(*a); res[name] = 'passed'\n"
+            "    except AssertionError as e:\n"
+            "        res[name] = 'FAILED: ' + str(e)[:400]\n"
+            "attempt('normals', t.test_noise_streams_of_the_benchmarked_kernel_neither_collide_nor_correlate)\n"
+            "attempt('sky', t.test_sky_counts_neither_collide_nor_correlate)\n"
+            "attempt('stellar', t.test_stellar_counts_neither_collide_nor_correlate)\n"
+            "ctx = _lib.Context(0)\n"
+            "for mode, ratio, what in t.THROWER_CASES:\n"
+            "    attempt('thrower: ' + what, t.test_thrower_streams_of_bins_subsamples_and_exposures_are_distinct, ctx, mode, ratio, what)\n"
+            "print(json.dumps(res))\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, WAYNE_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    print(json.dumps(res, indent=1))
+    report("negative_control/additive_keys", **res)
+    assert len(res) == 3 + len(THROWER_CASES)
+    for name, verdict in res.items():
+        assert verdict.startswith("FAILED"), "the additive-key library passed %r: %s" % (name, verdict)
+    assert "share their sixteen reads" in res["normals"]
+    assert "repeats bin" in res["thrower: the production split"]

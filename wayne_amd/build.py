@@ -69,6 +69,15 @@ def build_negctl_sky(force=False, verbose=False):
     return build_variant(["-DWAYNE_NEGCTL_SKY_RUNAWAY"], NEGCTL_SKY_LIB, force, verbose)
 
 
+# Negative-control library of tests/test_independence_gpu.py: stream keys that ADD element, sub-sample and exposure index
+# into one counter word (philox.h) -- marginal laws intact, streams shared between neighbours of consecutive exposures.
+NEGCTL_KEY_LIB = os.path.join(ROOT, "tests", "native", "_build", "libwayne_hip_negctl_key.so")
+
+
+def build_negctl_key(force=False, verbose=False):
+    return build_variant(["-DWAYNE_NEGCTL_ADDITIVE_KEY"], NEGCTL_KEY_LIB, force, verbose)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -87,9 +87,18 @@ WAYNE_HD uint32_t uint_below(uint32_t x, uint32_t n) {
 struct PhiloxStream {
   uint32_t c0, c2, c3, k0, k1, block, have;
   u32x4 buf;
+#ifdef WAYNE_NEGCTL_ADDITIVE_KEY
+  // NEGATIVE-CONTROL builds of tests/test_independence_gpu.py (never the shipped library): element, sub-sample / read and
+  // exposure index ADDED into one counter word -- (element e, exposure i + 1) then shares its stream with (e + 1, i), and
+  // (sub-sample 1, exposure 0) with (0, 1): marginal laws untouched, independence gone
+  WAYNE_HD PhiloxStream(uint32_t seed, uint32_t stage, uint32_t c0_, uint32_t c2_,
+                        uint32_t c3_)
+      : c0(c0_ + c2_ + c3_), c2(0u), c3(0u), k0(seed), k1(stage), block(0), have(0) {}
+#else
   WAYNE_HD PhiloxStream(uint32_t seed, uint32_t stage, uint32_t c0_, uint32_t c2_,
                         uint32_t c3_)
       : c0(c0_), c2(c2_), c3(c3_), k0(seed), k1(stage), block(0), have(0) {}
+#endif
   WAYNE_HD uint32_t next() {
     if (have == 0) {
       buf = philox4x32_10(c0, block, c2, c3, k0, k1);
@@ -109,7 +118,11 @@ struct SeededStream {
   uint32_t s0, s1, s2, s3;
   WAYNE_HD SeededStream() : s0(0), s1(0), s2(0), s3(0) {}
   WAYNE_HD SeededStream(uint32_t seed, uint32_t stage, uint32_t c0, uint32_t c2, uint32_t c3, uint32_t c1 = 0u) {
+#ifdef WAYNE_NEGCTL_ADDITIVE_KEY
+    const u32x4 b = philox4x32_10(c0 + c2 + c3, c1, 0u, 0u, seed, stage);   // (see PhiloxStream)
+#else
     const u32x4 b = philox4x32_10(c0, c1, c2, c3, seed, stage);
+#endif
     s0 = b.v[0]; s1 = b.v[1]; s2 = b.v[2]; s3 = b.v[3];
   }
   WAYNE_HD uint32_t next() {
