@@ -220,6 +220,45 @@ def test_sky_counts_neither_collide_nor_correlate():
     assert n_dup == 0, "%d pixels repeat another pixel's fifteen standardised sky counts" % n_dup
 
 
+def test_sky_words_and_normals_of_one_stream_are_uncorrelated():
+    # In the production layout ONE stream per pixel serves the sky draw and the two normals of every read (k_ramp.h:
+    # STAGE_READ; per read interval a pair of words for the sky, then the pair of the next read's normals), and a variant
+    # with a stage switched off still takes the stage's words.  So the sky-only run of an exposure tells which counts the
+    # all-on run of the SAME exposure drew, and what is left of its reads after them and the (constant) dark is the normals
+    # alone: sky counts against normals of the same read, the read before and the read after -- a word used twice would show
+    v = constant_planes_visit(3)
+    sky = v.calibration.sky[v.grism.name].astype(np.float32)
+    dt = np.diff(np.concatenate([[0.0], v.read_times]))
+    lam = np.stack([(sky * np.float32(5.0 * d)).astype(np.float64) for d in dt])           # (15, 1014, 1014)
+    sci, err = v.calibration.dark_frames(v.SUBARRAY, v.SAMPSEQ, v.read_times)
+    dark = np.array([float(sci[r][0, 0]) for r in range(15)])
+    sig = np.sqrt(float(err[0][0, 0]) ** 2 + READ_SIGMA ** 2)
+    kz, nz = [], []
+    for e in range(3):
+        only = run(v, e, PROD_FLAGS, sky_background=5.0, **ONLY_SKY).astype(np.float64)[:, 5:-5, 5:-5]
+        cum = np.rint(only * GAIN)                                                            # cumulative sky electrons
+        k = np.diff(cum, axis=0)
+        full = run(v, e, PROD_ALLON, sky_background=5.0, **STAR_OFF).astype(np.float64)[:, 5:-5, 5:-5]
+        normals = full[1:] - cum[1:] / GAIN - dark[:, None, None]
+        kz.append(((k - lam) / np.sqrt(lam)).astype(np.float32))
+        nz.append((normals / sig).astype(np.float32))
+    kz, nz = np.stack(kz), np.stack(nz)                                                      # (3, 15, 1014, 1014)
+    # (the all-on run did draw those counts: what is left is a unit normal, not a normal plus a Poisson's scatter)
+    assert abs(float(nz.std()) - 1.0) < 2e-3 and abs(float(nz.mean())) < 5 / np.sqrt(nz.size)
+    pairs = {}
+    p = kz * nz
+    pairs["sky count, normals of the same read"] = (float(p.sum(dtype=np.float64)), p.size)
+    p = kz[:, 1:] * nz[:, :-1]
+    pairs["sky count, normals of the read before"] = (float(p.sum(dtype=np.float64)), p.size)
+    p = kz[:, :-1] * nz[:, 1:]
+    pairs["sky count, normals of the read after"] = (float(p.sum(dtype=np.float64)), p.size)
+    p = kz * nz * nz
+    pairs["sky count, squared normals of the same read"] = (float((p - kz).sum(dtype=np.float64)) / np.sqrt(2.0), p.size)
+    pairs["sky count, normals of the neighbouring pixel"] = lag_product(kz, nz, 0, 1)
+    worst = assert_uncorrelated(pairs, "sky counts against normals")
+    print("sky x normals: %d products, worst %s at %.2f standard errors" % (len(pairs), worst[0], worst[1]))
+
+
 def test_stellar_counts_neither_collide_nor_correlate():
     # k_prep_sub's Poisson draw per (bin, sub-sample): one Philox block per pair, keyed by (bin, sub-sample, exposure)
     from oracle import wayne_oracle as wo
