@@ -232,6 +232,26 @@ def launch_ranks(n, argv):
     return 0
 
 
+_json_out = None
+
+
+def _claim_stdout():
+    """stdout carries ONE line, the JSON line.  Libraries write there too -- under torchrun gloo announces "[Gloo] Rank 0 is
+    connected to 1 peer ranks" on file descriptor 1 from C++ -- so the descriptor is kept aside for the line and
+    everything else that is written to 1, by anyone, goes to stderr."""
+    global _json_out
+    if _json_out is None:
+        sys.stdout.flush()
+        _json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    out = _json_out if _json_out is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def dry_run(rank, world):
     """`--dry-run`: the rendezvous of the N-rank path without any GPU work (gloo barrier, max-reduce, gather), so
     that the launcher and the ranks' meeting can be rehearsed at any N on a CPU.  Prints a line that cannot be
@@ -249,8 +269,7 @@ def dry_run(rank, world):
     got = [None] * world
     dist.all_gather_object(got, rank)
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_reported": len(set(got)), "max_rank": t.item(),
-                          "value": None}), flush=True)
+        emit_line({"dry_run": True, "n_gpus": world, "ranks_reported": len(set(got)), "max_rank": t.item(), "value": None})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -279,6 +298,7 @@ def main():
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     os.environ["WAYNE_STREAMS"] = "2"        # the context always owns two streams; slots select them
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -705,7 +725,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(visit)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -83,6 +83,27 @@ def test_launcher_rendezvous_at_eight_ranks():
     assert d == {"dry_run": True, "n_gpus": 8, "ranks_reported": 8, "max_rank": 7.0, "value": None}
 
 
+def test_the_drivers_torchrun_command_leaves_one_line_on_stdout():
+    # CPU: the driver launches N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    # 127.0.0.1 --master-port P bench.py --gpus N ...` and reads ONE JSON line from the job's stdout -- on which every rank's
+    # descriptor 1 ends up, and gloo announces "[Gloo] Rank 0 is connected to 1 peer ranks ..." there from C++ (seen on
+    # the GPU box in round 5: three lines instead of one).  bench.py keeps descriptor 1 aside for its line and sends
+    # whatever else is written to it to stderr
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "ranks_reported": 2, "max_rank": 1.0, "value": None}
+
+
 def test_launcher_starts_n_ranks_and_fails_loudly_without_gpus():
     # CPU: `--gpus 2` without WORLD_SIZE starts two rank processes; without a GPU both refuse, and the parent
     # reports the failure instead of printing a one-GPU line
