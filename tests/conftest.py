@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The checker is built BEFORE the test modules are collected: several of them decide at import time whether the compiled
+# reference kernel is there (`skipif(not clib.have_ref())`), and in a fresh clone it is only there once oracle/Makefile has
+# run (a no-op when the libraries are up to date; oracle/_ref needs /root/reference and is skipped without it).
+from oracle import clib as _clib  # noqa: E402
+_clib.build()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
