@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Mutation audit of the GPU suite: plant ONE defect at a time in a copy of the library's sources, build it, and ask
+which test notices.
+
+    python scripts/mutation_audit.py build            # here (hipcc cross-compiles): tests/native/_build/mutants/<name>.so
+    python scripts/mutation_audit.py run [name ...]   # on the GPU box: gpurun_out/mutation_audit.txt
+
+Why.  The oracle restates the reference's algorithm, and for three rounds it shared a defect with the kernels it checks
+(the sky draw's runaway search): same-counter parity was green with ~500 spurious electrons in one pixel per exposure.
+The question a reviewer cannot answer from a green suite is "what would you NOT see?".  So every mutant is run against
+two sets of tests, in this order:
+
+  INDEPENDENT  tests that do not go through the oracle's restatement of the mutated stage: the exact laws read off the
+               reference's text (test_extremes_gpu, test_detector_laws_gpu), stream independence (test_independence_gpu),
+               ensembles of the COMPILED reference C (test_ensemble_gpu), the reference's own golden frames
+               (test_psf_gpu's golden test), size-independent properties (test_configs_gpu).  A mutant killed here would have been
+               caught even if the oracle had shared the defect.
+  REST         the rest of the -m gpu suite (same-counter parity against the oracle): run only for a mutant the first set
+               let through -- such a mutant names a stage whose ONLY guard is the restatement.
+
+A mutant is a list of (file under wayne_amd/csrc, exact text, replacement); the text must occur exactly once.  The
+shipped sources are never touched: each mutant is built from a copy under tests/native/_build/mutants/ and loaded
+through WAYNE_HIP_LIB (wayne_amd/_lib.py), like the negative-control libraries.  Test infrastructure; results of round 5:
+profiles/r05/mutation_audit.txt, DESIGN.md section 6.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wayne_amd import build as wb  # noqa: E402
+
+OUT_DIR = os.path.join(ROOT, "tests", "native", "_build", "mutants")
+REPORT = os.path.join(ROOT, "gpurun_out", "mutation_audit.txt")
+
+INDEPENDENT = ["tests/test_detector_laws_gpu.py", "tests/test_independence_gpu.py", "tests/test_extremes_gpu.py",
+               "tests/test_psf_gpu.py::test_replay_mode_is_bit_exact_against_reference_golden",
+               "tests/test_ensemble_gpu.py", "tests/test_configs_gpu.py"]
+
+MUTANTS = [
+    # --- detector stages of k_ramp (A13-A15)
+    dict(name="read_noise_5pc", stage="A15 read noise (detector.py:33, 193-198)",
+         what="read noise 14.8 / 2.35 instead of 14.1 / 2.35",
+         edits=[("common.h", "constexpr double kReadNoise = 14.1 / 2.35;", "constexpr double kReadNoise = 14.8 / 2.35;")]),
+    dict(name="gain_2pc", stage="A13 gain (detector.py:30, 203-204; exposure_generator.py:507-511)",
+         what="gain 2.40 instead of 2.35 (constant and per-pixel form)",
+         edits=[("common.h", "constexpr double kGain = 2.35;", "constexpr double kGain = 2.40;"),
+                ("k_ramp.h", "const float g32 = 2.35f / t_pfl;", "const float g32 = 2.40f / t_pfl;")]),
+    dict(name="clip_max", stage="A15 clip (detector.py:26-28)",
+         what="upper detector limit 77 000 instead of 78 000 DN",
+         edits=[("common.h", "constexpr double kMaxCounts = 78000.0;", "constexpr double kMaxCounts = 77000.0;")]),
+    dict(name="dark_err_floor", stage="A15 dark (detector.py:189-190: err <= 0 -> 1e-5)",
+         what="non-positive dark errors replaced by 0.01 instead of 1e-5",
+         edits=[("wayne_hip.hip", "if (!(x > 0.f)) x = 0.00001f;", "if (!(x > 0.f)) x = 0.01f;"),
+                ("k_ramp.h", "const double err = (de > 0.f) ? (double)de : (double)0.00001f;",
+                 "const double err = (de > 0.f) ? (double)de : (double)0.01f;")]),
+    dict(name="nonlinear_c3_c4", stage="A15 non-linearity (detector.py:335-348)",
+         what="cubic and quartic coefficient planes exchanged in the production (float32) solve",
+         edits=[("k_ramp.h", "const float h = fmaf(u, fmaf(u, fmaf(u, c4, c3), c2), c1p);",
+                 "const float h = fmaf(u, fmaf(u, fmaf(u, c3, c4), c2), c1p);")]),
+    dict(name="reference_pixels_kept", stage="A15 reference pixels (exposure.py:122-131)",
+         what="reference pixels not reset to zero in the production chain",
+         edits=[("k_ramp.h", "if (!interior) v = 0.f;                            // reference pixels (exposure.py:122-131)",
+                 "if (false) v = 0.f;")]),
+    dict(name="zero_read_noiseless", stage="A14 zero read (exposure.py:61-68)",
+         what="no read noise on the zero read",
+         edits=[("k_ramp.h", "if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + kReadNoise * (double)zr; }",
+                 "if (rdn) { bm_pair<FAST>(w0, w1, zd, zr); v = v + 0.0 * (double)zr; }")]),
+    # --- sky (A13)
+    dict(name="sky_remainder_pmf", stage="A13 sky Poisson (exposure_generator.py:488-495)",
+         what="third term of the remainder's pmf m^2 * 0.6 instead of m^2 / 2 (production integer thresholds)",
+         edits=[("k_ramp.h", "t1 = thr(cdf);  t = t * (m_ * 0.5f);         cdf += t;",
+                 "t1 = thr(cdf);  t = t * (m_ * 0.6f);         cdf += t;")]),
+    dict(name="sky_shared_stream", stage="A13 / A15 random streams (exposure index in the key)",
+         what="the per-pixel read stream of k_ramp keyed without the exposure index: every exposure draws the same noise",
+         edits=[("k_ramp.h", "rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, a.exposure);",
+                 "rn = SeededStream(a.seed, STAGE_READ, (uint32_t)p, 0u, 0u);")]),
+    # --- cosmic rays (A13)
+    dict(name="cosmic_energy_range", stage="A13 cosmic rays (cosmic_rays.py:127-134)",
+         what="hit energies randint(20000, 45000) instead of (10000, 35000)",
+         edits=[("k_prep.h", "const uint32_t energy = 10000u + uint_below(w.v[0], 25000u);",
+                 "const uint32_t energy = 20000u + uint_below(w.v[0], 25000u);")]),
+    # --- counts chain / flat / trace (A9-A11)
+    dict(name="counts_chain_1pc", stage="A9 counts chain (exposure_generator.py:602-628)",
+         what="the 1e4 A / um factor of the counts chain 1 % high",
+         edits=[("k_prep.h", "  lam = lam * 1e4;", "  lam = lam * 1.01e4;")]),
+    dict(name="flat_cubic_terms", stage="A11 flat (grism.py:362-385)",
+         what="quadratic and cubic flat planes exchanged",
+         edits=[("k_throw.h", "((double)a.flat[2][i] * t2) +\n                   ((double)a.flat[3][i] * t3);",
+                 "((double)a.flat[2][i] * t3) +\n                   ((double)a.flat[3][i] * t2);")]),
+    # --- thrower (A1-A4)
+    dict(name="wide_sigma_2pc", stage="A4 wide PSF component (pyparallel_menu.c:87-108)",
+         what="sigma_h of the lane-thrown wide electrons 2.3 % large (k_lane)",
+         edits=[("k_narrow.h", "    ch = (-1.3862943611198906f * sh) * sh;", "    ch = (-1.45f * sh) * sh;")]),
+    dict(name="narrow_cell_masses", stage="A4 narrow PSF component as multinomials",
+         what="cell masses of the multinomial from a gaussian 1.8 % narrow (argument scale of the tail fit)",
+         edits=[("k_narrow.h", "const float z = t * 0.70710678118654752f;", "const float z = t * 0.72f;")]),
+    dict(name="lane_cos_sin_swapped", stage="A2 / A4 Box-Muller (pyparallel_menu.c:91-93)",
+         what="k_lane takes x from the sine and y from the cosine: the same law, other electrons",
+         edits=[("k_narrow.h", "    xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);      // C truncation toward zero (:91-92)\n"
+                               "    yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);",
+                 "    xi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, px);\n"
+                 "    yi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, py);")]),
+    dict(name="wide_count_rounded", stage="A4 N = (int)(counts ratio) (pyparallel_menu.c:89)",
+         what="the wide count rounded to nearest instead of truncated (thrower call and exposure path)",
+         edits=[("host_plan.h", "                                                   : (int32_t)nw;",
+                 "                                                   : (int32_t)(nw + 0.5);"),
+                ("k_prep.h", ": (int32_t)nw;", ": (int32_t)(nw + 0.5);")]),
+    # --- host planner
+    dict(name="boxes_too_small", stage="host planner: accumulator boxes of k_ramp",
+         what="reach of the accumulator boxes 3 sigma instead of 6.9 sigma: k_ramp never loads the electrons beyond",
+         edits=[("host_plan.h", "const double reach = 6.9 * e.smax + 2. + 1.;", "const double reach = 3.0 * e.smax + 2. + 1.;")]),
+    dict(name="read_trigger", stage="A12 read trigger (exposure_generator.py:336-378)",
+         what="every sub-sample accumulates into the read interval before its own (the first into its own)",
+         edits=[("k_prep.h", "  si.read = a.sample_read[k];", "  si.read = max(a.sample_read[k] - 1, 0);")]),
+]
+
+
+def lib_of(name):
+    return os.path.join(OUT_DIR, name + ".so")
+
+
+def build_one(m):
+    src = os.path.join(OUT_DIR, m["name"])
+    shutil.rmtree(src, ignore_errors=True)
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(src, "include"))
+    shutil.copytree(wb.CSRC, os.path.join(src, "wayne_amd", "csrc"))
+    for rel, old, new in m["edits"]:
+        p = os.path.join(src, "wayne_amd", "csrc", rel)
+        s = open(p).read()
+        if s.count(old) != 1:
+            raise SystemExit("mutant %s: %r occurs %d times in %s" % (m["name"], old, s.count(old), rel))
+        open(p, "w").write(s.replace(old, new))
+    cmd = [wb.HIPCC] + wb.FLAGS + ["-o", lib_of(m["name"]), os.path.join(src, "wayne_amd", "csrc", "wayne_hip.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("mutant %s does not compile:\n%s" % (m["name"], r.stderr[-3000:]))
+    shutil.rmtree(src, ignore_errors=True)
+    return m["name"]
+
+
+def verdict(output):
+    """(killed by | None, tail) from a `pytest -x -q` output."""
+    for line in output.splitlines():
+        if line.startswith("FAILED ") or line.startswith("ERROR "):
+            return line.split(" - ")[0].split(" ", 1)[1], line
+    return None, output.strip().splitlines()[-1] if output.strip() else ""
+
+
+def run_tests(lib, paths, extra=()):
+    env = dict(os.environ, WAYNE_HIP_LIB=lib)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", "not negative_control", "-p", "no:cacheprovider"]
+    cmd += list(extra) + list(paths)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    return verdict(r.stdout) + (time.time() - t0,)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else ""
+    names = sys.argv[2:]
+    todo = [m for m in MUTANTS if not names or m["name"] in names]
+    if what == "build":
+        os.makedirs(OUT_DIR, exist_ok=True)
+        with ThreadPoolExecutor(4) as ex:
+            for n in ex.map(build_one, todo):
+                print("built", n, flush=True)
+    elif what == "run":
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        rest = ["tests"] + ["--deselect=" + p for p in INDEPENDENT]
+        with open(REPORT, "a") as f:
+            def say(s):
+                print(s, flush=True)
+                f.write(s + "\n")
+                f.flush()
+            # the unmutated library first: the very same commands must be green
+            if not names:
+                k, tail, dt = run_tests(wb.LIB, INDEPENDENT)
+                say("%-22s | (the shipped library)                         | independent set: %s (%.0f s)" % (
+                    "none", "PASSED: " + tail if k is None else "FAILED " + k, dt))
+            for m in todo:
+                k, tail, dt = run_tests(lib_of(m["name"]), INDEPENDENT)
+                if k is not None:
+                    say("%-22s | %s | KILLED by the independent set: %s (%.0f s)" % (m["name"], m["what"], k, dt))
+                    continue
+                k2, tail2, dt2 = run_tests(lib_of(m["name"]), rest)
+                say("%-22s | %s | SURVIVED the independent set (%s, %.0f s); rest of the suite: %s (%.0f s)" % (
+                    m["name"], m["what"], tail, dt, "killed by " + k2 if k2 else "SURVIVED: " + tail2, dt2))
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,76 @@ def test_gain_variations_are_a_division_by_the_pixel_flat_gain(out_dtype):
     assert np.abs(var_gain[-1] - flat_gain[-1]).max() > 10.0           # (the pixel flat is there: 1 % of thousands of DN)
 
 
+@pytest.mark.parametrize("out_dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_dark_current_is_a_normal_about_the_super_dark_with_the_references_error_floor(out_dtype):
+    # detector.py:185-191: pixel_array + np.random.normal(dark, np.where(err > 0, err, 0.00001)), the frames of read NSAMP
+    # index n at HDU -5 n and -5 n + 1 of the mode's super-dark.  Two runs that differ in the dark switch alone (same
+    # electrons, read noise / non-linearity / clip off): their difference IS the dark draw.  Where the error plane is zero
+    # or negative (the synthetic planes sprinkle both) the draw sits within 6.8 x 1e-5 of the dark value -- found missing
+    # by scripts/mutation_audit.py: a floor of 0.01 instead of 1e-5 passed every test that does not go through the oracle
+    v = helpers.make_visit("cfg4")
+    sci, err = v.calibration.dark_frames(v.SUBARRAY, v.SAMPSEQ, v.read_times)
+    off = reads_of(v, out_dtype, add_dark=False, add_non_linear=False, clip_values_det_limits=False)
+    on = reads_of(v, out_dtype, add_dark=True, add_non_linear=False, clip_values_det_limits=False)
+    d = (on - off)[1:]                                                  # (15, S, S); the zero read has no dark
+    assert not (on[0] - off[0]).any()
+    d = d[:, 5:-5, 5:-5]
+    sci, err = sci[:, 5:-5, 5:-5].astype(np.float64), err[:, 5:-5, 5:-5].astype(np.float64)
+    # float32 reads round the sum (up to ~3e4 DN in the trace: ulp 2e-3; 2e-5 DN where only the sky is): keep to faint pixels
+    faint = off[1:, 5:-5, 5:-5] < 100.0
+    rnd = 2e-5 if out_dtype == np.float32 else 1e-12
+    floor = (err <= 0) & faint
+    assert (err[floor] == 0).sum() > 10000 and (err[floor] < 0).sum() > 5000
+    dev = d[floor] - sci[floor]
+    assert np.abs(dev).max() < 6.8e-5 + rnd, "a floor pixel %.2e DN from its dark value" % np.abs(dev).max()
+    if out_dtype == np.float64:
+        assert 0.9e-5 < dev.std() < 1.1e-5 and abs(dev.mean()) < 5e-5 / np.sqrt(dev.size)
+    # everywhere else: a unit normal once standardised by the error plane as it is
+    ok = (err > 0) & faint
+    z = (d[ok] - sci[ok]) / np.sqrt(err[ok] ** 2 + rnd ** 2)
+    assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1.0) < (2e-3 if out_dtype == np.float32 else 1e-3)
+    assert np.abs(z).max() < 6.9
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg5_g102", "cfg2"])
+def test_counts_chain_is_the_references_product(name):
+    # exposure_generator.py:600-628 and :678-684, as written: per wavelength bin and sub-sample
+    #     counts = flux (1 - depth) x sensitivity(wl) x delta_lambda [um -> A: 1e4] x exptime [ms -> s: 1e-3] x scale_factor
+    # with the sensitivity np.interp'ed from the grism's table (grism.py:116-118), delta_lambda = tools.bin_centers_to_widths
+    # of the CROPPED grid (tools.py:106-128: half-gaps to both neighbours, the end bins mirroring theirs), and np.round when
+    # the stellar noise is off (:627).  k_prep's counts against that product evaluated HERE, in numpy, from the visit's
+    # arrays -- no oracle (the audit's mutant with the 1e4 factor 1 % high passed every oracle-free test before this one)
+    from wayne_amd import tools
+    v = helpers.make_visit(name)
+    rec = {}
+    kw = v.frame_kwargs(0, add_stellar_noise=False, cosmic_rate=None)
+    helpers.product_generator(v, 0).scanning_frame(out_dtype=np.float32, record=rec, **kw)
+    lo, hi = v.grism.wl_limits
+    i0, i1 = tools.crop_spectrum_ind(lo, hi, v.wl.copy())
+    wl, flux = v.wl[i0:i1], kw["stellar_flux"][i0:i1]
+    # (the widths, spelled out from tools.py:106-128)
+    half = (wl - np.roll(wl, 1)) / 2.0
+    half[0] = half[1]
+    nxt = np.roll(half, -1)
+    nxt[-1] = half[-1]
+    dlam = half + nxt
+    swl, sval = v.calibration.sensitivity(v.grism.name)
+    sens = np.interp(wl, swl, sval)
+    depth = np.asarray(kw["planet_signal"])
+    depth = depth[:, i0:i1] if depth.ndim == 2 else depth[i0:i1][None, :]
+    dur = np.asarray(rec["dur"], dtype=np.float64)[:, None]
+    want = flux[None, :] * (1.0 - depth) * sens[None, :] * dlam[None, :] * 1e4 * dur * 1e-3 * kw["scale_factor"]
+    got = np.asarray(rec["counts"], dtype=np.float64)
+    assert got.shape == want.shape and want.max() > 100.0
+    # np.round of a product evaluated in another order of operations: equal except where the product lies within an ulp
+    # of a half-integer
+    diff = got - np.round(want)
+    assert np.abs(diff).max() <= 1.0 and (diff != 0).mean() < 1e-4, (np.abs(diff).max(), (diff != 0).mean())
+    near_tie = np.abs(want - np.floor(want) - 0.5) < 1e-6 * np.maximum(want, 1.0)
+    assert not (diff != 0)[~near_tie].any()
+    assert abs(got.sum() - np.round(want).sum()) <= (diff != 0).sum()
+
+
 def test_initial_bias_is_added_to_every_read_of_a_256_subarray():
     v = helpers.make_visit("small256")
     bias = np.asarray(v.calibration.bias_256, dtype=np.float64)
