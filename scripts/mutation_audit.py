@@ -117,6 +117,48 @@ MUTANTS = [
     dict(name="read_trigger", stage="A12 read trigger (exposure_generator.py:336-378)",
          what="every sub-sample accumulates into the read interval before its own (the first into its own)",
          edits=[("k_prep.h", "  si.read = a.sample_read[k];", "  si.read = max(a.sample_read[k] - 1, 0);")]),
+    # --- second wave
+    dict(name="dark_read_shifted", stage="A15 dark (detector.py:183-190: the frame of read NSAMP index n)",
+         what="read 1 takes the dark frame of read 2 (its error plane stays its own)",
+         edits=[("k_ramp.h", "float ds_next = ld_dark ? ld_f32(rs_ds, 0) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;",
+                 "float ds_next = ld_dark ? ld_f32(rs_ds, 1) : 0.f, de_next = ld_dark ? ld_f32(rs_de, 0) : 0.f;")]),
+    dict(name="nonlinear_f64_c3_c4", stage="A15 non-linearity, float64 chain",
+         what="cubic and quartic coefficients exchanged in the float64 solve's residual",
+         edits=[("k_ramp.h", "const double f = fma(u0, fma(u0, fma(u0, fma(k4, u0, k3), k2), k1), -px);",
+                 "const double f = fma(u0, fma(u0, fma(u0, fma(k3, u0, k4), k2), k1), -px);")]),
+    dict(name="sens_nearest_lower", stage="A8 sensitivity (grism.py:116-118: np.interp)",
+         what="the sensitivity table read at the entry below the wavelength instead of interpolated",
+         edits=[("k_prep.h", "    s = slope * (x - g.sens_wl[lo]) + g.sens_val[lo];", "    s = 0. * slope + g.sens_val[lo];")]),
+    dict(name="dlam_end_bins", stage="A9 bin widths (tools.py:106-128)",
+         what="the end bins take one half-gap instead of mirroring it",
+         edits=[("k_prep.h", "    left = (i == 0) ? (wl[1] - wl[0]) / 2. : (wl[i] - wl[i - 1]) / 2.;",
+                 "    left = (i == 0) ? 0. : (wl[i] - wl[i - 1]) / 2.;")]),
+    dict(name="sigl_from_sigh_poly", stage="A8 PSF polynomials (grism.py:85-90)",
+         what="sigma_l evaluated with the polynomial of sigma_h",
+         edits=[("k_prep.h", "  o.sigl[i] = poly3(g.p_sigl, x);", "  o.sigl[i] = poly3(g.p_sigh, x);")]),
+    dict(name="trace_cross_term", stage="A6 / A7 trace (grism.py:779-803)",
+         what="the x y term of the trace's slope polynomial dropped",
+         edits=[("plan_consts.h", "                       t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);\n    const double c_t",
+                 "                       0. * t[7] * x_ref * y_ref + t[8] * (y_ref * y_ref);\n    const double c_t")]),
+    dict(name="wl_solution_cross_term", stage="A6 / A7 dispersion solution (grism.py:779-803)",
+         what="the x y term of the dispersion polynomial dropped",
+         edits=[("plan_consts.h", "                       b[7] * x_ref * y_ref + b[8] * (y_ref * y_ref);",
+                 "                       0. * b[7] * x_ref * y_ref + b[8] * (y_ref * y_ref);")]),
+    dict(name="alias_table_bias", stage="A13 sky: Walker tables of the host planner",
+         what="the alias construction takes 0.995 instead of 1 off a donor column",
+         edits=[("host_plan.h", "    q[l_] = (q[l_] + q[s_]) - 1.;", "    q[l_] = (q[l_] + q[s_]) - 0.995;")]),
+    dict(name="cosmic_rate_unscaled", stage="A13 cosmic rays (cosmic_rays.py:33-44: rate per 1024^2 scaled to the frame)",
+         what="the hit rate not scaled to the frame's size",
+         edits=[("k_prep.h", "const double rate_size = a.rate / (1024. * 1024.) * (double)((long long)a.N * a.N);",
+                 "const double rate_size = a.rate;")]),
+    dict(name="lc_limb_exponent", stage="f3 light curves (observation.py:293-357; Claret law)",
+         what="the third limb-darkening term with mu^2 instead of mu^(3/2) in the quadrature",
+         tests=["tests/test_lightcurve.py"],
+         edits=[("k_lightcurve.h", "- a3 * (1.f - mu * sm) - a4", "- a3 * (1.f - mu * mu) - a4")]),
+    dict(name="lc_eclipse_norm", stage="f3 eclipse term (observation.py:352-355)",
+         what="the eclipse term without its 1 / (1 + f) normalisation",
+         tests=["tests/test_lightcurve.py"],
+         edits=[("k_lightcurve.h", "      ecl = f * hid / (1. + f);", "      ecl = f * hid;")]),
 ]
 
 
@@ -183,11 +225,11 @@ def main():
                 say("%-22s | (the shipped library)                         | independent set: %s (%.0f s)" % (
                     "none", "PASSED: " + tail if k is None else "FAILED " + k, dt))
             for m in todo:
-                k, tail, dt = run_tests(lib_of(m["name"]), INDEPENDENT)
+                k, tail, dt = run_tests(lib_of(m["name"]), INDEPENDENT + m.get("tests", []))
                 if k is not None:
                     say("%-22s | %s | KILLED by the independent set: %s (%.0f s)" % (m["name"], m["what"], k, dt))
                     continue
-                k2, tail2, dt2 = run_tests(lib_of(m["name"]), rest)
+                k2, tail2, dt2 = run_tests(lib_of(m["name"]), rest + ["--deselect=" + p for p in m.get("tests", [])])
                 say("%-22s | %s | SURVIVED the independent set (%s, %.0f s); rest of the suite: %s (%.0f s)" % (
                     m["name"], m["what"], tail, dt, "killed by " + k2 if k2 else "SURVIVED: " + tail2, dt2))
     else:

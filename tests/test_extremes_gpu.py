@@ -362,24 +362,26 @@ def test_thrower_largest_single_pixel_deviation_at_full_size():
     assert t_bright.n > 2e5 and t_dim.n > 2e5 and 4.0 < worst_excess < 6.5
 
 
-@pytest.mark.parametrize("path", ["k_prep_sub", "k_lane_fused"])
-def test_cosmic_ray_hits_follow_their_three_laws(path, monkeypatch):
+@pytest.mark.parametrize("path,name,N,n_exp", [("k_prep_sub", "cfg5", 1014, 8), ("k_lane_fused", "cfg5", 1014, 8),
+                                              ("k_lane_fused", "cfg3", 256, 24)])
+def test_cosmic_ray_hits_follow_their_three_laws(path, name, N, n_exp, monkeypatch):
     # MinMaxPossionCosmicGenerator.cosmic_frame (cosmic_rays.py:70-139): per read interval Poisson(rate N^2 / 1024^2 dt)
     # hits, each with energy randint(10000, 35000) (upper bound exclusive) at a pixel randint(0, N)^2, hits on one pixel
     # adding.  Star off: the accumulators hold the hits and nothing else -- 8 exposures x 15 intervals, ~12 000 hits.
     # The hits ride in the first workgroups of k_prep_sub (the benchmarked sequence) or, on a thin exposure -- which a
-    # star this dim is -- of k_lane_fused: both, the first forced with WAYNE_NO_FUSE.
+    # star this dim is -- of k_lane_fused: both, the first forced with WAYNE_NO_FUSE.  And on a SUB-ARRAY (256: the rate
+    # scales by 1 / 16 -- scripts/mutation_audit.py: an unscaled rate is 2 % at the full array and passed there).
     from scipy import stats
     if path == "k_prep_sub":
         monkeypatch.setenv("WAYNE_NO_FUSE", "1")
-    v = helpers.make_visit("cfg5", n_exposures=8)
-    rate, N = 11.0, 1014
+    v = helpers.make_visit(name, n_exposures=n_exp)
+    rate = 11.0
     dt = np.diff(np.concatenate([[0.0], v.read_times]))
     lam = rate * (N * N) / 1024.0 ** 2 * dt
     rng = np.random.default_rng(5)
     counts, energies, xs_, ys_ = [], [], [], []
     doubles = 0
-    for i in range(8):
+    for i in range(n_exp):
         rec = {}
         pg = helpers.product_generator(v, i)
         pg.scanning_frame(out_dtype=np.float32, record=rec, **v.frame_kwargs(i, cosmic_rate=rate, add_flat=False, **{
@@ -389,7 +391,7 @@ def test_cosmic_ray_hits_follow_their_three_laws(path, monkeypatch):
         for r in range(acc.shape[0]):
             yy, xx = np.nonzero(acc[r])
             e = acc[r][yy, xx]
-            assert np.all(e == np.rint(e)) and e.min() >= 10000
+            assert np.all(e == np.rint(e)) and (e.size == 0 or e.min() >= 10000)
             two = e >= 35000                                   # two hits on one pixel add (:134-139): counted as two
             doubles += int(two.sum())
             counts.append(e.size + int(two.sum()))
@@ -399,7 +401,7 @@ def test_cosmic_ray_hits_follow_their_three_laws(path, monkeypatch):
     counts = np.array(counts, dtype=float)
     e = np.concatenate(energies)
     x, y = np.concatenate(xs_), np.concatenate(ys_)
-    lam_all = np.tile(lam, 8)
+    lam_all = np.tile(lam, n_exp)
     t = xs.poisson_tails(counts, lam_all, rng)
     z_total = (counts.sum() - lam_all.sum()) / np.sqrt(lam_all.sum())
     # energies: discrete uniform on 10000 .. 34999
@@ -407,14 +409,15 @@ def test_cosmic_ray_hits_follow_their_three_laws(path, monkeypatch):
     # positions: uniform on the light-sensitive N x N pixels (chi-square on an 8 x 8 grid) and both axes use all of it
     grid = np.histogram2d(y, x, bins=8, range=[[0, N], [0, N]])[0]
     chi2 = ((grid - x.size / 64.0) ** 2 / (x.size / 64.0)).sum()
-    report("cosmic/cfg5/" + path, hits=int(counts.sum()), expected=float(lam_all.sum()), z_total=float(z_total), doubles=doubles,
+    report("cosmic/%s/%s" % (name, path), hits=int(counts.sum()), expected=float(lam_all.sum()), z_total=float(z_total), doubles=doubles,
            energy_ks_p=float(ks.pvalue), energy_min=float(e.min()), energy_max=float(e.max()), position_chi2=float(chi2),
            min_u_hi=float(t.u_hi.min()) if t.u_hi.size else None, min_u_lo=float(t.u_lo.min()) if t.u_lo.size else None)
     assert abs(z_total) < 5.0 and not xs.check(t, "hits per interval", qs=())
-    assert ks.pvalue > 1e-4 and e.min() <= 10100 and 34900 <= e.max() <= 34999
+    edge = 100 if e.size > 5000 else 400
+    assert ks.pvalue > 1e-4 and e.min() <= 10000 + edge and 34999 - edge <= e.max() <= 34999
     assert chi2 < 63 + 6 * np.sqrt(2 * 63.0)
     assert x.min() == 0 and y.min() == 0 and x.max() == N - 1 and y.max() == N - 1 or (x.max() >= N - 3 and y.max() >= N - 3)
-    assert doubles <= 6
+    assert doubles <= 6 + 3.0 * float((lam_all ** 2).sum()) / (2.0 * N * N)     # (two hits on one pixel: n^2 / 2 N^2 per interval)
 
 
 # ---------------------------------------------------------------------------------------------------------------
