@@ -162,6 +162,27 @@ MUTANTS = [
 ]
 
 
+# Mutants of the HOST half (Python: sample loop, read trigger, frame offset, scan positions -- SURVEY 8 row A12): edits are
+# relative to the repository root and the tests run in a temporary copy of the tree (the shipped library as it is).
+PY_MUTANTS = [
+    dict(name="py_scan_speed", stage="A12 scan positions (exposure_generator.py:247, 258)",
+         what="scan speed 1 % high in the sub-samples' y positions",
+         edits=[("wayne_amd/exposure_generator.py", "scan_speed_ms = scan_speed / 1000.          # px/s -> px/ms (:247)",
+                 "scan_speed_ms = scan_speed / 1000. * 1.01")]),
+    dict(name="py_read_trigger", stage="A12 read trigger (`if i in read_index`, exposure_generator.py:361)",
+         what="the sub-sample that closes a read is counted into the next read",
+         edits=[("wayne_amd/exposure_generator.py", 'np.searchsorted(np.asarray(read_index), np.arange(K), side="left")',
+                 'np.minimum(np.searchsorted(np.asarray(read_index), np.arange(K), side="right"), R - 1)')]),
+    dict(name="py_sub_scale", stage="A10 sub-array offset (exposure_generator.py:630)",
+         what="frame offset 512 - SUBARRAY / 2 instead of 507 - SUBARRAY / 2",
+         edits=[("wayne_amd/exposure_generator.py", "sub_scale = 507 - self.SUBARRAY // 2", "sub_scale = 512 - self.SUBARRAY // 2")]),
+    dict(name="py_read_dt", stage="A13 read intervals (exposure_generator.py:362-365)",
+         what="every read interval as long as the first",
+         edits=[("wayne_amd/exposure_generator.py", "read_dt = np.diff(np.concatenate([[0.0], self.read_times]))                   # (:362-365)",
+                 "read_dt = np.full(len(self.read_times), float(self.read_times[0]))")]),
+]
+
+
 def lib_of(name):
     return os.path.join(OUT_DIR, name + ".so")
 
@@ -202,10 +223,42 @@ def run_tests(lib, paths, extra=()):
     return verdict(r.stdout) + (time.time() - t0,)
 
 
+def run_py_mutant(m, say):
+    """A host-Python mutant: the tests run in a temporary copy of the tree with the edit applied."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "repo")
+        shutil.copytree(ROOT, dst, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "mutants", "__pycache__",
+                                                                 ".pytest_cache"))
+        for rel, old, new in m["edits"]:
+            p = os.path.join(dst, rel)
+            s = open(p).read()
+            if s.count(old) != 1:
+                raise SystemExit("mutant %s: %r occurs %d times in %s" % (m["name"], old, s.count(old), rel))
+            open(p, "w").write(s.replace(old, new))
+        env = {k: v for k, v in os.environ.items() if k != "WAYNE_HIP_LIB"}
+
+        def run(paths, marker):
+            cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", marker, "-k", "not negative_control", "-p",
+                   "no:cacheprovider"] + list(paths)
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd=dst, env=env, capture_output=True, text=True, timeout=1500)
+            return verdict(r.stdout) + (time.time() - t0,)
+
+        k, tail, dt = run(INDEPENDENT + ["tests/test_reference_goldens.py"], "gpu or not gpu")
+        if k is not None:
+            say("%-22s | %s | KILLED by the independent set: %s (%.0f s)" % (m["name"], m["what"], k, dt))
+            return
+        k2, tail2, dt2 = run(["tests"] + ["--deselect=" + p_ for p_ in INDEPENDENT], "gpu")
+        say("%-22s | %s | SURVIVED the independent set (%s, %.0f s); rest of the GPU suite: %s (%.0f s)" % (
+            m["name"], m["what"], tail, dt, "killed by " + k2 if k2 else "SURVIVED: " + tail2, dt2))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else ""
     names = sys.argv[2:]
     todo = [m for m in MUTANTS if not names or m["name"] in names]
+    todo_py = [m for m in PY_MUTANTS if m["name"] in names]
     if what == "build":
         os.makedirs(OUT_DIR, exist_ok=True)
         with ThreadPoolExecutor(4) as ex:
@@ -224,6 +277,8 @@ def main():
                 k, tail, dt = run_tests(wb.LIB, INDEPENDENT)
                 say("%-22s | (the shipped library)                         | independent set: %s (%.0f s)" % (
                     "none", "PASSED: " + tail if k is None else "FAILED " + k, dt))
+            for m in todo_py:
+                run_py_mutant(m, say)
             for m in todo:
                 k, tail, dt = run_tests(lib_of(m["name"]), INDEPENDENT + m.get("tests", []))
                 if k is not None:

@@ -179,6 +179,40 @@ def test_counts_chain_is_the_references_product(name):
     assert abs(got.sum() - np.round(want).sum()) <= (diff != 0).sum()
 
 
+@pytest.mark.parametrize("name", ["cfg4", "cfg3", "cfg5_g102", "tiny512"])
+def test_bin_positions_are_the_references_trace_scan_and_frame_offset(name):
+    # exposure_generator.py:258, 517-529, 591-594, 630-632, as written: at sub-sample i the star sits at
+    # (x_ref + jitter, y_ref + mid_point_i x scan_speed), a bin of wavelength wl at trace.wl_to_x / wl_to_y of that star, and
+    # on the frame at that position minus 507 - SUBARRAY / 2 (0 at the full array here: the reference's -5 there shifts
+    # the spectrum off its own flat, DESIGN.md section 1, kept only with reference_quirks).  The trace is the product's
+    # PYTHON `_SpectrumTrace` -- whose coefficients and wavelength map are held to the reference's own test values in
+    # tests/test_reference_goldens.py -- evaluated here; the positions are the DEVICE's (k_prep_wl / k_prep_sub).  No oracle:
+    # the audit's mutants "scan speed 1 % high" and "offset 512 - SUBARRAY / 2" were stopped only by tests that restate the host loop.
+    from wayne_amd import tools
+    v = helpers.make_visit(name)
+    rec = {}
+    kw = v.frame_kwargs(0, add_stellar_noise=False, cosmic_rate=None)
+    helpers.product_generator(v, 0).scanning_frame(out_dtype=np.float32, record=rec, **kw)
+    lo, hi = v.grism.wl_limits
+    i0, i1 = tools.crop_spectrum_ind(lo, hi, v.wl.copy())
+    wl = v.wl[i0:i1]
+    sub_scale = 0 if v.SUBARRAY == 1024 else 507 - v.SUBARRAY // 2
+    mid = np.asarray(v.sample_mid_points, dtype=float)                       # ms
+    y_star = v.y_refs[0] + mid * (v.scan_speed / 1000.0)                     # px/s -> px/ms (:247)
+    K = len(mid)
+    assert rec["x"].shape == rec["y"].shape == (K, wl.size)
+    # the star's x is x_ref + N(0, x_jitter) per sub-sample (:327-329): the draw is the product's own, its size is not
+    jit = np.asarray(rec["x_ref"]) - v.x_refs[0]
+    assert np.abs(jit).max() < 6 * v.x_jitter and (K < 20 or 0.5 * v.x_jitter < jit.std() < 1.5 * v.x_jitter)
+    np.testing.assert_allclose(rec["y_ref"], y_star, rtol=0, atol=1e-9)      # (y_jitter is 1e-15 in these visits)
+    if name != "tiny512":
+        assert y_star[-1] - y_star[0] > 20.0                                 # (a real scan: 1 % of it is a fraction of a pixel or more)
+    for k in sorted(set([0, K // 3, K - 1])):
+        tr = v.grism.get_trace(float(rec["x_ref"][k]), float(y_star[k]))
+        np.testing.assert_allclose(rec["x"][k], tr.wl_to_x(wl) - sub_scale, rtol=0, atol=1e-8, err_msg="x, sub-sample %d" % k)
+        np.testing.assert_allclose(rec["y"][k], tr.wl_to_y(wl) - sub_scale, rtol=0, atol=1e-8, err_msg="y, sub-sample %d" % k)
+
+
 def test_initial_bias_is_added_to_every_read_of_a_256_subarray():
     v = helpers.make_visit("small256")
     bias = np.asarray(v.calibration.bias_256, dtype=np.float64)
