@@ -180,6 +180,14 @@ PY_MUTANTS = [
          what="every read interval as long as the first",
          edits=[("wayne_amd/exposure_generator.py", "read_dt = np.diff(np.concatenate([[0.0], self.read_times]))                   # (:362-365)",
                  "read_dt = np.full(len(self.read_times), float(self.read_times[0]))")]),
+    dict(name="py_ssv_amplitude", stage="A12 scan speed variations (scan_speed_varations.py:33-60)",
+         what="the sine's amplitude doubled (stddev / 50 instead of / 100)",
+         edits=[("wayne_amd/trend_generators/scan_speed_varations.py", "ssv_scaling = (self.stddev / 100.) * np.sin(",
+                 "ssv_scaling = (self.stddev / 50.) * np.sin(")]),
+    dict(name="py_sample_mid_points", stage="A12 sample loop (exposure_generator.py:531-579)",
+         what="sub-sample mid-points a third into the sub-sample instead of half",
+         edits=[("wayne_amd/exposure_generator.py", "sample_mid_points = sample_starts + (sample_durations / 2)",
+                 "sample_mid_points = sample_starts + (sample_durations / 3)")]),
 ]
 
 
