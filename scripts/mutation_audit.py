@@ -4,6 +4,7 @@ which test notices.
 
     python scripts/mutation_audit.py build            # here (hipcc cross-compiles): tests/native/_build/mutants/<name>.so
     python scripts/mutation_audit.py run [name ...]   # on the GPU box: gpurun_out/mutation_audit.txt
+    python scripts/mutation_audit.py cpu [name ...]   # here: host-only mutants (FITS writer) against the CPU suite
 
 Why.  The oracle restates the reference's algorithm, and for three rounds it shared a defect with the kernels it checks
 (the sky draw's runaway search): same-counter parity was green with ~500 spurious electrons in one pixel per exposure.
@@ -191,6 +192,21 @@ PY_MUTANTS = [
 ]
 
 
+# Mutants of host code no GPU test is needed for (the FITS writer): `python scripts/mutation_audit.py cpu
+# [name ...]` runs the CPU suite in a temporary copy of the tree.
+CPU_MUTANTS = [
+    dict(name="fits_read_order", stage="f1 FITS layout (exposure.py:133-214: reads in reverse time order)",
+         what="the reads written first read first",
+         edits=[("wayne_amd/exposure.py", "            samp = n - 1 - i\n", "            samp = i\n")]),
+    dict(name="fits_bunit", stage="f1 FITS extension header (exposure.py:186-199)",
+         what="BUNIT = ELECTRONS instead of COUNTS",
+         edits=[("wayne_amd/exposure.py", '("BUNIT", "COUNTS", "")', '("BUNIT", "ELECTRONS", "")')]),
+    dict(name="fits_byte_order", stage="f1 FITS data (big-endian float64)",
+         what="the image cube left in the host's byte order",
+         edits=[("wayne_amd/exposure.py", 'cube = np.empty((n,) + arrs[0].shape, dtype=">f8")', 'cube = np.empty((n,) + arrs[0].shape, dtype="<f8")')]),
+]
+
+
 def lib_of(name):
     return os.path.join(OUT_DIR, name + ".so")
 
@@ -295,6 +311,26 @@ def main():
                 k2, tail2, dt2 = run_tests(lib_of(m["name"]), rest + ["--deselect=" + p for p in m.get("tests", [])])
                 say("%-22s | %s | SURVIVED the independent set (%s, %.0f s); rest of the suite: %s (%.0f s)" % (
                     m["name"], m["what"], tail, dt, "killed by " + k2 if k2 else "SURVIVED: " + tail2, dt2))
+    elif what == "cpu":
+        import tempfile
+        for m in [m for m in CPU_MUTANTS if not names or m["name"] in names]:
+            with tempfile.TemporaryDirectory() as tmp:
+                dst = os.path.join(tmp, "repo")
+                shutil.copytree(ROOT, dst, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "mutants",
+                                                                         "__pycache__", ".pytest_cache"))
+                for rel, old, new in m["edits"]:
+                    p = os.path.join(dst, rel)
+                    s = open(p).read()
+                    if s.count(old) != 1:
+                        raise SystemExit("mutant %s: %r occurs %d times in %s" % (m["name"], old, s.count(old), rel))
+                    open(p, "w").write(s.replace(old, new))
+                t0 = time.time()
+                r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider", "tests"],
+                                   cwd=dst, capture_output=True, text=True, timeout=1500,
+                                   env={k: v for k, v in os.environ.items() if k != "WAYNE_HIP_LIB"})
+                k, tail = verdict(r.stdout)
+                print("%-22s | %s | CPU suite: %s (%.0f s)" % (m["name"], m["what"], "KILLED by " + k if k else "SURVIVED: " + tail,
+                                                              time.time() - t0), flush=True)
     else:
         raise SystemExit(__doc__)
 

@@ -63,6 +63,13 @@ def test_exposure_file_layout_and_primary_header(tmp_path):
     np.testing.assert_array_equal(sci[0].data, frames[3].astype(np.float64))
     np.testing.assert_array_equal(sci[3].data, frames[0].astype(np.float64))
     assert sci[0].header["SAMPTIME"] == pytest.approx(t[2]) and sci[3].header["SAMPTIME"] == 0.0
+    # the read header's three cards (exposure.py:413-430) and SAMPNUM (:161) are the reference's; EXTVER (1 for the last
+    # read, counting up, on all five extensions of a read) and BUNIT = COUNTS are this writer's additions, as in a real
+    # _raw file -- a superset a reader of the reference's files never misses
+    assert sci[0].header["DELTATIM"] == pytest.approx(t[2] - t[1]) and sci[2].header["DELTATIM"] == pytest.approx(t[0])
+    assert [x.header["CRPIX1"] for x in sci] == [0, 0, 0, 0]
+    assert [x.header["EXTVER"] for x in sci] == [1, 2, 3, 4] and all(x.header["BUNIT"] == "COUNTS" for x in sci)
+    assert [x.header["EXTVER"] for x in h[1:6]] == [1] * 5 and [x.header["EXTVER"] for x in h[16:21]] == [4] * 5
     p0 = h[0].header
     assert p0["TELESCOP"] == "HST" and p0["INSTRUME"] == "WFC3" and p0["DETECTOR"] == "IR" and p0["FILTER"] == "G141"
     assert p0["EXPSTART"] == pytest.approx(2456196.25 - 2400000.5, abs=1e-9) and p0["EXPTIME"] == pytest.approx(t[-1])
