@@ -160,6 +160,9 @@ MUTANTS = [
          what="the eclipse term without its 1 / (1 + f) normalisation",
          tests=["tests/test_lightcurve.py"],
          edits=[("k_lightcurve.h", "      ecl = f * hid / (1. + f);", "      ecl = f * hid;")]),
+    dict(name="lane_no_tail_refinement", stage="A2 / A4 wide electrons beyond 4.85 sigma (k_lane's one-word draw)",
+         what="the radius cell h = 0 not subdivided: 1.5e-5 of the wide electrons land AT 4.855 sigma, none beyond",
+         edits=[("k_narrow.h", "if (__builtin_expect(h == 0u, 0)) {", "if (false) {")]),
 ]
 
 

@@ -362,6 +362,47 @@ def test_thrower_largest_single_pixel_deviation_at_full_size():
     assert t_bright.n > 2e5 and t_dim.n > 2e5 and 4.0 < worst_excess < 6.5
 
 
+@pytest.mark.parametrize("mode", [_lib.RNG_SPLIT, _lib.RNG_PHILOX], ids=["k_lane", "k_throw"])
+def test_wide_electrons_populate_the_gaussian_tail_out_to_their_reach(gpu_ctx, mode):
+    # pyparallel_menu.c:87-108: an electron lands at (int)(x + sigma z_x), (int)(y + sigma z_y), z a pair of Box-Muller normals --
+    # a 2-D gaussian whose radius has the tail exp(-r^2 / 2).  k_lane draws the radius from ONE 16-bit half-word and
+    # subdivides its last cell (R > 4.7 sigma, 1.5e-5 of the electrons) by a side stream; without that subdivision every
+    # such electron would sit AT 4.855 sigma and nothing beyond -- a defect the audit (scripts/mutation_audit.py) showed
+    # only same-counter parity could see.  4 x 10^8 wide electrons from one position: the pixels between 5 and 6.8 sigma
+    # hold what the gaussian's exact pixel masses say (~1300, ~180, ~6 electrons in three rings), and none lies beyond
+    # the draw's reach (6.87 sigma in k_lane, 6.76 in the per-electron thrower: u >= 2^-33 / 2^-32)
+    from scipy.stats import norm
+    B, n_each, calls, sig, cx, cy, N = 50000, 4000, 2, 5.5, 507.3, 507.6, 1014       # (a thrower call takes <= 65536 bins)
+    counts = np.full(B, n_each, dtype=np.int32)
+    one = np.ones(B)
+    f = np.zeros((N, N))
+    for e in range(calls):
+        f += np.asarray(gpu_ctx.psf_apply(counts, cx * one, cy * one, 1.0 * one, 0.7 * one, sig * one, N, N, 31337, 1,
+                                          rng_mode=mode, exposure=e), dtype=np.float64).reshape(N, N)
+    total = float(B) * n_each * calls
+    assert f.sum() == total
+    edges = np.arange(N + 1, dtype=np.float64)
+    px = np.diff(norm.cdf((edges - cx) / sig))                       # P(column): (int) truncation = floor on a positive position
+    py = np.diff(norm.cdf((edges - cy) / sig))
+    mean = total * np.outer(py, px)
+    yy, xx = np.mgrid[0:N, 0:N]
+    d = np.hypot(xx + 0.5 - cx, yy + 0.5 - cy) / sig                  # pixel centre, in sigma
+    got, want = {}, {}
+    for ring, (lo, hi) in {"5.0-5.4": (5.0, 5.4), "5.4-6.0": (5.4, 6.0), "6.0-6.8": (6.0, 6.8)}.items():
+        m = (d >= lo) & (d < hi)
+        got[ring], want[ring] = float(f[m].sum()), float(mean[m].sum())
+    beyond = float(f[d >= 7.05].sum())
+    report("thrower/far_tail/" + ("k_lane" if mode == _lib.RNG_SPLIT else "k_throw"), electrons=total, observed=got,
+           expected=want, beyond_7p05_sigma=beyond)
+    assert 1000 < want["5.0-5.4"] < 1700 and 100 < want["5.4-6.0"] < 260 and 2 < want["6.0-6.8"] < 12
+    for ring in got:
+        assert abs(got[ring] - want[ring]) < 5.0 * np.sqrt(want[ring]) + 3.0, (ring, got[ring], want[ring])
+    assert beyond == 0.0
+    # and the core is where it belongs: the whole frame against the exact masses, pixel by pixel
+    z = (f - mean) / np.sqrt(np.maximum(mean * (1.0 - mean / total), 1e-300))
+    assert np.abs(z[mean > 50.0]).max() < 6.0
+
+
 @pytest.mark.parametrize("path,name,N,n_exp", [("k_prep_sub", "cfg5", 1014, 8), ("k_lane_fused", "cfg5", 1014, 8),
                                               ("k_lane_fused", "cfg3", 256, 24)])
 def test_cosmic_ray_hits_follow_their_three_laws(path, name, N, n_exp, monkeypatch):
