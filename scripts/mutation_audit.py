@@ -163,6 +163,15 @@ MUTANTS = [
     dict(name="lane_no_tail_refinement", stage="A2 / A4 wide electrons beyond 4.85 sigma (k_lane's one-word draw)",
          what="the radius cell h = 0 not subdivided: 1.5e-5 of the wide electrons land AT 4.855 sigma, none beyond",
          edits=[("k_narrow.h", "if (__builtin_expect(h == 0u, 0)) {", "if (false) {")]),
+    dict(name="narrow_tail_cut", stage="A4 narrow component: where the multinomial's window ends",
+         what="the gaussian tail taken as 0 beyond 4 sigma_l instead of 6.5",
+         edits=[("k_narrow.h", "constexpr float kTailCut = 6.5f;", "constexpr float kTailCut = 4.0f;")]),
+    dict(name="sky_remainder_capped", stage="A13 sky Poisson: the remainder beyond three",
+         what="the remainder's search stops at 3 (no fourth compare, no continuation)",
+         edits=[("k_ramp.h", "  if (wr > sr.t3) {\n    k += 1;", "  if (false) {\n    k += 1;")]),
+    dict(name="ptrs_quick_accept", stage="A9 stellar Poisson noise (PTRS: Hoermann's transformed rejection)",
+         what="the quick-acceptance region of a trial widened (us >= 0.03 instead of 0.07): no density test where one is due",
+         edits=[("samplers.h", "    if (us >= (T)0.07 && V <= vr) return 1;", "    if (us >= (T)0.03 && V <= vr) return 1;")]),
 ]
 
 

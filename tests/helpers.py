@@ -63,3 +63,25 @@ def split_moved_bound(counts, total, exact=False):
     n_chain = 16.0 * float(counts.max()) if counts.size else 0.0
     rate = 2e-6 if exact else 1e-4        # measured: 3.5e-7 / 5e-6 at 1e9 electrons, 2.5e-8 / 2.3e-5 at 1.2e8
     return 2 + rate * float(total) + 3.0 * np.sqrt(n_chain)
+
+
+def reference_counts(v, kw, dur_ms):
+    """The reference's counts chain, as written (exposure_generator.py:600-628, 678-684), per (sub-sample, cropped bin) BEFORE
+    the Poisson draw / np.round:
+        flux (1 - depth) x np.interp'ed sensitivity x tools.bin_centers_to_widths [um -> A: 1e4] x exptime [ms -> s: 1e-3] x scale
+    evaluated in numpy from the visit's own arrays -- no oracle.  Returns (rates (K, W_cropped), cropped wavelengths)."""
+    from wayne_amd import tools
+    lo, hi = v.grism.wl_limits
+    i0, i1 = tools.crop_spectrum_ind(lo, hi, v.wl.copy())
+    wl, flux = v.wl[i0:i1], np.asarray(kw["stellar_flux"], dtype=float)[i0:i1]
+    half = (wl - np.roll(wl, 1)) / 2.0                       # tools.py:106-128, spelled out
+    half[0] = half[1]
+    nxt = np.roll(half, -1)
+    nxt[-1] = half[-1]
+    dlam = half + nxt
+    swl, sval = v.calibration.sensitivity(v.grism.name)
+    sens = np.interp(wl, swl, sval)                           # grism.py:116-118
+    depth = np.asarray(kw["planet_signal"])
+    depth = depth[:, i0:i1] if depth.ndim == 2 else depth[i0:i1][None, :]
+    dur = np.asarray(dur_ms, dtype=np.float64)[:, None]
+    return flux[None, :] * (1.0 - depth) * sens[None, :] * dlam[None, :] * 1e4 * dur * 1e-3 * kw["scale_factor"], wl

@@ -148,26 +148,11 @@ def test_counts_chain_is_the_references_product(name):
     # of the CROPPED grid (tools.py:106-128: half-gaps to both neighbours, the end bins mirroring theirs), and np.round when
     # the stellar noise is off (:627).  k_prep's counts against that product evaluated HERE, in numpy, from the visit's
     # arrays -- no oracle (the audit's mutant with the 1e4 factor 1 % high passed every oracle-free test before this one)
-    from wayne_amd import tools
     v = helpers.make_visit(name)
     rec = {}
     kw = v.frame_kwargs(0, add_stellar_noise=False, cosmic_rate=None)
     helpers.product_generator(v, 0).scanning_frame(out_dtype=np.float32, record=rec, **kw)
-    lo, hi = v.grism.wl_limits
-    i0, i1 = tools.crop_spectrum_ind(lo, hi, v.wl.copy())
-    wl, flux = v.wl[i0:i1], kw["stellar_flux"][i0:i1]
-    # (the widths, spelled out from tools.py:106-128)
-    half = (wl - np.roll(wl, 1)) / 2.0
-    half[0] = half[1]
-    nxt = np.roll(half, -1)
-    nxt[-1] = half[-1]
-    dlam = half + nxt
-    swl, sval = v.calibration.sensitivity(v.grism.name)
-    sens = np.interp(wl, swl, sval)
-    depth = np.asarray(kw["planet_signal"])
-    depth = depth[:, i0:i1] if depth.ndim == 2 else depth[i0:i1][None, :]
-    dur = np.asarray(rec["dur"], dtype=np.float64)[:, None]
-    want = flux[None, :] * (1.0 - depth) * sens[None, :] * dlam[None, :] * 1e4 * dur * 1e-3 * kw["scale_factor"]
+    want, _ = helpers.reference_counts(v, kw, rec["dur"])          # (tests/helpers.py: the chain spelled out in numpy)
     got = np.asarray(rec["counts"], dtype=np.float64)
     assert got.shape == want.shape and want.max() > 100.0
     # np.round of a product evaluated in another order of operations: equal except where the product lies within an ulp

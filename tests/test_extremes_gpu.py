@@ -114,6 +114,9 @@ def sky_only_tails(v, n_exposures, rng, first=0, on_level=None):
             if on_level is not None:
                 on_level["dev"].append((k - lam[r - 1])[on_level["mask"]])
                 on_level["var"].append(lam[r - 1][on_level["mask"]])
+                if "bulk_k" in on_level and i == first:                   # (one exposure's 1.5e7 draws for the bulk test)
+                    on_level["bulk_k"].append(k[::2, ::2].ravel())
+                    on_level["bulk_lam"].append(lam[r - 1][::2, ::2].ravel())
             tr = xs.poisson_tails(k, lam[r - 1], rng)
             t = tr if t is None else t.merged(tr)
     return t, k_max
@@ -124,7 +127,7 @@ def test_sky_draws_largest_deviation_and_tail_frequencies():
     # every read interval of every pixel is an integer with a known Poisson law
     v = helpers.make_visit("cfg4", n_exposures=4)
     rng = np.random.default_rng(1)
-    lvl = {"mask": on_level_pixels(v), "dev": [], "var": []}
+    lvl = {"mask": on_level_pixels(v), "dev": [], "var": [], "bulk_k": [], "bulk_lam": []}
     t, k_max = sky_only_tails(v, 4, rng, on_level=lvl)
     s = xs.summary(t)
     # pixels that sit exactly ON their level: remainder mean 0, cdf = 1 from the first term -- all four integer
@@ -134,7 +137,10 @@ def test_sky_draws_largest_deviation_and_tail_frequencies():
     z_level = float(dev.sum() / np.sqrt(var.sum()))
     s["on_level_draws"], s["on_level_mean_z"] = int(dev.size), z_level
     assert dev.size >= 7 * 15 * 4 and abs(z_level) < 5.0, (dev.size, z_level, float(dev.mean()))
+    chi2, p_bulk, n_bulk = xs.poisson_pit_uniformity(np.concatenate(lvl["bulk_k"]), np.concatenate(lvl["bulk_lam"]), rng)
+    s["bulk_pit_chi2_49dof"], s["bulk_pit_p"], s["bulk_pit_draws"] = chi2, p_bulk, n_bulk
     report("sky/production_math", largest_excess_electrons=k_max, **s)
+    assert p_bulk > 1e-6, "the bulk of the sky draws is not Poisson: chi2 = %.1f on 49 degrees of freedom (%d draws)" % (chi2, n_bulk)
     assert t.n == 4 * 15 * 1014 * 1014
     bad = xs.check(t, "sky")
     assert not bad, "; ".join(bad) + "\n%r" % s
@@ -267,16 +273,12 @@ def test_background_reads_of_the_benchmarked_instantiation():
 
 def test_stellar_counts_largest_deviation_and_tail_frequencies():
     # k_prep_sub's Poisson draw per (bin, sub-sample) -- fp64 PTRS behind an fp32 squeeze from a mean of 10, inversion
-    # below -- at the benchmarked size (128 x 4494 bins per exposure), against the oracle's counts chain
-    # (exposure_generator.py:602-628)
+    # below -- at the benchmarked size (128 x 4494 bins per exposure), against the reference's counts chain
+    # (exposure_generator.py:600-628) evaluated in numpy from the visit's arrays (tests/helpers.py reference_counts: no oracle)
     v = helpers.make_visit("cfg4", n_exposures=6)
-    eo = helpers.oracle_generator(v)
-    gr = eo.grism
-    i0, i1 = wo.crop_spectrum_ind(gr.wl_limits[0], gr.wl_limits[1], v.wl.copy())
-    s_wl = v.wl[i0:i1]
-    gr.set_current_wavelength_only_dependent_array(s_wl)
     rng = np.random.default_rng(2)
     t = None
+    all_k, all_lam = [], []
     for i in range(6):
         # a dimmer star in every other exposure: the edges of the spectrum then fall below a mean of 10 (the inversion sampler)
         scale = v.scale_factor(i) * (1.0 if i % 2 == 0 else 3e-3)
@@ -284,16 +286,22 @@ def test_stellar_counts_largest_deviation_and_tail_frequencies():
         pg = helpers.product_generator(v, i)
         kw = v.frame_kwargs(i, scale_factor=scale, cosmic_rate=None)
         pg.scanning_frame(out_dtype=np.float32, record=rec, **kw)
-        lam = np.stack([eo.counts_before_noise(s_wl, kw["stellar_flux"][i0:i1] * (1.0 - kw["planet_signal"][k][i0:i1]),
-                                               rec["dur"][k], scale) for k in range(v.K)])
+        lam, _ = helpers.reference_counts(v, kw, rec["dur"])
         assert rec["counts"].shape == lam.shape == (128, 4494)
         tr = xs.poisson_tails(rec["counts"], lam, rng)
         t = tr if t is None else t.merged(tr)
+        all_k.append(rec["counts"].ravel())
+        all_lam.append(lam.ravel())
     s = xs.summary(t)
+    # the BULK of the law too (the audit's mutant: PTRS accepting without its density test in part of the proposal region
+    # left tails and extremes alone): the randomised PIT of every draw is uniform
+    chi2, p_bulk, n_bulk = xs.poisson_pit_uniformity(np.concatenate(all_k), np.concatenate(all_lam), rng)
+    s["bulk_pit_chi2_49dof"], s["bulk_pit_p"], s["bulk_pit_draws"] = chi2, p_bulk, n_bulk
     report("stellar/k_prep_sub", **s)
     assert t.n == 6 * 128 * 4494
     bad = xs.check(t, "stellar counts")
     assert not bad, "; ".join(bad) + "\n%r" % s
+    assert p_bulk > 1e-6, "the bulk of the stellar counts is not Poisson: chi2 = %.1f on 49 degrees of freedom (%d draws)" % (chi2, n_bulk)
 
 
 def test_thrower_largest_single_pixel_deviation_at_full_size():
@@ -401,6 +409,43 @@ def test_wide_electrons_populate_the_gaussian_tail_out_to_their_reach(gpu_ctx, m
     # and the core is where it belongs: the whole frame against the exact masses, pixel by pixel
     z = (f - mean) / np.sqrt(np.maximum(mean * (1.0 - mean / total), 1e-300))
     assert np.abs(z[mean > 50.0]).max() < 6.0
+
+
+@pytest.mark.parametrize("sigmas", [(0.7,), (0.7, 0.85)], ids=["pooled_rows", "own_chains"])
+def test_narrow_electrons_fill_their_window_with_the_gaussians_masses(gpu_ctx, sigmas):
+    # The narrow component as multinomials (k_narrow): cell masses from a fit of the gaussian tail, taken as 0 beyond
+    # 6.5 sigma_l, in a window of +-6 px.  The audit's mutant that cuts the tail at 4 sigma_l (6e-5 of the electrons per
+    # axis put somewhere else) passed every oracle-free test.  2 x 10^8 all-narrow electrons from one position: every
+    # column and every row of the frame against the gaussian's exact masses (pyparallel_menu.c:87-108), the few hundred
+    # electrons in the columns / rows wholly beyond 4 sigma_l in particular, and nothing beyond the window.  Bins that coincide pool their row chains
+    # (k_narrow.h "pooled rows"); bins whose sigma_l alternate by 20 % do not (each runs its own chains): both.
+    from scipy.stats import norm
+    B, n_each, cx, cy, N = 50000, 4000, 507.3, 507.6, 1014
+    counts = np.full(B, n_each, dtype=np.int32)
+    one = np.ones(B)
+    sl = np.resize(np.asarray(sigmas, dtype=float), B)
+    f = np.asarray(gpu_ctx.psf_apply(counts, cx * one, cy * one, 0.0 * one, sl, 5.5 * one, N, N, 271828, 1,
+                                     rng_mode=_lib.RNG_SPLIT), dtype=np.float64).reshape(N, N)
+    total = float(B) * n_each
+    assert f.sum() == total
+    edges = np.arange(N + 1, dtype=np.float64)
+    figures = {}
+    for axis, c in (("columns", cx), ("rows", cy)):
+        got = f.sum(axis=0 if axis == "columns" else 1)
+        p = np.mean([np.diff(norm.cdf((edges - c) / s_)) for s_ in sigmas], axis=0)     # equal numbers of bins per sigma
+        want = total * p
+        z = (got - want) / np.sqrt(np.maximum(want * (1.0 - p), 1e-300))
+        big = want > 25.0
+        assert big.sum() >= 7 and np.abs(z[big]).max() < 6.0, (axis, float(np.abs(z[big]).max()))
+        centre = np.arange(N) + 0.5 - c
+        far = np.abs(centre) > 4.0 * min(sigmas) + 0.5                       # wholly beyond 4 sigma of the narrower gaussian
+        out = np.abs(centre) > 6.0 + 1.0                                     # beyond the multinomial's window of +-6 px
+        figures[axis] = dict(beyond_4_sigma=float(got[far].sum()), expected=float(want[far].sum()), outside_window=float(got[out].sum()),
+                             largest_abs_z=float(np.abs(z[big]).max()))
+        assert want[far].sum() > 50.0
+        assert abs(got[far].sum() - want[far].sum()) < 5.0 * np.sqrt(want[far].sum()) + 3.0, (axis, figures[axis])
+        assert got[out].sum() == 0.0
+    report("thrower/narrow_window/" + ("pooled_rows" if len(sigmas) == 1 else "own_chains"), electrons=total, **figures)
 
 
 @pytest.mark.parametrize("path,name,N,n_exp", [("k_prep_sub", "cfg5", 1014, 8), ("k_lane_fused", "cfg5", 1014, 8),
