@@ -169,9 +169,12 @@ MUTANTS = [
     dict(name="sky_remainder_capped", stage="A13 sky Poisson: the remainder beyond three",
          what="the remainder's search stops at 3 (no fourth compare, no continuation)",
          edits=[("k_ramp.h", "  if (wr > sr.t3) {\n    k += 1;", "  if (false) {\n    k += 1;")]),
-    dict(name="ptrs_quick_accept", stage="A9 stellar Poisson noise (PTRS: Hoermann's transformed rejection)",
+    dict(name="ptrs_quick_accept", stage="A13 sky (direct sampler) and cosmic-ray counts: PTRS, Hoermann's transformed rejection (samplers.h)",
          what="the quick-acceptance region of a trial widened (us >= 0.03 instead of 0.07): no density test where one is due",
          edits=[("samplers.h", "    if (us >= (T)0.07 && V <= vr) return 1;", "    if (us >= (T)0.03 && V <= vr) return 1;")]),
+    dict(name="stellar_ptrs_quick_accept", stage="A9 stellar Poisson noise: k_prep_sub's own PTRS (fp64 behind an fp32 squeeze)",
+         what="the quick-acceptance region of a trial widened (us >= 0.03 instead of 0.07) in the stellar counts' sampler",
+         edits=[("k_prep.h", "    if (us >= 0.07 && V <= vr) return k;", "    if (us >= 0.03 && V <= vr) return k;")]),
 ]
 
 
