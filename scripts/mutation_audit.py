@@ -175,6 +175,9 @@ MUTANTS = [
     dict(name="stellar_ptrs_quick_accept", stage="A9 stellar Poisson noise: k_prep_sub's own PTRS (fp64 behind an fp32 squeeze)",
          what="the quick-acceptance region of a trial widened (us >= 0.03 instead of 0.07) in the stellar counts' sampler",
          edits=[("k_prep.h", "    if (us >= 0.07 && V <= vr) return k;", "    if (us >= 0.03 && V <= vr) return k;")]),
+    dict(name="btrs_quick_accept", stage="A4 narrow component: BTRS (Hoermann's binomial transformed rejection) in k_narrow's chains",
+         what="the quick-acceptance region of a BTRS trial widened (us >= 0.03 instead of 0.07)",
+         edits=[("samplers.h", "      if (us >= (T)0.07 && V <= vr) { x = k; break; }", "      if (us >= (T)0.03 && V <= vr) { x = k; break; }")]),
 ]
 
 

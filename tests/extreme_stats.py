@@ -83,6 +83,19 @@ def poisson_pit_uniformity(k, lam, rng, bins=50, max_draws=4000000):
     return chi2, float(stats.chi2.sf(chi2, bins - 1)), int(k.size)
 
 
+def normal_pit_uniformity(x, mean, sigma, rng, bins=50, max_draws=4000000):
+    """The bulk of a normal law: u = Phi((x - mean) / sigma) of (a random subset of) the draws is uniform on (0, 1); a
+    chi-square over `bins` equal bins.  Returns (chi2, p-value, n)."""
+    z = ((np.asarray(x, dtype=np.float64) - mean) / sigma).ravel()
+    if z.size > max_draws:
+        z = z[rng.choice(z.size, max_draws, replace=False)]
+    u = special.ndtr(z)
+    hist = np.histogram(np.clip(u, 0.0, np.nextafter(1.0, 0.0)), bins=bins, range=(0.0, 1.0))[0]
+    expect = z.size / float(bins)
+    chi2 = float(((hist - expect) ** 2 / expect).sum())
+    return chi2, float(stats.chi2.sf(chi2, bins - 1)), int(z.size)
+
+
 def normal_tails(x, mean, sigma, z_pre=3.0):
     x = np.asarray(x, dtype=np.float64)
     z = ((x - np.asarray(mean, dtype=np.float64)) / np.asarray(sigma, dtype=np.float64)).ravel()

@@ -251,7 +251,15 @@ def test_dark_and_read_noise_normals_in_the_benchmarked_instantiation():
             t = t.merged(tr)
             worst = max(worst, float((np.abs(reads[r + 1] - mean) / sig).max()))
     s = xs.summary(t)
+    # ... and the body of the law (hardware log2 / sqrt / sin / cos in Box-Muller): the last exposure's reads 3, 8 and 15
+    rng = np.random.default_rng(3)
+    pick = [3, 8, 15]
+    chi2, p_bulk, n_bulk = xs.normal_pit_uniformity(np.stack([reads[r] for r in pick]),
+                                                    np.stack([law[r - 1][1] for r in pick]),
+                                                    np.stack([law[r - 1][2] for r in pick]), rng)
+    s["bulk_pit_chi2_49dof"], s["bulk_pit_p"], s["bulk_pit_draws"] = chi2, p_bulk, n_bulk
     report("normals/allon", largest_abs_z=worst, **s)
+    assert p_bulk > 1e-6, "the bulk of the reads is not normal: chi2 = %.1f on 49 degrees of freedom (%d draws)" % (chi2, n_bulk)
     assert t.n == 3 * 16 * 1024 * 1024
     bad = xs.check(t, "dark + read noise")
     assert not bad, "; ".join(bad) + "\n%r" % s
