@@ -7,7 +7,7 @@ the checker, on the same data, to show the difference.
 """
 import numpy as np
 import pytest
-from scipy import stats
+from scipy import special, stats
 
 import extreme_stats as xs
 
@@ -163,3 +163,48 @@ def test_saddlepoint_tails_of_a_sum_of_binomials_against_the_exact_pmf():
     S2 = np.rint(mean + (S - mean) * 1.06)
     t2 = xs.poisson_binomial_tails(S2, (S2 - mean) / sd, lambda i: (n, p), rng)
     assert xs.check(t2, "6 % too wide")
+
+
+def _ptrs(lam, n, us_min, rng):
+    """Hoermann's PTRS in numpy (the algorithm of wayne_amd/csrc/samplers.h PtrsSetup), with the quick-acceptance region
+    us >= us_min (0.07 in the algorithm)."""
+    slam, loglam = np.sqrt(lam), np.log(lam)
+    b = 0.931 + 2.53 * slam
+    a = -0.059 + 0.02483 * b
+    invalpha = 1.1239 + 1.1328 / (b - 3.4)
+    vr = 0.9277 - 3.6224 / (b - 2)
+    out = np.empty(0)
+    while out.size < n:
+        m = int((n - out.size) * 1.3) + 1000
+        U, V = rng.random(m) - 0.5, rng.random(m)
+        us = 0.5 - np.abs(U)
+        k = np.floor((2 * a / us + b) * U + lam + 0.43)
+        quick = (us >= us_min) & (V <= vr)
+        undecided = ~quick & ~((k < 0) | ((us < 0.013) & (V > us)))
+        acc = quick.copy()
+        kk = k[undecided]
+        acc[undecided] = (np.log(V[undecided]) + np.log(invalpha) - np.log(a / us[undecided] ** 2 + b)
+                          <= -lam + kk * loglam - special.gammaln(kk + 1))
+        out = np.concatenate([out, k[acc]])
+    return out[:n]
+
+
+def test_the_body_of_a_law_is_out_of_the_tails_sight_and_in_the_pit_tests():
+    # The audit's mutant (scripts/mutation_audit.py ptrs_quick_accept): PTRS accepting without its density test for
+    # 0.03 <= us < 0.07 puts mass between 1.9 and 3.2 sigma -- + 8 % of variance at a rate of 60 -- and leaves the law from
+    # 3.7 sigma on alone.  The tail checks pass on it; the randomised-PIT chi-square does not.  And both pass on the algorithm
+    # as published, and on numpy's normals / fail on normals 1 % too wide.
+    rng = np.random.default_rng(17)
+    lam = np.full(2000000, 60.0)
+    good, bad = _ptrs(60.0, lam.size, 0.07, rng), _ptrs(60.0, lam.size, 0.03, rng)
+    assert abs(bad.var() / 60.0 - 1.08) < 0.02 and abs(good.var() / 60.0 - 1.0) < 0.005
+    for k in (good, bad):
+        assert not xs.check(xs.poisson_tails(k, lam, rng), "PTRS", qs=(1e-4, 1e-5))      # tails: blind to it
+    chi2_good, p_good, n = xs.poisson_pit_uniformity(good, lam, rng)
+    chi2_bad, p_bad, _ = xs.poisson_pit_uniformity(bad, lam, rng)
+    assert n == lam.size and p_good > 1e-3 and p_bad < 1e-12 and chi2_bad > 100 * chi2_good
+    x = rng.normal(3.0, 2.0, 3000000)
+    assert xs.normal_pit_uniformity(x, 3.0, 2.0, rng)[1] > 1e-3
+    assert xs.normal_pit_uniformity(x, 3.0, 2.02, rng)[1] < 1e-9
+    # a subset is drawn when there are more draws than max_draws
+    assert xs.normal_pit_uniformity(x, 3.0, 2.0, rng, max_draws=100000)[2] == 100000
