@@ -178,6 +178,20 @@ MUTANTS = [
     dict(name="btrs_quick_accept", stage="A4 narrow component: BTRS (Hoermann's binomial transformed rejection) in k_narrow's chains",
          what="the quick-acceptance region of a BTRS trial widened (us >= 0.03 instead of 0.07)",
          edits=[("samplers.h", "      if (us >= (T)0.07 && V <= vr) { x = k; break; }", "      if (us >= (T)0.03 && V <= vr) { x = k; break; }")]),
+    # --- third wave
+    dict(name="throw_sigma_swapped", stage="A4 per-electron thrower: which electrons take the wide gaussian (pyparallel_menu.c:89-98)",
+         what="k_throw gives the first n_wide electrons of a bin the NARROW sigma and the rest the wide one",
+         edits=[("k_throw.h", "              c = wide ? cur.ch : cur.cl;", "              c = wide ? cur.cl : cur.ch;")]),
+    dict(name="replay_lcg_increment", stage="A2 rand_r replay (glibc: next = next * 1103515245 + 12345)",
+         what="the LCG's increment 12346 in the replay thrower's sequential step",
+         edits=[("k_throw.h", "  s = s * 1103515245u + 12345u; r = (s >> 16) & 2047u;", "  s = s * 1103515245u + 12346u; r = (s >> 16) & 2047u;")]),
+    dict(name="pooled_common_mass", stage="A4 narrow component: pooled rows, the mass Z the group shares",
+         what="the common mass Z of a pooling group 2 % low (more electrons go the residual way, with the residual law of the true Z)",
+         edits=[("k_narrow.h", "      Z = fminf(PL[kNarrowR] + SU[kNarrowR + 1], 1.f);", "      Z = 0.98f * fminf(PL[kNarrowR] + SU[kNarrowR + 1], 1.f);")]),
+    dict(name="binv_cap_8", stage="A4 narrow component: BINV (inversion for n p < 10)",
+         what="the inversion search gives up after 8 steps and returns the mean",
+         edits=[("samplers.h", "    for (int it = 0; it < 64; ++it) {\n      if (u <= r) break;", "    for (int it = 0; it < 8; ++it) {\n      if (u <= r) break;"),
+                ("samplers.h", "    if (x >= (T)64 && x < n) x = M::floor_(n * p + (T)0.5);", "    if (x >= (T)8 && x < n) x = M::floor_(n * p + (T)0.5);")]),
 ]
 
 
@@ -207,6 +221,10 @@ PY_MUTANTS = [
          what="sub-sample mid-points a third into the sub-sample instead of half",
          edits=[("wayne_amd/exposure_generator.py", "sample_mid_points = sample_starts + (sample_durations / 2)",
                  "sample_mid_points = sample_starts + (sample_durations / 3)")]),
+    dict(name="py_orbit_inclination", stage="f3 light curves: the planet's sky position (observation.py:293-357 via pylightcurve's orbit)",
+         what="the projected y of the planet with sin(i) instead of cos(i)",
+         tests=["tests/test_lightcurve.py"],
+         edits=[("wayne_amd/lightcurve.py", "    Y = -r * np.sin(w + f) * np.cos(inc)", "    Y = -r * np.sin(w + f) * np.sin(inc)")]),
 ]
 
 
@@ -287,7 +305,7 @@ def run_py_mutant(m, say):
             r = subprocess.run(cmd, cwd=dst, env=env, capture_output=True, text=True, timeout=1500)
             return verdict(r.stdout) + (time.time() - t0,)
 
-        k, tail, dt = run(INDEPENDENT + ["tests/test_reference_goldens.py"], "gpu or not gpu")
+        k, tail, dt = run(INDEPENDENT + ["tests/test_reference_goldens.py"] + m.get("tests", []), "gpu or not gpu")
         if k is not None:
             say("%-22s | %s | KILLED by the independent set: %s (%.0f s)" % (m["name"], m["what"], k, dt))
             return
