@@ -240,6 +240,15 @@ CPU_MUTANTS = [
     dict(name="fits_byte_order", stage="f1 FITS data (big-endian float64)",
          what="the image cube left in the host's byte order",
          edits=[("wayne_amd/exposure.py", 'cube = np.empty((n,) + arrs[0].shape, dtype=">f8")', 'cube = np.empty((n,) + arrs[0].shape, dtype="<f8")')]),
+    dict(name="planner_buffer_dump", stage="f2 visit planner (visit_planner.py:76: 5.8 min per buffer dump)",
+         what="a buffer dump takes 8.5 minutes",
+         edits=[("wayne_amd/visit_planner.py", "time_buffer_dump = 5.8 ", "time_buffer_dump = 8.5 ")]),
+    dict(name="planner_guide_star", stage="f2 visit planner (guide-star acquisition: 6 min in the first orbit, 5 after)",
+         what="guide-star acquisition 5 minutes in every orbit",
+         edits=[("wayne_amd/visit_planner.py", "guide_star_aq = 6.0 if orbit_n == 0 else 5.0", "guide_star_aq = 5.0")]),
+    dict(name="hook_uses_visit_start", stage="f2 visit trends (visit_trends.py:44-73: the hook restarts every orbit)",
+         what="the exponential hook measured from the visit's start instead of each orbit's",
+         edits=[("wayne_amd/trend_generators/visit_trends.py", "        t_0[lo:hi] = time_array[lo]", "        t_0[lo:hi] = time_array[0]")]),
 ]
 
 

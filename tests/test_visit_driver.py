@@ -207,6 +207,18 @@ def test_visit_planner():
     assert abs(t[1] - t[0] - step) < 1e-12
     assert np.all(t[:vp["orbit_start_index"][1]] < 54.0)                    # visibility window
     assert det.num_exp_per_buffer(5, 256) == 21                              # floor(2*16*4 / 6)
+    # buffer dumps (visit_planner.py:74-76, 106-111): `exp_n > exp_per_dump` -- after exp_per_dump + 1 exposures -- the visit
+    # waits 5.8 minutes and the count starts again.  A full-array NSAMP 16 exposure fills the buffer by itself: every second
+    # step is a step + 5.8 min (the mutation audit's 8.5-minute dump was stopped only by the oracle's planner)
+    assert det.num_exp_per_buffer(16, 1024) == 1
+    vp = visit_planner.VisitPlanner(det, 16, "SPARS10", 1024, num_orbits=2)
+    t, first = vp["exp_times"], vp["orbit_start_index"][1]
+    step = det.exptime(16, 1024, "SPARS10") / 60.0 + 1.0
+    gaps = np.diff(t[:first])
+    np.testing.assert_allclose(gaps[0::2], step, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(gaps[1::2], step + 5.8, rtol=0, atol=1e-12)
+    assert vp["buffer_dump_index"][:3] == [2, 4, 6]
+    assert t[first] == 95.0 + 5.0 and abs(t[first + 1] - t[first] - step) < 1e-12            # the count restarts with every orbit (:97)
 
 
 def test_build_observation_from_yaml():
