@@ -249,6 +249,20 @@ CPU_MUTANTS = [
     dict(name="hook_uses_visit_start", stage="f2 visit trends (visit_trends.py:44-73: the hook restarts every orbit)",
          what="the exponential hook measured from the visit's start instead of each orbit's",
          edits=[("wayne_amd/trend_generators/visit_trends.py", "        t_0[lo:hi] = time_array[lo]", "        t_0[lo:hi] = time_array[0]")]),
+    # --- the ORACLE by itself (which of its statements do the CPU tests pin, with no device in sight?)
+    dict(name="oracle_rand_r", stage="oracle A2: glibc rand_r restated (psf_oracle.c)",
+         what="the second LCG step of rand_r with increment 12346",
+         edits=[("oracle/psf_oracle.c", "  s = s * 1103515245u + 12345u;\n  r = (s >> 16) & 2047u;", "  s = s * 1103515245u + 12346u;\n  r = (s >> 16) & 2047u;")]),
+    dict(name="oracle_counts_chain", stage="oracle A9: the counts chain (wayne_oracle.py)",
+         what="the 1e4 A / um factor 1 % high",
+         edits=[("oracle/wayne_oracle.py", "        count_rate = count_rate * 1e4\n", "        count_rate = count_rate * 1.01e4\n")]),
+    dict(name="oracle_flat_norm", stage="oracle A11: the flat's wavelength normalisation (wayne_oracle.py)",
+         what="(wl - wmin) / wmax instead of / (wmax - wmin)",
+         edits=[("oracle/wayne_oracle.py", "wl_array_norm = (wl_array - self.flat_wmin) / (self.flat_wmax - self.flat_wmin)",
+                 "wl_array_norm = (wl_array - self.flat_wmin) / (self.flat_wmax)")]),
+    dict(name="oracle_read_noise", stage="oracle A15: read noise (wayne_oracle.py)",
+         what="read noise 14.8 / gain",
+         edits=[("oracle/wayne_oracle.py", "self.read_noise = 14.1 / self.constant_gain", "self.read_noise = 14.8 / self.constant_gain")]),
 ]
 
 
