@@ -341,7 +341,7 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else ""
     names = sys.argv[2:]
     todo = [m for m in MUTANTS if not names or m["name"] in names]
-    todo_py = [m for m in PY_MUTANTS if m["name"] in names]
+    todo_py = [m for m in PY_MUTANTS if not names or m["name"] in names]
     if what == "build":
         os.makedirs(OUT_DIR, exist_ok=True)
         with ThreadPoolExecutor(4) as ex:
