@@ -225,6 +225,23 @@ PY_MUTANTS = [
          what="the projected y of the planet with sin(i) instead of cos(i)",
          tests=["tests/test_lightcurve.py"],
          edits=[("wayne_amd/lightcurve.py", "    Y = -r * np.sin(w + f) * np.cos(inc)", "    Y = -r * np.sin(w + f) * np.sin(inc)")]),
+    # --- the visit level (observation.py:415-504)
+    dict(name="obs_time_array", stage="f2 Observation: the sub-samples' times handed to the light curves (observation.py:440-445)",
+         what="sample mid-points taken as seconds instead of milliseconds when turned into days",
+         tests=["tests/test_visit_driver.py"],
+         edits=[("wayne_amd/observation.py", "time_array = expstart + sample_mid_points / (86400. * 1000.)", "time_array = expstart + sample_mid_points / 86400.")]),
+    dict(name="obs_shift_index", stage="f2 Observation: x / y shifts per exposure (observation.py:447-452)",
+         what="the drift x_shifts * exposure NUMBER instead of * its index (one exposure's shift too many)",
+         tests=["tests/test_visit_driver.py"],
+         edits=[("wayne_amd/observation.py", "x_ref = self._try_index(self.x_ref, index_number) + self.x_shifts * index_number", "x_ref = self._try_index(self.x_ref, index_number) + self.x_shifts * number")]),
+    dict(name="obs_trend_ignored", stage="f2 Observation: the visit trend's scale factor per exposure (observation.py:455-458)",
+         what="the visit trend never applied",
+         tests=["tests/test_visit_driver.py"],
+         edits=[("wayne_amd/observation.py", "scale_factor = self._visit_trend.get_scale_factor(index_number) if self._visit_trend else None", "scale_factor = None")]),
+    dict(name="obs_exp_start_units", stage="f2 Observation: exposure start times from the planner's minutes (observation.py:268-272)",
+         what="the planner's minutes divided by 24 x 3600 instead of 24 x 60",
+         tests=["tests/test_visit_driver.py"],
+         edits=[("wayne_amd/observation.py", 'self.exp_start_times = self.visit_plan["exp_times"] / (24. * 60.) + self.start_JD', 'self.exp_start_times = self.visit_plan["exp_times"] / (24. * 3600.) + self.start_JD')]),
 ]
 
 

@@ -236,6 +236,56 @@ def test_build_observation_from_yaml():
     assert m.shape == (2, obs.wl.size) and 0.015 < m.mean() < 0.0175
 
 
+@pytest.mark.gpu
+def test_generate_exposure_follows_the_references_bookkeeping():
+    # Observation._generate_exposure and setup_visit as the reference writes them (observation.py:189-226, 415-462), host half
+    # only (ExposureGenerator.prepare: nothing is launched; the context exists for the calibration it holds) -- the mutation audit's four visit-level mutants (sample times as seconds,
+    # one shift too many, the visit trend ignored, planner minutes / 86400) passed everything but the visit ORACLE:
+    #   exp_start_times = planner minutes -> days + start_JD;   file number n -> index n - 1;
+    #   x_ref / y_ref = their per-exposure value + shift x index;   sky and visit-trend factor of that index;
+    #   the light curves asked for at expstart + sub-sample mid-points (ms -> days)
+    from wayne_amd import observation, visit_planner
+    cfg = yaml.safe_load(open(os.path.join(MINI, "params.yml")))
+    obs = run_visit.build_observation(cfg, MINI)
+    obs.x_shifts, obs.y_shifts = 0.37, -0.11
+    asked = []
+    inner = obs.device_depths
+
+    def recording(time_array):
+        asked.append(np.array(time_array, dtype=float))
+        return inner(time_array)
+
+    obs.device_depths = recording
+    xs_, ys_, sky = (np.loadtxt(os.path.join(MINI, f)) for f in ("xref.txt", "yref.txt", "sky.txt"))
+    jd = np.loadtxt(os.path.join(MINI, "jd.txt"))
+    np.testing.assert_array_equal(obs.exp_start_times, jd)                       # (times given: taken as they are, :202-204)
+    t = np.asarray(obs.visit_plan["exp_start_times"], dtype=float)
+    t0 = np.concatenate([np.full(hi - lo, t[lo]) for lo, hi in zip(obs.visit_plan["orbit_start_index"],
+                                                                   obs.visit_plan["orbit_start_index"][1:] + [len(t)])])
+    a1, b1, b2, to = cfg["trends"]["visit_trend_coeffs"]
+    trend = (1 - a1 * (t - to)) * (1 - b1 * np.exp(-b2 * (t - t0)))             # visit_trends.py:44-57
+    for n in (1, 2, 4, 6):
+        asked.clear()
+        g = obs._generate_exposure(obs.exp_start_times[n - 1], n, prepare_only=True)
+        i = n - 1
+        assert g.exp_info["filename"] == "%04d_raw.fits" % n
+        assert g.exp_info["x_ref"] == pytest.approx(np.atleast_1d(xs_)[i] + 0.37 * i, abs=1e-12)
+        assert g.exp_info["y_ref"] == pytest.approx(np.atleast_1d(ys_)[i] - 0.11 * i, abs=1e-12)
+        assert g.exp_info["sky_background"] == pytest.approx(np.atleast_1d(sky)[i])
+        assert g.exp_info["scale_factor"] == pytest.approx(trend[i], rel=1e-12) and abs(trend[i] - 1.0) > 1e-5
+        _, mid, _, _ = g._gen_scanning_sample_times(obs.sample_rate)
+        assert len(asked) == 1
+        np.testing.assert_allclose(asked[0], jd[i] + np.asarray(mid) / 86400e3, rtol=0, atol=1e-12)
+        assert 1e-7 < asked[0][-1] - asked[0][0] < 1e-3                          # (a fraction of a second to a minute, in days)
+    # a generated plan: the planner's minutes (exposure overhead 3 min, :215-219) over 1440, plus start_JD
+    o2 = observation.Observation()
+    o2.setup_detector(obs.detector, 4, "RAPID", 128)
+    o2.setup_visit(2456196.25, 2)
+    vp = visit_planner.VisitPlanner(obs.detector, 4, "RAPID", 128, 2, exp_overhead=3.0)
+    np.testing.assert_allclose(o2.exp_start_times, 2456196.25 + vp["exp_times"] / 1440.0, rtol=0, atol=1e-12)
+    assert o2.exp_start_times[1] - o2.exp_start_times[0] == pytest.approx((obs.detector.exptime(4, 128, "RAPID") / 60.0 + 3.0) / 1440.0)
+
+
 def test_example_yaml_of_the_reference_parses():
     ex = "/root/reference/examples"
     if not os.path.exists(ex):
