@@ -266,6 +266,13 @@ CPU_MUTANTS = [
     dict(name="hook_uses_visit_start", stage="f2 visit trends (visit_trends.py:44-73: the hook restarts every orbit)",
          what="the exponential hook measured from the visit's start instead of each orbit's",
          edits=[("wayne_amd/trend_generators/visit_trends.py", "        t_0[lo:hi] = time_array[lo]", "        t_0[lo:hi] = time_array[0]")]),
+    # --- the CLI's YAML handling (run_visit.py:100-260)
+    dict(name="cli_pre_crop", stage="f2 CLI: the planet spectrum's pre-crop (run_visit.py:152-153: 0.9 - 1.8 um)",
+         what="the planet spectrum cropped to 1.0 - 1.7 um",
+         edits=[("wayne_amd/run_visit.py", "tools.crop_spectrum(0.9, 1.8, wl_planet, depth_planet)", "tools.crop_spectrum(1.0, 1.7, wl_planet, depth_planet)")]),
+    dict(name="cli_flux_scale", stage="f2 CLI: the stellar flux scale (run_visit.py:205)",
+         what="flux_scale applied twice",
+         edits=[("wayne_amd/run_visit.py", 'stellar_flux_scaled = flux_star * target["flux_scale"]', 'stellar_flux_scaled = flux_star * target["flux_scale"] * target["flux_scale"]')]),
     # --- the ORACLE by itself (which of its statements do the CPU tests pin, with no device in sight?)
     dict(name="oracle_rand_r", stage="oracle A2: glibc rand_r restated (psf_oracle.c)",
          what="the second LCG step of rand_r with increment 12346",
@@ -349,7 +356,7 @@ def run_py_mutant(m, say):
         if k is not None:
             say("%-22s | %s | KILLED by the independent set: %s (%.0f s)" % (m["name"], m["what"], k, dt))
             return
-        k2, tail2, dt2 = run(["tests"] + ["--deselect=" + p_ for p_ in INDEPENDENT], "gpu")
+        k2, tail2, dt2 = run(["tests", "--deselect=tests/test_mutation_sites.py"] + ["--deselect=" + p_ for p_ in INDEPENDENT], "gpu")
         say("%-22s | %s | SURVIVED the independent set (%s, %.0f s); rest of the GPU suite: %s (%.0f s)" % (
             m["name"], m["what"], tail, dt, "killed by " + k2 if k2 else "SURVIVED: " + tail2, dt2))
 
@@ -401,7 +408,8 @@ def main():
                         raise SystemExit("mutant %s: %r occurs %d times in %s" % (m["name"], old, s.count(old), rel))
                     open(p, "w").write(s.replace(old, new))
                 t0 = time.time()
-                r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider", "tests"],
+                r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider", "tests",
+                                    "--deselect=tests/test_mutation_sites.py"],      # (it reads the sources the mutant edits)
                                    cwd=dst, capture_output=True, text=True, timeout=1500,
                                    env={k: v for k, v in os.environ.items() if k != "WAYNE_HIP_LIB"})
                 k, tail = verdict(r.stdout)

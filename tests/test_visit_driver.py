@@ -228,6 +228,12 @@ def test_build_observation_from_yaml():
     assert obs.NSAMP == 4 and obs.SUBARRAY == 128 and obs.grism.name == "G141"
     assert obs.transmission_spectroscopy and obs.ssv_gen.stddev == 1.5
     assert obs.wl.min() >= 0.9 and obs.wl.max() <= 1.8                       # run_visit.py:152-153 pre-crop
+    raw_wl = np.sort(np.loadtxt(os.path.join(MINI, "planet_spectrum.dat"))[:, 0])
+    assert obs.wl.min() == raw_wl[raw_wl >= 0.9].min() and obs.wl.max() == raw_wl[raw_wl <= 1.8].max()    # ... and nothing narrower
+    # no stellar file: a black body of the star's temperature on the planet's grid, times flux_scale ONCE (run_visit.py:201-205)
+    from wayne_amd import tools
+    np.testing.assert_allclose(obs.stellar_flux, tools.blackbody_lambda(obs.wl, 6100.0) * 1.8e-20, rtol=1e-12)
+    assert obs.sample_rate == 25 and obs.scan_speed == 30.0                  # ms, px/s, as the YAML gives them
     assert obs._visit_trend.scale_factors.shape == (6,)
     t, model = obs.show_lightcurve()
     assert model[0] > 0.995 and model[3] < 0.986 and model[5] > 0.99         # ingress, mid-transit, out
