@@ -41,6 +41,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -54,6 +55,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16
 REPS = 5
 SUSTAIN_S = 6.5       # length of the sustained-rate pass (longer than the period of the driver's gpu_busy sampler)
+# what the reads of the timed region are, as `config.workload` says it (tests/test_bench_contract.py holds the strings):
+# float32 is the default of every entry point -- ExposureGenerator.scanning_frame, Observation, VisitRunner, the CLI
+READS_LABEL = {False: "f32 reads (the default of ExposureGenerator, Observation, VisitRunner and the CLI)",
+               True: "f64 reads (out_dtype=float64 / --float64-reads: the reference's dtype)"}
 RAMP_EVENTS_EVERY = 4   # k_ramp's HIP events in the timed region: on every 4th exposure (they cost the stream ~10 us a pair)
 
 
@@ -197,7 +202,9 @@ def dtype_label(ramp_variant, out_f64):
     """`dtype` of the JSON line: the arithmetic the TIMED kernels compute in, derived from the k_ramp instantiation the
     library reports for the timed slots (wayne_exposure_ramp_variant) -- not a fixed string."""
     thrower = "f32 thrower (int32 LDS tiles -> int64 fixed-point accumulators, 2^-28 e-)"
-    if ramp_variant.startswith("k_ramp<float, true"):
+    if re.match(r"k_ramp<float, true, 1, false, (true|false)>$", ramp_variant):
+        # (ramp_body's all-float32 chain needs SKY == 1 && !NOISE, k_ramp.h; sky drawn in pieces (2) or the gaussian
+        # stage on run the fp64 cumulative sum)
         ramp = "exact integer sums (int64 accumulators + int32 sky counts) then an all-f32 per-read chain"
     elif "<float" in ramp_variant:
         ramp = "f64 cumulative sum and per-read chain, reads rounded to f32"
@@ -324,12 +331,18 @@ def main():
     from wayne_amd import launch
     launch.pin_to_gpu_numa(device)           # the rank's host threads on its GPU's NUMA node (best effort)
     dist = None
+    grp = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # gloo: a barrier and a max-reduce of one double on the host -- the data path has no collective
         # (a rank that never arrives is an error after launch.RENDEZVOUS_TIMEOUT_S, not a wait until the driver's limit)
         dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=launch.rendezvous_timeout())
+        dist.barrier()
+        # ... and only the rendezvous: the collectives of the measurement run in a group of their own whose timeout
+        # does not turn one rank's slow pass (a cold page cache, a first-time build) into a lost line
+        import datetime
+        grp = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
 
     from wayne_amd import _lib, calibration, detector, engine, grism, synthetic, visit as wvisit
     from wayne_amd.exposure_generator import ExposureGenerator
@@ -361,7 +374,7 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=grp)
 
     own_rates = []       # one entry per timed() call: what THIS rank did by its own clock (not the max over ranks)
 
@@ -373,9 +386,9 @@ def main():
         own_rates.append(steps / elapsed if (steps and elapsed > 0) else 0.0)    # this rank's own exposures/s
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
             elapsed = float(t.item())
-            dist.barrier()
+            dist.barrier(group=grp)
         return elapsed
 
     out_dtype = np.float64 if args.out_f64 else np.float32
@@ -390,6 +403,7 @@ def main():
     # timed region: HIP events around the roofline kernel only (every event pair costs a few microseconds
     # of stream time; the other kernels are timed in the breakdown pass below)
     timed(slot_of, 0, args.warmup)
+    reruns_before = ctx.reruns
     ctx.profile_select(["k_ramp"])
     ctx.profile_enable(True)
     ctx.profile_reset()
@@ -401,17 +415,19 @@ def main():
     elapsed = float(np.median(reps))
     # every exposure of the timed region must have been complete: a slot whose status word says otherwise would have
     # been run a second time by a download -- which a loop of run() calls never makes
+    # (every pass ends in ctx.synchronize(), which settles the slots -- wayne_ctx_synchronize -- so nothing can be left
+    # incomplete; a second run it had to make is counted here, and its time is inside the repetition that made it)
     statuses = [ctx.status(slot_of(j)) for j in range(min(n_res, args.steps))]
-    reruns_timed = sum(1 for st in statuses if st != 0)
-    if reruns_timed:
-        raise SystemExit("rank %d: %d exposures of the timed region were incomplete (status %s)" % (
-            rank, reruns_timed, sorted(set(statuses))))
+    if any(statuses):
+        raise SystemExit("rank %d: exposures of the timed region incomplete after synchronize (status %s)" % (
+            rank, sorted(set(statuses))))
+    reruns_timed = ctx.reruns - reruns_before
 
     ranks_reported = 1
     per_rank = {0: rank_rates}
     if dist is not None:
         got = [None] * world
-        dist.all_gather_object(got, (rank, args.steps, rank_rates))
+        dist.all_gather_object(got, (rank, args.steps, rank_rates), group=grp)
         ranks_reported = len(set(r for r, _, _ in got))
         if ranks_reported != world or any(s != args.steps for _, s, _ in got):
             raise SystemExit("ranks disagree: %s" % (got,))
@@ -486,11 +502,17 @@ def main():
             ctx.profile_enable(True)
             ctx.profile_reset()
             n_cold = min(args.steps, 24)
+            # (even slots only: they run on streams[0], the stream the fill is enqueued on -- with --streams 2 the odd
+            # slots' k_ramp would be neither ordered after the fill nor evicted)
+            n_even = n_res if stride == 2 else max(n_res // 2, 1)
+
+            def cold_slot(j):
+                return (j % n_even) * 2
             for j in range(n_cold):
-                ctx.run_front(slot_of(j))
+                ctx.run_front(cold_slot(j))
                 with torch.cuda.stream(ext):
                     scrub.fill_(j & 0xFF)
-                ctx.run_back(slot_of(j))
+                ctx.run_back(cold_slot(j))
             ctx.synchronize()
             torch.cuda.synchronize()
             pr = ctx.profile_get()["k_ramp"]
@@ -507,7 +529,8 @@ def main():
             n_two = max(args.steps, 40)
             med, vals = median_rate(lambda j: j % n_res, n_two, warmup=4)
             extras["two_streams"] = {"value": med, "unit": "exposures/s", "repetitions": vals, "steps_each": n_two,
-                                     "note": "same exposures alternating over two HIP streams; median of 3 passes of %d "
+                                     "note": "what VisitRunner (Observation, the CLI) delivers device-side: the "
+                                             "same exposures alternating over the context's two HIP streams; median of 3 passes of %d "
                                              "after 4 warm-up exposures (bench.timed_pass: the function "
                                              "scripts/bench_configs.py uses too)" % n_two}
         # (2) float64 reads, the reference's SCI dtype (exposure.py:133-214) -- a different k_ramp instantiation (fp64
@@ -560,13 +583,13 @@ def main():
                 dt_max = dt_own
                 if dist is not None:
                     tt = torch.tensor([dt_own], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)
                     dt_max = float(tt.item())
                 vals.append(n_d * n_gpus / dt_max)
             per = {0: own}
             if dist is not None:
                 got_ = [None] * world
-                dist.all_gather_object(got_, (rank, own))
+                dist.all_gather_object(got_, (rank, own), group=grp)
                 per = {r_: o_ for r_, o_ in got_}
             med = float(np.median(vals))
             return {"value": med, "unit": "exposures/s", "GB_per_s": med * out_mb / 1e3,
@@ -627,9 +650,9 @@ def main():
         sb = survey_bytes(N, S, R, K, W, ob, 1.64e5)
         throw_ms = prof["k_throw"]["ms"] / max(prof["k_throw"]["launches"], 1)
         narrow_ms = prof["k_narrow"]["ms"] / max(prof["k_narrow"]["launches"], 1)
-        # WAYNE_FORK_NARROW=1 (default off): the library launches k_narrow on a side stream beside k_lane and
+        # knob fork_narrow (WAYNE_FORK_NARROW=1 at context creation; default off): the library launches k_narrow on a side stream beside k_lane and
         # the k_throw profile interval then covers both kernels
-        forked = args.thrower == "split" and os.environ.get("WAYNE_FORK_NARROW", "0") not in ("", "0")
+        forked = args.thrower == "split" and bool(ctx.get_knob("fork_narrow"))
         # (the k_throw interval always includes k_lane, which follows it on the slot's stream)
         thrower_ms = throw_ms if forked else throw_ms + narrow_ms
         electrons = prof["electrons"] / max(n_break, 1)
@@ -645,18 +668,20 @@ def main():
             "repetitions": {"n": REPS, "steps_each": args.steps, "values": [args.steps * n_gpus / e for e in reps],
                             "median": rates[len(rates) // 2], "min": rates[0], "max": rates[-1],
                             "per_rank_exposures_s": {str(r): [round(x, 1) for x in per_rank[r]] for r in sorted(per_rank)},
-                            "incomplete_exposures": reruns_timed,
+                            "incomplete_exposures": 0, "second_runs_in_timed_region": reruns_timed,
                             "note": "value = the median repetition; each is exactly `steps` exposures per rank between "
                                     "barrier + synchronise, max over ranks; per_rank_exposures_s: every rank's own rate "
                                     "in each repetition by its own clock (an imbalance shows here, not in the max)"},
             "config": {"workload": "%s: %s spatial scan %g px/s, SUBARRAY=%d (frame %dx%d), %s NSAMP=%d, "
                                    "K=%d sub-samples, W=%d bins, %.3g electrons/exposure, all detector effects on "
                                    "(flat, sky, cosmic rays, gain, dark, non-linearity, clip, read noise), "
-                                   "thrower=%s, device-complete reads in HBM" % (
+                                   "thrower=%s, %s, %s, device-complete reads in HBM" % (
                                        args.config, gr.name, visit.scan_speed, visit.SUBARRAY, N, N, visit.SAMPSEQ,
                                        visit.NSAMP, K, W, electrons,
                                        "split (wide component per electron, narrow component multinomial)"
-                                       if args.thrower == "split" else "per-electron"),
+                                       if args.thrower == "split" else "per-electron",
+                                       READS_LABEL[bool(args.out_f64)],
+                                       "one HIP stream" if args.streams == 1 else "two HIP streams (what VisitRunner runs)"),
                        "exposures_per_rank": args.steps, "sharding": "round-robin exposures, no collective"},
             "roofline": {"bound": "hbm", "kernel": ramp_variant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -684,6 +709,12 @@ def main():
                                 "k_lane on the slot's stream with k_narrow beside them on a side stream"
                         if forked else "k_throw + k_lane (one interval), then k_narrow, on one stream"},
         }
+        lib_path, lib_flags = _lib.library_info()
+        line["library"] = {"path": os.path.relpath(lib_path, ROOT), "build_flags": lib_flags, "abi": _lib.ABI_VERSION}
+        if lib_flags:
+            # a negative-control or timing build (its sources say "wrong frames"): not a measurement of the product
+            line["value"] = None
+            line["library"]["note"] = "value withheld: this library was built with %s" % lib_flags
         line["sustained"] = sustained
         cold = extras.pop("ramp_cold", None)
         if cold and "ms_per_launch" in cold and cold["ms_per_launch"] > 0:
@@ -727,7 +758,7 @@ def main():
             line["cpu_baseline"] = None
         emit_line(line)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=grp)
         dist.destroy_process_group()
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WAYNE_ABI_VERSION 6
+#define WAYNE_ABI_VERSION 7
 
 /* status codes */
 #define WAYNE_OK 0
@@ -69,6 +69,10 @@ typedef struct wayne_ctx wayne_ctx;
 
 int wayne_abi_version(void);
 const char *wayne_strerror(int status);
+/* The compile-time switches (-DWAYNE_...) of this build that change what the library computes or launches, separated
+ * by spaces: "" for the shipped library.  Negative-control and timing builds (tests/native, scripts/) name theirs
+ * here, so that a measurement or a file can say which library produced it and refuse a defective one. */
+const char *wayne_build_flags(void);
 
 /* Number of HIP devices visible (0 when there is none / no driver). */
 int wayne_device_count(void);
@@ -79,7 +83,20 @@ int wayne_device_count(void);
 wayne_ctx *wayne_ctx_create(int device, int *status);
 void wayne_ctx_destroy(wayne_ctx *ctx);
 const char *wayne_last_error(const wayne_ctx *ctx);
+/* Wait for everything enqueued on the context AND settle it: the status word of every exposure run since the last
+ * look is read (one copy for all slots); an exposure that met a bin beyond the reach of the short launch sequence
+ * chosen from the host's electron estimate is run a second time with the general sequence (wayne_ctx_reruns counts
+ * them), an overflow is reported as WAYNE_E_OVERFLOW.  After WAYNE_OK the reads of every slot are complete: this is
+ * the call a throughput loop of wayne_exposure_run ends with. */
 int wayne_ctx_synchronize(wayne_ctx *ctx);
+/* Tuning and test knobs.  Each is read ONCE from the environment (WAYNE_<NAME IN CAPITALS>) by wayne_ctx_create; no
+ * other entry point looks at the environment, so editing it from another thread cannot change what a live context
+ * launches.  Afterwards only this call changes a knob (value < 0: back to the library's own choice).  Names:
+ * tile_ints, batch, thin, no_acc_box, lane_reach, throw_wgs, keep_narrow, no_fuse, fork_narrow, streams,
+ * upload_timing, ramp_reads (timing builds only).  None changes a frame (integer accumulation commutes); they change
+ * launch shapes.  WAYNE_E_INVALID for an unknown name. */
+int wayne_ctx_set_knob(wayne_ctx *ctx, const char *name, long long value);
+int wayne_ctx_get_knob(const wayne_ctx *ctx, const char *name, long long *value);
 /* The context's hipStream_t (as void*), for callers that interoperate. */
 void *wayne_ctx_stream(wayne_ctx *ctx);
 
@@ -219,12 +236,16 @@ int wayne_exposure_upload(wayne_ctx *ctx, int slot, const wayne_exposure_desc *d
 /* Enqueue the whole synthesis of slot `slot` on the context stream
  * (asynchronous; inputs and outputs stay in HBM). */
 int wayne_exposure_run(wayne_ctx *ctx, int slot);
+/* wayne_exposure_run, then wait for the slot and settle it (see wayne_ctx_synchronize): when this returns WAYNE_OK the
+ * slot's reads in HBM are complete.  The blocking form for callers that read wayne_exposure_device_reads directly. */
+int wayne_exposure_run_checked(wayne_ctx *ctx, int slot);
 /* The status word of the slot's last run (synchronises its stream): 0 = complete; bit 0 = a count overflowed (the
- * download / wait calls report it as WAYNE_E_OVERFLOW); bit 1 = a bin held more electrons than the launch sequence
- * chosen from the host's estimate handles -- wayne_exposure_download / _wait / _debug_fetch then run the exposure a
- * second time with the general sequence, but a caller that only ever calls wayne_exposure_run (a throughput loop) must
- * look here to learn that a slot's reads are incomplete.  wayne_ctx_reruns: how many such second runs the context has
- * made (their electrons are counted twice in wayne_profile.electrons). */
+ * download / wait / synchronize calls report it as WAYNE_E_OVERFLOW); bit 1 = a bin held more electrons than the
+ * launch sequence chosen from the host's estimate handles.  Every call that hands results over or ends a batch --
+ * wayne_exposure_download / _wait / _run_checked / _debug_fetch and wayne_ctx_synchronize -- looks at the word itself
+ * and runs such an exposure a second time with the general sequence; only a caller that waits on wayne_ctx_stream
+ * with its own HIP calls bypasses that and must look here.  wayne_ctx_reruns: how many such second runs the context
+ * has made (their electrons are counted twice in wayne_profile.electrons). */
 int wayne_exposure_status(wayne_ctx *ctx, int slot, int *status);
 unsigned long long wayne_ctx_reruns(const wayne_ctx *ctx);
 /* Copy the NSAMP reads (read 0 = zero read) of `slot` to the host:

@@ -48,7 +48,7 @@ def lib():
         L.wayne_oracle_psf.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _i32p]
         L.wayne_oracle_psf_philox.restype = C.c_int
-        L.wayne_oracle_psf_philox.argtypes = [_i32p, C.c_int, _f32p, _f32p, _f64p, _f32p, _f32p,
+        L.wayne_oracle_psf_philox.argtypes = [_i32p, C.c_int, _f64p, _f64p, _f64p, _f32p, _f32p,
                                               C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _i32p]
         L.wayne_oracle_philox4x32.restype = None
         L.wayne_oracle_philox4x32.argtypes = [_u32p, _u32p, _u32p]
@@ -151,11 +151,11 @@ def psf_reference(counts, x, y, ratio, sl, sh, nr, nc, test, threads):
 
 def psf_philox_oracle(counts, x, y, ratio, sl, sh, nr, nc, seed, exposure, subsample):
     counts = np.ascontiguousarray(counts, dtype=np.int32)
-    x32, y32, sl32, sh32 = (np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
-                            for a in (x, y, sl, sh))
+    sl32, sh32 = (np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32)) for a in (sl, sh))
+    x64, y64 = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y))   # split into pixel + fraction in the C
     ratio = np.ascontiguousarray(ratio, dtype=np.float64)
     out = np.empty(nr * nc, dtype=np.int32)
-    rc = lib().wayne_oracle_psf_philox(counts, counts.size, x32, y32, ratio, sl32, sh32, nr, nc,
+    rc = lib().wayne_oracle_psf_philox(counts, counts.size, x64, y64, ratio, sl32, sh32, nr, nc,
                                        int(seed), int(exposure), int(subsample), out)
     if rc != 0:
         raise ValueError("wayne_oracle_psf_philox: status %d" % rc)

@@ -213,10 +213,22 @@ uint32_t wayne_oracle_xo_next(uint32_t state[4]) {
  * in fp32 (the device uses v_sin/v_cos/v_log hardware approximations, so
  * device-vs-oracle agreement is "all but a ~1e-4 fraction of electrons land
  * in the same pixel", asserted and counted in tests/test_psf_gpu.py).
- * Positions are fp32.  Same sigma split, truncation and bounds rule as A4.
+ * x_pos, y_pos above are the FRACTION of the bin's pixel: the fp64 position is split
+ * once per bin into floor(pos) and (float)(pos - floor(pos)), the float32 offset is
+ * added to the fraction and the electron's pixel is floor(pos) + floor(that sum)
+ * (wayne_amd/csrc/common.h, bin_local; split_oracle.c, so_bin_local) -- floor where
+ * the reference truncates (:91-92), which keeps the same electrons under the strict
+ * bounds 0 < pos < n (:93).  Same sigma split and bounds rule as A4.
  */
+static int wo_cell(int o, float v) {
+  if (!(v > -2147483904.0f)) return INT32_MIN;
+  if (!(v < 2147483648.0f)) return INT32_MAX;
+  const int64_t c = (int64_t)o + (int64_t)floorf(v);
+  return c < INT32_MIN ? INT32_MIN : (c > INT32_MAX ? INT32_MAX : (int)c);
+}
+
 int wayne_oracle_psf_philox(const int32_t *counts, int size,
-                            const float *x_pos, const float *y_pos,
+                            const double *x_pos, const double *y_pos,
                             const double *psf_ratio, const float *psf_sigmal,
                             const float *psf_sigmah, int nr, int nc,
                             uint32_t seed, uint32_t exposure,
@@ -230,6 +242,10 @@ int wayne_oracle_psf_philox(const int32_t *counts, int size,
     if (counts[b] < 0) return -2;
     /* sigma split in fp64, as the reference (:89) */
     const int n_wide = wo_trunc_int(counts[b] * psf_ratio[b]);
+    const int sane = fabs(x_pos[b]) < 1e6 && fabs(y_pos[b]) < 1e6;
+    const double flx = sane ? floor(x_pos[b]) : 0.0, fly = sane ? floor(y_pos[b]) : 0.0;
+    const float fx = (float)(x_pos[b] - flx), fy = (float)(y_pos[b] - fly);
+    const int ox = (int)flx, oy = (int)fly;
     for (int j = 0; j < counts[b]; ++j, ++e) {
       if ((e & 127u) == 0) {
         /* new block of 128 electrons: fresh stream */
@@ -242,8 +258,8 @@ int wayne_oracle_psf_philox(const int32_t *counts, int size,
       const float sig = (j < n_wide) ? psf_sigmah[b] : psf_sigmal[b];
       const float c = (-1.3862943611198906f * sig) * sig;
       const float Rs = sqrtf(c * log2f(wo_u01(rb)));
-      const int xp = wo_trunc_int((double)fmaf(cosf(ang), Rs, x_pos[b]));
-      const int yp = wo_trunc_int((double)fmaf(sinf(ang), Rs, y_pos[b]));
+      const int xp = wo_cell(ox, fmaf(cosf(ang), Rs, fx));
+      const int yp = wo_cell(oy, fmaf(sinf(ang), Rs, fy));
       if (xp > 0 && xp < nr && yp > 0 && yp < nc) out[yp * nc + xp] += 1;
     }
   }

@@ -191,9 +191,28 @@ static int so_cell_offset(int c) { return c == 0 ? 0 : (c % 2 ? (c + 1) / 2 : -(
 
 static float so_clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
-static int so_trunc(float v) {
-  if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
-  return (int)v;
+/* Bin-local coordinates (wayne_amd/csrc/common.h, bin_local): a bin's position is split in fp64 into its pixel o and
+ * the fraction f of it, pos = o + f, f = (float)(pos - o); an electron's float32 offset is added to f and its pixel is
+ * o + floor(f + offset).  floor, where the reference truncates toward zero (pyparallel_menu.c:91-92): the two differ
+ * only for frame coordinates in (-1, 0), which both leave outside 0 < pos < n (:93).  A position that is not finite or
+ * beyond +-1e6 is not split: o = 0, f = (float)pos. */
+typedef struct { float fx, fy; int ox, oy; int sane; } so_local;
+
+static so_local so_bin_local(double xd, double yd) {
+  so_local b;
+  b.sane = fabs(xd) < 1e6 && fabs(yd) < 1e6;
+  const double flx = b.sane ? floor(xd) : 0.0, fly = b.sane ? floor(yd) : 0.0;
+  b.fx = (float)(xd - flx); b.fy = (float)(yd - fly);
+  b.ox = (int)flx; b.oy = (int)fly;
+  return b;
+}
+
+/* o + floor(v); a NaN or a value beyond int32 lands off every frame (the device saturates the conversion) */
+static int so_cell(int o, float v) {
+  if (!(v > -2147483904.0f)) return INT32_MIN;
+  if (!(v < 2147483648.0f)) return INT32_MAX;
+  const int64_t c = (int64_t)o + (int64_t)floorf(v);
+  return c < INT32_MIN ? INT32_MIN : (c > INT32_MAX ? INT32_MAX : (int)c);
 }
 
 /*
@@ -209,14 +228,14 @@ static int so_trunc(float v) {
  * Either way: the first n_wide electrons of a bin take sigma_h
  * (pyparallel_menu.c:89-107), same arithmetic as wayne_oracle_psf_philox.
  */
-static void so_throw_one(uint32_t g[4], float x, float y, float sig, int n, int32_t *out) {
+static void so_throw_one(uint32_t g[4], const so_local *L, float sig, int n, int32_t *out) {
   uint32_t w[2];
   wayne_oracle_xo_next2(g, w);            /* one pair per electron: angle, radius */
   const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
   const float c = (-1.3862943611198906f * sig) * sig;
   const float Rs = sqrtf(c * log2f(so_u01(w[1])));
-  const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
-  const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
+  const int xp = so_cell(L->ox, fmaf(cosf(ang), Rs, L->fx));
+  const int yp = so_cell(L->oy, fmaf(sinf(ang), Rs, L->fy));
   if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
 }
 
@@ -224,7 +243,7 @@ static void so_throw_one(uint32_t g[4], float x, float y, float sig, int n, int3
  * mantissa of a float in [1, 2) revolutions), its low half h the radius, u = (h + 1/2) / 2^16; h = 0 (the far tail,
  * where the cell is not small) is subdivided by 17 bits of the bin's side LCG: u = (h' + 1/2) / 2^33.  Same arithmetic
  * as the device's k_lane (k_narrow.h), libm for the hardware's log2 / sqrt / sin / cos. */
-static void so_throw_word(uint32_t wd, uint32_t *refine, float x, float y, float sig, int n, int32_t *out) {
+static void so_throw_word(uint32_t wd, uint32_t *refine, const so_local *L, float sig, int n, int32_t *out) {
   const uint32_t bits = 0x3f800000u | (wd >> 9);
   float rev;
   memcpy(&rev, &bits, 4);
@@ -237,8 +256,8 @@ static void so_throw_word(uint32_t wd, uint32_t *refine, float x, float y, float
     r2 = fmaf(c, log2f((float)(*refine >> 15) + 0.5f), -33.0f * c);
   }
   const float Rs = sqrtf(r2);
-  const int xp = so_trunc(fmaf(cosf(ang), Rs, x));
-  const int yp = so_trunc(fmaf(sinf(ang), Rs, y));
+  const int xp = so_cell(L->ox, fmaf(cosf(ang), Rs, L->fx));
+  const int yp = so_cell(L->oy, fmaf(sinf(ang), Rs, L->fy));
   if (xp > 0 && xp < n && yp > 0 && yp < n) out[(size_t)yp * n + xp] += 1;
 }
 
@@ -258,12 +277,13 @@ static void so_throw_word(uint32_t wd, uint32_t *refine, float x, float y, float
  */
 enum { SO_GROUP = 16, SO_PROWS = 2 * SO_WINDOW + 2, SO_STAGE_POOL = 11 };
 
-/* masses of N(y, sigma^2) on the rows [J0 + t, J0 + t + 1), t = 0..SO_PROWS-1, normalised to sum 1; every mass is
- * a difference of two tails on the same side of y (no cancellation), the row that holds y is 1 - both tails */
-static void so_rows_abs(float y, float inv_s, int J0, float q[SO_PROWS]) {
+/* masses of N(y, sigma^2) on the rows [J0 + t, J0 + t + 1), t = 0..SO_PROWS-1, normalised to sum 1, from
+ * yl = y - J0 (the bin's height above the bottom row of the window); every mass is a difference of two tails on the
+ * same side of y (no cancellation), the row that holds y is 1 - both tails */
+static void so_rows_abs(float yl, float inv_s, float q[SO_PROWS]) {
   float A[SO_PROWS + 1], E[SO_PROWS + 1];
   for (int t = 0; t <= SO_PROWS; ++t) {
-    E[t] = (float)(J0 + t) - y;
+    E[t] = (float)t - yl;
     A[t] = so_tail(fabsf(E[t]) * inv_s);
   }
   float S = 0.0f;
@@ -278,23 +298,34 @@ static void so_rows_abs(float y, float inv_s, int J0, float q[SO_PROWS]) {
   for (int t = 0; t < SO_PROWS; ++t) q[t] = q[t] / S;
 }
 
-typedef struct { int split; float n, x, y, sl; int ic, jc; } so_bin;
+/* a bin of a group: pixel (ic, jc) + fraction (fx, fy) of its position (so_bin_local); yd: the position's y in fp64 */
+typedef struct { int split, sane; float n, fx, fy, sl; double yd; int ic, jc; } so_bin;
+
+/* the bin's height above row J0, rounded once from fp64 */
+static float so_yl(const so_bin *b, int J0) { return (float)(b->yd - (double)J0); }
 
 static int so_group_pools(const so_bin *B, int nb) {
-  int act = 0, ic0 = INT32_MAX, ic1 = INT32_MIN;
-  float y0 = 3e38f, y1 = -3e38f, s0 = 3e38f, s1 = 0.0f;
+  int act = 0, ic0 = INT32_MAX, ic1 = INT32_MIN, jc0 = INT32_MAX;
+  float s0 = 3e38f, s1 = 0.0f;
   int64_t tot = 0;
   for (int i = 0; i < nb; ++i) {
     if (!B[i].split) continue;
-    if (!(fabsf(B[i].x) < 1e6f && fabsf(B[i].y) < 1e6f)) return 0;
+    if (!B[i].sane) return 0;
     ++act;
     if (B[i].ic < ic0) ic0 = B[i].ic;
     if (B[i].ic > ic1) ic1 = B[i].ic;
-    y0 = fminf(y0, B[i].y); y1 = fmaxf(y1, B[i].y);
+    if (B[i].jc < jc0) jc0 = B[i].jc;
     s0 = fminf(s0, B[i].sl); s1 = fmaxf(s1, B[i].sl);
     tot += (int64_t)B[i].n;
   }
-  return act >= 2 && ic1 - ic0 <= 2 && (y1 - y0) <= 0.25f * s0 && s1 <= 1.1f * s0 && tot <= 16777216;
+  if (act < 2) return 0;
+  float y0 = 3e38f, y1 = -3e38f;
+  for (int i = 0; i < nb; ++i) {
+    if (!B[i].split) continue;
+    const float yl = so_yl(&B[i], jc0 - SO_WINDOW);
+    y0 = fminf(y0, yl); y1 = fmaxf(y1, yl);
+  }
+  return ic1 - ic0 <= 2 && (y1 - y0) <= 0.25f * s0 && s1 <= 1.1f * s0 && tot <= 16777216;
 }
 
 static void so_put(int32_t *out, int n, int col, int row, float m) {
@@ -303,10 +334,11 @@ static void so_put(int32_t *out, int n, int col, int row, float m) {
 
 static void so_narrow_own(const so_bin *b, int bin, const uint32_t key_n[2], uint32_t subsample, uint32_t exposure,
                           int n, int32_t *out) {
+  if (!b->sane) return;          /* (none of its electrons can reach the frame: k_narrow.h) */
   const float inv_s = 1.0f / b->sl;
   float P[SO_CELLS], Pb[SO_CELLS], Q[SO_CELLS], Qb[SO_CELLS];
-  so_cell_masses(b->x - (float)b->ic, inv_s, P, Pb);
-  so_cell_masses(b->y - (float)b->jc, inv_s, Q, Qb);
+  so_cell_masses(b->fx, inv_s, P, Pb);
+  so_cell_masses(b->fy, inv_s, Q, Qb);
   const uint32_t ctr[4] = {(uint32_t)bin, 0u, subsample, exposure};
   uint32_t st[4];
   wayne_oracle_philox4x32(ctr, key_n, st);
@@ -337,7 +369,7 @@ static void so_narrow_pooled(const so_bin *B, int nb, int bin0, uint32_t seed, u
   for (int t = 0; t < SO_PROWS; ++t) qbar[t] = 3e38f;
   for (int i = 0; i < nb; ++i) {
     if (!B[i].split) continue;
-    so_rows_abs(B[i].y, 1.0f / B[i].sl, J0, q[i]);
+    so_rows_abs(so_yl(&B[i], J0), 1.0f / B[i].sl, q[i]);
     for (int t = 0; t < SO_PROWS; ++t) qbar[t] = fminf(qbar[t], q[i][t]);
   }
   /* tails of qbar about the centre row SO_WINDOW, summed from the far ends inwards */
@@ -361,7 +393,7 @@ static void so_narrow_pooled(const so_bin *B, int nb, int bin0, uint32_t seed, u
     /* the common electrons' columns */
     const float inv_s = 1.0f / b->sl;
     float P[SO_CELLS], Pb[SO_CELLS];
-    so_cell_masses(b->x - (float)b->ic, inv_s, P, Pb);
+    so_cell_masses(b->fx, inv_s, P, Pb);
     float left = common;
     for (int c = 0; c < SO_CELLS && left > 0.0f; ++c) {
       const float in_col = wayne_oracle_binomial_f(left, so_clamp01(P[c] / Pb[c]), st);
@@ -378,9 +410,10 @@ static void so_narrow_pooled(const so_bin *B, int nb, int bin0, uint32_t seed, u
       wayne_oracle_xo_next2(st, v);
       const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
       const float Rs = sqrtf(cs * log2f(so_u01(w[1])));
-      int col = (int)floorf(fmaf(cosf(ang), Rs, b->x));
-      if (col < b->ic - SO_WINDOW) col = b->ic - SO_WINDOW;
-      if (col > b->ic + SO_WINDOW) col = b->ic + SO_WINDOW;
+      int col = so_cell(0, fmaf(cosf(ang), Rs, b->fx));
+      if (col < -SO_WINDOW) col = -SO_WINDOW;
+      if (col > SO_WINDOW) col = SO_WINDOW;
+      col += b->ic;
       const float u = so_u01(v[0]) * R;
       int row = 0;
       for (int t = 0; t < SO_PROWS - 1; ++t) row += (u >= D[t]);
@@ -433,10 +466,10 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
       /* (the chain counts in float32: bins beyond 2^24 narrow electrons stay with the per-electron thrower) */
       const int split = split_min > 0 && n_narrow >= split_min && n_narrow <= 16777216 && psf_sigmal[b] > 0.05 &&
                         psf_sigmal[b] * 6.5 <= (double)SO_WINDOW;
-      const float x = (float)x_pos[b], y = (float)y_pos[b];
+      const so_local L = so_bin_local(x_pos[b], y_pos[b]);
       const float sl = (float)psf_sigmal[b], sh = (float)psf_sigmah[b];
-      B[i].split = split; B[i].n = (float)n_narrow; B[i].x = x; B[i].y = y; B[i].sl = sl;
-      B[i].ic = (int)floorf(x); B[i].jc = (int)floorf(y);
+      B[i].split = split; B[i].sane = L.sane; B[i].n = (float)n_narrow; B[i].fx = L.fx; B[i].fy = L.fy; B[i].sl = sl;
+      B[i].yd = y_pos[b]; B[i].ic = L.ox; B[i].jc = L.oy;
 
       /* one by one */
       const int64_t thrown = split ? n_wide : counts[b];
@@ -447,7 +480,7 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
         uint32_t refine = (gl[1] * 0x9E3779B9u) ^ gl[3], w2[2] = {0u, 0u};
         for (int64_t j = 0; j < thrown; ++j) {
           if ((j & 1) == 0) wayne_oracle_xo_next2(gl, w2);          /* a pair of the stream serves two electrons */
-          so_throw_word(w2[j & 1], &refine, x, y, (j < n_wide) ? sh : sl, n, out);
+          so_throw_word(w2[j & 1], &refine, &L, (j < n_wide) ? sh : sl, n, out);
         }
       } else {
         for (int64_t j = 0; j < thrown; ++j, ++e) {
@@ -455,7 +488,7 @@ int wayne_oracle_psf_split(const int32_t *counts, int size, const double *x_pos,
             const uint32_t ctr[4] = {(uint32_t)(e >> 7), 0u, subsample, exposure};
             wayne_oracle_philox4x32(ctr, key_t, g);
           }
-          so_throw_one(g, x, y, (j < n_wide) ? sh : sl, n, out);
+          so_throw_one(g, &L, (j < n_wide) ? sh : sl, n, out);
         }
       }
     }

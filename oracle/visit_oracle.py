@@ -180,6 +180,12 @@ class ObservationOracle(object):
         kw = dict(self.frame_kwargs)
         kw.update(sky_background=inp["sky_background"], scale_factor=inp["scale_factor"])
         kw.update(oracle_kw)
+        # `planet_signal`: a K x W depth matrix to use instead of this oracle's own light curves (a test hands in the
+        # device's, after comparing the two, so that np.round / Poisson of the counts see the same means to the last bit)
+        override = kw.pop("planet_signal", None)
+        if override is not None:
+            assert np.shape(override) == np.shape(inp["planet_signal"])
+            inp["planet_signal"] = np.asarray(override, dtype=float)
         if self.spatial_scan:
             return self.eo.scanning_frame(inp["x_ref"], inp["y_ref"], self.x_jitter, self.y_jitter, self.wl,
                                           self.stellar_flux, inp["planet_signal"], self.scan_speed, self.sample_rate,
@@ -189,3 +195,65 @@ class ObservationOracle(object):
         return self.eo.staring_frame(inp["x_ref"], inp["y_ref"], self.x_jitter, self.y_jitter, self.wl,
                                      self.stellar_flux, inp["planet_signal"], inp["sample_mid_points"],
                                      inp["sample_durations"], inp["read_index"], draws=draws, **kw)
+
+
+# ---------------------------------------------------------------------------
+# the CLI's ingestion of a parameter file (run_visit.py:41-320), for the reference's example visit
+# ---------------------------------------------------------------------------
+R_SUN_IN_AU = 6.957e8 / 1.495978707e11      # IAU 2015 nominal solar radius over the astronomical unit
+
+
+def blackbody_lambda(wl_um, T):
+    """Planck's law per unit wavelength in erg / (s cm^2 angstrom sr), what astropy's blackbody_lambda returns
+    (run_visit.py:201-203); wavelengths in micron.  Written from the SI form, converted at the end."""
+    h, c, kB = 6.62607015e-34, 2.99792458e8, 1.380649e-23
+    lam = np.asarray(wl_um, dtype=float) * 1e-6                                  # m
+    b_si = 2.0 * h * c ** 2 / lam ** 5 / (np.exp(h * c / (lam * kB * T)) - 1.0)  # W m^-2 m^-1 sr^-1
+    return b_si * 1e7 * 1e-4 * 1e-10                                             # erg/s, per cm^2, per angstrom
+
+
+def visit_from_parameter_file(cfg, directory, exposure_oracle, detector, star_temperature=6100.0):
+    """The ObservationOracle of a parsed YAML parameter file whose file names are relative to `directory`, following
+    run_visit.py statement by statement for the keys the example file holds: planet spectrum sorted by wavelength
+    and cropped to 0.9-1.8 micron whatever the grism (:151-153), no rebinning (`rebin_resolution: false`), stellar
+    flux = black body x flux_scale when there is no stellar spectrum file to read (:201-205; the example's FITS blob
+    is absent here and its YAML says the flux is a black body), per-exposure x_ref / y_ref / sky / start times from
+    text files (:268-290), SSVSine from `ssv_coeffs` (:233-245), the visit ramp (:316-318).  The orbit's a / R* from
+    `sma` (au) and `stellar_radius` (solar radii); Rp/R* of the white light curve = sqrt(mean depth) (the reference
+    takes it from the Open Exoplanet Catalogue entry, which is absent: it only enters the secondary eclipse).
+    Returns (ObservationOracle, dict of the plain inputs)."""
+    import os
+    target, oc = cfg["target"], cfg["observation"]
+
+    def load(name):
+        return np.loadtxt(os.path.join(directory, name))
+
+    spec = load(target["planet_spectrum_file"])
+    order = np.argsort(spec[:, 0], kind="stable")                       # tools.load_and_sort_spectrum (tools.py:182-200)
+    wl_all, depth_all = spec[order, 0], spec[order, 1]
+    i0, i1 = wo.crop_spectrum_ind(0.9, 1.8, wl_all.copy())              # run_visit.py:152-153
+    wl, depth = wl_all[i0:i1], depth_all[i0:i1]
+    assert not target["rebin_resolution"]
+    flux = blackbody_lambda(wl, star_temperature) * target["flux_scale"]
+    sma_over_rs = target["sma"] / (target["stellar_radius"] * R_SUN_IN_AU)
+    orbit = (target["period"], sma_over_rs, target["eccentricity"], target["inclination"], target["periastron"],
+             target["transit_time"])
+    x_ref = load(oc["x_ref"]) if isinstance(oc["x_ref"], str) else oc["x_ref"]
+    y_ref = load(oc["y_ref"]) if isinstance(oc["y_ref"], str) else oc["y_ref"]
+    sky = load(oc["sky_background"]) if isinstance(oc["sky_background"], str) else oc["sky_background"]
+    starts = load(oc["exp_start_times"]) if oc.get("exp_start_times") else None
+    assert oc["ssv_type"] == "sine" and oc["spatial_scan"]
+    frame_kwargs = dict(ssv_generator=wo.SSVSine(*oc["ssv_coeffs"]), cosmic_rate=oc["cosmic_rate"],
+                        noise_mean=oc["noise_mean"], noise_std=oc["noise_std"], add_dark=oc["add_dark"],
+                        add_flat=oc["add_flat"], add_gain_variations=oc["add_gain_variations"],
+                        add_non_linear=oc["add_non_linear"], add_read_noise=oc["add_read_noise"],
+                        add_initial_bias=oc["add_initial_bias"], add_stellar_noise=oc["add_stellar_noise"],
+                        clip_values_det_limits=oc["clip_values_det_limits"], threads=cfg["general"]["threads"])
+    rp_white = float(np.sqrt(np.mean(depth)))
+    oo = ObservationOracle(exposure_oracle, detector, oc["NSAMP"], oc["SAMPSEQ"], oc["SUBARRAY"], wl, flux, depth, orbit,
+                           target["ldcoeffs"], rp_white, x_ref, y_ref, True, oc["scan_speed"], oc["sample_rate"],
+                           oc["start_JD"] or 0.0, oc["num_orbits"], exp_start_times=starts, x_shifts=oc["x_shifts"],
+                           y_shifts=oc["y_shifts"], x_jitter=oc["x_jitter"], y_jitter=oc["y_jitter"], sky_background=sky,
+                           visit_trend_coeffs=cfg["trends"]["visit_trend_coeffs"], frame_kwargs=frame_kwargs)
+    return oo, dict(wl=wl, depth=depth, flux=flux, x_ref=x_ref, y_ref=y_ref, sky=sky, starts=starts, orbit=orbit,
+                    rp_white=rp_white)

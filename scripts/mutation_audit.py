@@ -102,10 +102,13 @@ MUTANTS = [
          edits=[("k_narrow.h", "const float z = t * 0.70710678118654752f;", "const float z = t * 0.72f;")]),
     dict(name="lane_cos_sin_swapped", stage="A2 / A4 Box-Muller (pyparallel_menu.c:91-93)",
          what="k_lane takes x from the sine and y from the cosine: the same law, other electrons",
-         edits=[("k_narrow.h", "    xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);      // C truncation toward zero (:91-92)\n"
-                               "    yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);",
-                 "    xi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, px);\n"
-                 "    yi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, py);")]),
+         edits=[("k_narrow.h", "    vx = fmaf(__builtin_amdgcn_cosf(rev), Rs, px);            // offset + the bin's fraction of a pixel (:91-92; bin_local)\n"
+                               "    vy = fmaf(__builtin_amdgcn_sinf(rev), Rs, py);",
+                 "    vx = fmaf(__builtin_amdgcn_sinf(rev), Rs, px);\n"
+                 "    vy = fmaf(__builtin_amdgcn_cosf(rev), Rs, py);")]),
+    dict(name="bin_fraction_dropped", stage="A4 position of a bin inside its pixel (pyparallel_menu.c:91-92; common.h bin_local)",
+         what="the production throwers forget the fraction of a pixel of every bin's position: electrons thrown from the pixel's corner",
+         edits=[("common.h", "  b.fx = (float)(xd - flx); b.fy = (float)(yd - fly);", "  b.fx = 0.f; b.fy = 0.f;")]),
     dict(name="wide_count_rounded", stage="A4 N = (int)(counts ratio) (pyparallel_menu.c:89)",
          what="the wide count rounded to nearest instead of truncated (thrower call and exposure path)",
          edits=[("host_plan.h", "                                                   : (int32_t)nw;",

@@ -20,6 +20,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wayne_amd import build as _wb  # noqa: E402
+os.environ["WAYNE_ALLOW_FLAGGED_LIB"] = "1"      # a timing build, on purpose (wayne_amd/_lib.py refuses one otherwise)
 os.environ["WAYNE_HIP_LIB"] = _wb.build_variant(["-DWAYNE_TIMING_KNOBS"] + os.environ.get("WAYNE_CXXFLAGS", "").split(),
                                                 os.path.join(ROOT, "ab", "timing_knobs.so"))
 from wayne_amd import calibration, detector, engine, grism, synthetic  # noqa: E402
@@ -38,7 +39,7 @@ ctx.run(0)
 ctx.synchronize()
 rows = []
 for R in [15] + list(range(1, 16)):
-    os.environ["WAYNE_RAMP_READS"] = str(R)
+    ctx.set_knob("ramp_reads", R)
     ctx.run(0)
     ctx.synchronize()
     ctx.profile_enable(True)
@@ -50,7 +51,7 @@ for R in [15] + list(range(1, 16)):
     t = p["k_ramp"]["ms"] / p["k_ramp"]["launches"] * 1e3
     rows.append((R, t))
     print("R = %2d   k_ramp %.2f us" % (R, t), flush=True)
-del os.environ["WAYNE_RAMP_READS"]
+ctx.set_knob("ramp_reads", None)
 R = np.array([r for r, _ in rows[1:]], dtype=float)
 T = np.array([t for _, t in rows[1:]])
 t1, t0 = np.polyfit(R, T, 1)

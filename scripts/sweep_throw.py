@@ -21,11 +21,8 @@ ctx = eng.ctx
 eg = ExposureGenerator(det, gr, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=cal, seed=v.seed)
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 for wgs, tile, margin in itertools.product([512, 1024, 1536, 2048, 3072, 4096], [0], [16, 20, 24]):
-    os.environ["WAYNE_THROW_WGS"] = str(wgs)
-    if tile:
-        os.environ["WAYNE_TILE_INTS"] = str(tile)
-    else:
-        os.environ.pop("WAYNE_TILE_INTS", None)
+    ctx.set_knob("throw_wgs", wgs)
+    ctx.set_knob("tile_ints", tile if tile else None)
     desc = eg.build_descriptor(eng, rng_mode=mode, out_dtype=np.float32, **v.frame_kwargs(0))
     desc.thrower_margin = margin
     ctx.upload(0, desc)

@@ -37,6 +37,15 @@ def load_golden_psf(name):
     return k
 
 
+@pytest.fixture(autouse=True)
+def _knobs_back_to_default():
+    """A test that sets tuning knobs on the live contexts (_lib.set_knob_all) leaves none behind, pass or fail."""
+    yield
+    from wayne_amd import _lib
+    if _lib._knob_defaults:
+        _lib.reset_knobs_all()
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
     """One wayne_ctx on cuda:0 for the whole GPU session (fails loudly without a GPU)."""

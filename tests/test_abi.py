@@ -29,9 +29,48 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_strerror():
     L = _lib.load()
-    assert L.wayne_abi_version() == 6
+    assert L.wayne_abi_version() == 7 == _lib.ABI_VERSION
     assert L.wayne_strerror(0) == b"ok"
     assert b"gfx950" in L.wayne_strerror(_lib.E_NODEVICE)
+    assert L.wayne_build_flags() == b""            # the shipped library carries no negative-control / timing switch
+
+
+def test_the_environment_is_read_in_one_place_only():
+    # the tuning knobs are frozen when a context is created (wayne_hip.h, wayne_ctx_set_knob): no entry point of a live
+    # context may look at the environment -- one getenv in the whole library, inside wayne_ctx_create
+    src = open(os.path.join(ROOT, "wayne_amd", "csrc", "wayne_hip.hip")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    assert len(re.findall(r"\bgetenv\s*\(", code)) == 1
+    create = code[code.index("wayne_ctx* wayne_ctx_create("):code.index("void wayne_ctx_destroy(")]
+    assert "getenv" in create
+    for h in os.listdir(os.path.join(ROOT, "wayne_amd", "csrc")):
+        if h.endswith(".h"):
+            assert "getenv" not in open(os.path.join(ROOT, "wayne_amd", "csrc", h)).read(), h
+    # every knob the header names is one the binding knows, and the other way round
+    header = open(os.path.join(ROOT, "include", "wayne_hip.h")).read()
+    named = header[header.index("Names:"):header.index("None changes a frame")]
+    names = set(re.findall(r"\b([a-z]+(?:_[a-z]+)+|batch|thin|streams)\b", named)) - {"timing", "builds", "only"}
+    assert names == set(_lib.KNOBS), names ^ set(_lib.KNOBS)
+    table = set(re.findall(r'\{"([a-z_]+)", "WAYNE_[A-Z_]+", &Knobs::', src))
+    assert table == set(_lib.KNOBS)
+
+
+def test_a_flagged_library_is_refused(tmp_path, monkeypatch):
+    # a negative-control or timing build names its switches in wayne_build_flags(); the binding refuses it unless the
+    # caller says it means to load one
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "tests", "native", "_build", "libwayne_hip_negctl_sky.so")
+    if not os.path.exists(lib):
+        pytest.skip("negative-control library not built")
+    code = "from wayne_amd import _lib; _lib.load(); print(_lib.library_info()[1])"
+    env = dict(os.environ, WAYNE_HIP_LIB=lib)
+    env.pop("WAYNE_ALLOW_FLAGGED_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WAYNE_NEGCTL_SKY_RUNAWAY" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, WAYNE_ALLOW_FLAGGED_LIB="1"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "WAYNE_NEGCTL_SKY_RUNAWAY"
 
 
 def test_host_philox_known_answers():

@@ -63,11 +63,12 @@ def test_cfg4_deterministic_and_geometry_invariant():
     a = frames(v)
     b = frames(v)
     np.testing.assert_array_equal(a, b)
-    os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"] = "700", "5000"
+    _lib.set_knob_all("throw_wgs", 700)
+    _lib.set_knob_all("tile_ints", 5000)
     try:
         c = frames(v)
     finally:
-        del os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"]
+        _lib.reset_knobs_all()
     np.testing.assert_array_equal(a, c)
 
 

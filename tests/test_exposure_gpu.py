@@ -301,12 +301,12 @@ def test_exposure_is_deterministic_and_split_invariant():
     b = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
     np.testing.assert_array_equal(a, b)
     import os
-    os.environ["WAYNE_THROW_WGS"] = "37"
-    os.environ["WAYNE_TILE_INTS"] = "2000"
+    _lib.set_knob_all("throw_wgs", 37)
+    _lib.set_knob_all("tile_ints", 2000)
     try:
         c = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
     finally:
-        del os.environ["WAYNE_THROW_WGS"], os.environ["WAYNE_TILE_INTS"]
+        _lib.reset_knobs_all()
     np.testing.assert_array_equal(a, c)      # integer accumulation: launch geometry cannot change a bit
     other = helpers.product_generator(v, 1)
     d = np.stack([r[0] for r in other.scanning_frame(**kw).reads])

@@ -476,7 +476,7 @@ def test_cosmic_ray_hits_follow_their_three_laws(path, name, N, n_exp, monkeypat
     # scales by 1 / 16 -- scripts/mutation_audit.py: an unscaled rate is 2 % at the full array and passed there).
     from scipy import stats
     if path == "k_prep_sub":
-        monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+        _lib.set_knob_all("no_fuse", "1")
     v = helpers.make_visit(name, n_exposures=n_exp)
     rate = 11.0
     dt = np.diff(np.concatenate([[0.0], v.read_times]))
@@ -538,7 +538,7 @@ def test_negative_control_the_unbounded_sky_search_is_caught():
             "tails, k_max = t.sky_only_tails(v, 8, np.random.default_rng(1))\n"
             "print(json.dumps({'bad': xs.check(tails, 'sky'), 'k_max': k_max, 'summary': xs.summary(tails)}))\n"
             % (ROOT, os.path.join(ROOT, "tests")))
-    env = dict(os.environ, WAYNE_HIP_LIB=lib)
+    env = dict(os.environ, WAYNE_HIP_LIB=lib, WAYNE_ALLOW_FLAGGED_LIB="1")   # a negative-control build, on purpose
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])

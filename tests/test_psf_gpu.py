@@ -135,15 +135,11 @@ def test_philox_mode_is_deterministic_and_geometry_invariant(gpu_ctx):
     a = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
     b = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
     np.testing.assert_array_equal(a, b)
-    old = os.environ.get("WAYNE_TILE_INTS")
-    os.environ["WAYNE_TILE_INTS"] = "300"          # tiny LDS tile: most electrons take the global path
+    gpu_ctx.set_knob("tile_ints", 300)             # tiny LDS tile: most electrons take the global path
     try:
         c = gpu_ctx.psf_apply(k["counts"], k["x"], k["y"], k["ratio"], k["sl"], k["sh"], 1014, 1014, 42, rng_mode=1)
     finally:
-        if old is None:
-            del os.environ["WAYNE_TILE_INTS"]
-        else:
-            os.environ["WAYNE_TILE_INTS"] = old
+        gpu_ctx.set_knob("tile_ints", None)
     np.testing.assert_array_equal(a, c)
     assert a.sum() == k["counts"].sum()             # nothing falls off this frame
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import helpers
-from wayne_amd import visit
+from wayne_amd import _lib, visit
 from wayne_amd.exposure_generator import ExposureGenerator
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,7 @@ def test_a_bin_beyond_the_lanes_reach_reruns_with_k_throw(monkeypatch):
     kw = v.frame_kwargs(0)
     pg = helpers.product_generator(v, 0)
     want = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
-    monkeypatch.setenv("WAYNE_LANE_REACH", "5")
+    _lib.set_knob_all("lane_reach", "5")
     rec = {}
     via_record = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw).reads])     # debug_fetch re-runs the front half
     via_download = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])              # download re-runs the exposure
@@ -48,11 +48,33 @@ def test_a_bin_beyond_the_lanes_reach_reruns_with_k_throw(monkeypatch):
     eng.ctx.run(3)
     eng.ctx.fetch_async(3)
     via_wait = np.array(eng.ctx.wait(3))                                                 # the pipelined path re-runs too
-    monkeypatch.delenv("WAYNE_LANE_REACH")
+    # a throughput loop: run() calls only, then ONE synchronize -- which settles every slot it finds flagged
+    # (wayne_ctx_synchronize), so that the reads in HBM are complete without any download having looked at them
+    n0 = eng.ctx.reruns
+    for slot in (4, 6, 7):
+        eng.ctx.upload(slot, desc)
+        eng.ctx.run(slot)
+    eng.ctx.synchronize()
+    assert eng.ctx.reruns == n0 + 3 and [eng.ctx.status(s) for s in (4, 6, 7)] == [0, 0, 0]
+    n1 = eng.ctx.reruns
+    via_sync = [eng.ctx.download(slot) for slot in (4, 6, 7)]
+    assert eng.ctx.reruns == n1                                                          # nothing left for the downloads to repair
+    # the blocking form: complete when it returns
+    eng.ctx.upload(9, desc)
+    eng.ctx.run_checked(9)
+    assert eng.ctx.status(9) == 0 and eng.ctx.reruns == n1 + 1
+    via_checked = eng.ctx.download(9)
+    # and a slot that has been repaired once runs the general sequence from then on (no second run per launch)
+    eng.ctx.run(9)
+    eng.ctx.synchronize()
+    assert eng.ctx.reruns == n1 + 1
+    _lib.set_knob_all("lane_reach", None)
     assert (rec["counts"] * 0.2 > 5).mean() > 0.5                                        # most bins were beyond the reach
     np.testing.assert_array_equal(via_record, want)
     np.testing.assert_array_equal(via_download, want)
     np.testing.assert_array_equal(via_wait, want)
+    for got in via_sync + [via_checked]:
+        np.testing.assert_array_equal(got, want)
 
 
 @pytest.mark.parametrize("name", ["small256", "tiny"])
@@ -65,19 +87,18 @@ def test_frames_do_not_depend_on_batches_or_the_thin_flush(name, monkeypatch):
     pg = helpers.product_generator(v, 0)
     want = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
     for batch, thin in (("1", "0"), ("1", "1"), ("4", "1"), ("4", "0"), ("32", "1")):
-        monkeypatch.setenv("WAYNE_BATCH", batch)
-        monkeypatch.setenv("WAYNE_THIN", thin)
+        _lib.set_knob_all("batch", batch)
+        _lib.set_knob_all("thin", thin)
         got = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
         np.testing.assert_array_equal(got, want, err_msg="WAYNE_BATCH=%s WAYNE_THIN=%s" % (batch, thin))
     # the per-electron and replay throwers go through the batched k_prep_sub too
-    from wayne_amd import _lib
-    monkeypatch.delenv("WAYNE_BATCH")
-    monkeypatch.delenv("WAYNE_THIN")
+    _lib.set_knob_all("batch", None)
+    _lib.set_knob_all("thin", None)
     for mode in (_lib.RNG_PHILOX, _lib.RNG_REPLAY):
         a = np.stack([r[0] for r in pg.scanning_frame(rng_mode=mode, **kw).reads])
-        monkeypatch.setenv("WAYNE_BATCH", "5")
+        _lib.set_knob_all("batch", "5")
         b = np.stack([r[0] for r in pg.scanning_frame(rng_mode=mode, **kw).reads])
-        monkeypatch.delenv("WAYNE_BATCH")
+        _lib.set_knob_all("batch", None)
         np.testing.assert_array_equal(a, b)
 
 
@@ -90,9 +111,9 @@ def test_thin_exposure_without_k_narrow_and_its_rerun(monkeypatch):
     rec = {}
     a = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw).reads])
     assert rec["counts"].max() < 32 and rec["counts"].mean() > 1
-    monkeypatch.setenv("WAYNE_KEEP_NARROW", "1")
+    _lib.set_knob_all("keep_narrow", "1")
     b = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
-    monkeypatch.delenv("WAYNE_KEEP_NARROW")
+    _lib.set_knob_all("keep_narrow", None)
     np.testing.assert_array_equal(a, b)
     # ... and a bin that defies the estimate (the host's estimate does not know the transit-depth matrix: a depth of
     # -30 makes one bin 31 times brighter): the run flags itself and is repeated with k_narrow -- same frame as when
@@ -105,9 +126,9 @@ def test_thin_exposure_without_k_narrow_and_its_rerun(monkeypatch):
     c = np.stack([r[0] for r in pg.scanning_frame(record=rec, **kw2).reads])
     assert rec["counts"].max() > 60                                   # that bin went to the multinomial
     c2 = np.stack([r[0] for r in pg.scanning_frame(**kw2).reads])
-    monkeypatch.setenv("WAYNE_KEEP_NARROW", "1")
+    _lib.set_knob_all("keep_narrow", "1")
     d = np.stack([r[0] for r in pg.scanning_frame(**kw2).reads])
-    monkeypatch.delenv("WAYNE_KEEP_NARROW")
+    _lib.set_knob_all("keep_narrow", None)
     np.testing.assert_array_equal(c, d)
     np.testing.assert_array_equal(c2, d)
     assert rec["acc"].sum() > 0.4 * rec["counts"].sum()            # (a 64-px frame: much of the scan falls off it)
@@ -125,9 +146,9 @@ def test_fused_thin_path_equals_the_three_kernel_path(name, scale, monkeypatch):
     rec_f, rec_u = {}, {}
     a = np.stack([r[0] for r in pg.scanning_frame(record=rec_f, **kw).reads])
     a2 = np.stack([r[0] for r in pg.scanning_frame(**kw).reads])
-    monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+    _lib.set_knob_all("no_fuse", "1")
     b = np.stack([r[0] for r in pg.scanning_frame(record=rec_u, **kw).reads])
-    monkeypatch.delenv("WAYNE_NO_FUSE")
+    _lib.set_knob_all("no_fuse", None)
     assert rec_u["counts"].max() < 32 and rec_u["counts"].sum() > 1000
     for key in ("counts", "x", "y", "acc"):
         np.testing.assert_array_equal(rec_f[key], rec_u[key], err_msg=key)
@@ -158,9 +179,9 @@ def test_fused_thin_path_on_hostile_inputs(case, monkeypatch):
     pg = helpers.product_generator(v, 0)
     rec_f, rec_u = {}, {}
     a = np.stack([r[0] for r in pg.scanning_frame(record=rec_f, **kw).reads])
-    monkeypatch.setenv("WAYNE_NO_FUSE", "1")
+    _lib.set_knob_all("no_fuse", "1")
     b = np.stack([r[0] for r in pg.scanning_frame(record=rec_u, **kw).reads])
-    monkeypatch.delenv("WAYNE_NO_FUSE")
+    _lib.set_knob_all("no_fuse", None)
     for key in ("counts", "acc"):
         np.testing.assert_array_equal(rec_f[key], rec_u[key], err_msg=key)
     np.testing.assert_array_equal(a, b)
@@ -179,7 +200,6 @@ def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):
     # k_ramp loads a read's accumulators only inside the host's bound on where that read's electrons can land and
     # where a cosmic-ray segment bit is set; with the boxes off (every accumulator loaded, as in rounds 1-2) the
     # reads must be the same bit for bit -- cosmic rays, jitter, SSV, scan and stare, every rng mode
-    from wayne_amd import _lib
     v = helpers.make_visit(name, **kw_over)
     pg = helpers.product_generator(v, 0)
     kw = v.frame_kwargs(0)
@@ -189,9 +209,9 @@ def test_accumulator_boxes_lose_nothing(name, kw_over, monkeypatch):
     gen = pg.staring_frame if staring else pg.scanning_frame
     for mode in (_lib.RNG_SPLIT, _lib.RNG_PHILOX, _lib.RNG_REPLAY):
         a = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
-        monkeypatch.setenv("WAYNE_NO_ACC_BOX", "1")
+        _lib.set_knob_all("no_acc_box", "1")
         b = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
-        monkeypatch.delenv("WAYNE_NO_ACC_BOX")
+        _lib.set_knob_all("no_acc_box", None)
         np.testing.assert_array_equal(a, b, err_msg="%s rng_mode %d" % (name, mode))
         # and a second exposure in the same slot starts from clean accumulators and segment bits
         c = np.stack([r[0] for r in gen(rng_mode=mode, **kw).reads])
@@ -224,9 +244,9 @@ def test_accumulator_boxes_with_wavelengths_out_of_order(monkeypatch):
         a = ctx.synthesize(desc)
         _, _, _, acc_after = ctx.debug_fetch(0, acc=True)
         assert not acc_after.any(), "accumulators left dirty: %g electrons" % acc_after.sum()
-        monkeypatch.setenv("WAYNE_NO_ACC_BOX", "1")
+        _lib.set_knob_all("no_acc_box", "1")
         b = ctx.synthesize(desc)
-        monkeypatch.delenv("WAYNE_NO_ACC_BOX")
+        _lib.set_knob_all("no_acc_box", None)
         np.testing.assert_array_equal(a, b, err_msg="rng_mode %d" % mode)
         assert (a[-1] - a[0]).max() > 50              # the star is there
 

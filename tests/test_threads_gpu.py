@@ -113,3 +113,71 @@ def test_apply_psf_drop_in_from_several_python_threads():
         np.testing.assert_array_equal(got[s], serial[s], err_msg="call %d" % s)
     assert np.abs(serial[0] - serial[1]).max() > 0
     np.testing.assert_array_equal(serial[0], np.asarray(g["frame"], dtype=np.float64).ravel())   # and seed 0 is the reference's golden frame
+
+
+def test_a_thread_editing_the_environment_does_not_change_a_live_context():
+    # The knobs are frozen when the context is created (wayne_ctx_create reads WAYNE_* once; afterwards only
+    # wayne_ctx_set_knob changes one): a thread that rewrites every WAYNE_* variable while another thread's context
+    # uploads and runs exposures changes neither the frames NOR the launch shapes -- the knobs read back unchanged, and
+    # knobs that would show in the frame's bookkeeping (lane_reach = 5 forces second runs) stay without effect.
+    import os
+    v = helpers.make_visit("small256", n_exposures=4)
+    eng = engine.Engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
+    names = {"WAYNE_BATCH": "7", "WAYNE_THIN": "1", "WAYNE_NO_ACC_BOX": "1", "WAYNE_LANE_REACH": "5", "WAYNE_THROW_WGS": "33",
+             "WAYNE_TILE_INTS": "300", "WAYNE_KEEP_NARROW": "1", "WAYNE_NO_FUSE": "1", "WAYNE_STREAMS": "1"}
+    saved = {k: os.environ.get(k) for k in names}
+    try:
+        def frames():
+            out = []
+            for i in range(4):
+                pg = helpers.product_generator(v, i)
+                desc = pg.build_descriptor(eng, out_dtype=np.float32, **v.frame_kwargs(i))
+                eng.ctx.upload(i, desc)
+                eng.ctx.run(i)
+            eng.ctx.synchronize()
+            for i in range(4):
+                out.append(eng.ctx.download(i))
+            return np.stack(out)
+        want = frames()
+        knobs_before = {k: eng.ctx.get_knob(k) for k in _lib.KNOBS}
+        reruns_before = eng.ctx.reruns
+        stop = threading.Event()
+
+        def meddle():
+            flip = 0
+            while not stop.is_set():
+                for k, val in names.items():
+                    if flip & 1:
+                        os.environ[k] = val
+                    else:
+                        os.environ.pop(k, None)
+                flip += 1
+        t = threading.Thread(target=meddle)
+        t.start()
+        try:
+            for _ in range(5):
+                np.testing.assert_array_equal(frames(), want)
+        finally:
+            stop.set()
+            t.join(60)
+        assert {k: eng.ctx.get_knob(k) for k in _lib.KNOBS} == knobs_before
+        assert eng.ctx.reruns == reruns_before                  # lane_reach = 5 never reached the context
+        # ... while the explicit call does change the launch sequence (and still not the frames)
+        eng.ctx.set_knob("lane_reach", 5)
+        np.testing.assert_array_equal(frames(), want)
+        assert eng.ctx.reruns > reruns_before
+        # and a context created NOW does pick the variables up -- the one place they are read
+        os.environ["WAYNE_LANE_REACH"] = "5"
+        os.environ["WAYNE_BATCH"] = "7"
+        c2 = _lib.Context(0)
+        try:
+            assert c2.get_knob("lane_reach") == 5 and c2.get_knob("batch") == 7
+        finally:
+            c2.close()
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+        eng.close()

@@ -7,6 +7,7 @@ context is requested, this raises -- there is no CPU fallback.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -26,7 +27,7 @@ F_ADD_INITIAL_BIAS = 1 << 7
 F_OUT_F64 = 1 << 16
 F_EXACT_SAMPLERS = 1 << 17
 PROF_KERNELS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class WayneError(RuntimeError):
@@ -81,12 +82,15 @@ _vp = C.c_void_p
 SYMBOLS = {
     "wayne_abi_version": (C.c_int, []),
     "wayne_strerror": (C.c_char_p, [C.c_int]),
+    "wayne_build_flags": (C.c_char_p, []),
     "wayne_device_count": (C.c_int, []),
     "wayne_ctx_create": (_vp, [C.c_int, C.POINTER(C.c_int)]),
     "wayne_ctx_destroy": (None, [_vp]),
     "wayne_last_error": (C.c_char_p, [_vp]),
     "wayne_ctx_synchronize": (C.c_int, [_vp]),
     "wayne_ctx_stream": (_vp, [_vp]),
+    "wayne_ctx_set_knob": (C.c_int, [_vp, C.c_char_p, C.c_longlong]),
+    "wayne_ctx_get_knob": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     "wayne_psf_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                   C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _vp]),
     "wayne_psf_apply_ex": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
@@ -96,6 +100,7 @@ SYMBOLS = {
     "wayne_ctx_slots": (C.c_int, [_vp]),
     "wayne_exposure_upload": (C.c_int, [_vp, C.c_int, C.POINTER(ExposureDesc)]),
     "wayne_exposure_run": (C.c_int, [_vp, C.c_int]),
+    "wayne_exposure_run_checked": (C.c_int, [_vp, C.c_int]),
     "wayne_exposure_status": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "wayne_ctx_reruns": (C.c_ulonglong, [_vp]),
     "wayne_exposure_download": (C.c_int, [_vp, C.c_int, _vp]),
@@ -122,7 +127,7 @@ _lib = None
 
 def load():
     """Load (building first if needed) libwayne_hip.so.  Raises on failure."""
-    global _lib
+    global _lib, _lib_path
     if _lib is None:
         path = _build.LIB
         override = os.environ.get("WAYNE_HIP_LIB")
@@ -142,8 +147,23 @@ def load():
             f.argtypes = args
         if L.wayne_abi_version() != ABI_VERSION:
             raise ImportError("libwayne_hip.so ABI version mismatch")
+        flags = L.wayne_build_flags().decode().split()
+        if flags and os.environ.get("WAYNE_ALLOW_FLAGGED_LIB", "") != "1":
+            # a negative-control or timing build (its sources say "wrong frames"): never by accident
+            raise ImportError("%s was built with %s: not the product's library (tests and measurement scripts that mean "
+                              "to load it set WAYNE_ALLOW_FLAGGED_LIB=1)" % (path, " ".join(flags)))
         _lib = L
+        _lib_path = path
     return _lib
+
+
+_lib_path = None
+
+
+def library_info():
+    """(path, build flags) of the loaded library: what a measurement or a written file names as its producer."""
+    L = load()
+    return _lib_path or _build.LIB, L.wayne_build_flags().decode().strip()
 
 
 def ptr(a, ctype=None):
@@ -168,6 +188,32 @@ def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+KNOBS = ("tile_ints", "batch", "thin", "no_acc_box", "lane_reach", "throw_wgs", "keep_narrow", "no_fuse", "fork_narrow",
+         "streams", "upload_timing", "ramp_reads")
+_live_contexts = weakref.WeakSet()
+_knob_defaults = {}
+
+
+def set_knob_all(name, value):
+    """Set a tuning / test knob on every live context of this process and on those created later (None: back to the
+    library's own choice).  The explicit, per-process replacement of editing WAYNE_* environment variables under a
+    running context -- the library reads those once, in wayne_ctx_create."""
+    if name not in KNOBS:
+        raise KeyError("no knob named %r" % (name,))
+    if value is None:
+        _knob_defaults.pop(name, None)
+    else:
+        _knob_defaults[name] = int(value)
+    for c in list(_live_contexts):
+        if getattr(c, "_h", None):
+            c.set_knob(name, value)
+
+
+def reset_knobs_all():
+    for name in list(_knob_defaults):
+        set_knob_all(name, None)
+
+
 class Context(object):
     """One wayne_ctx: a GPU, a HIP stream and the HBM buffers of the path."""
 
@@ -182,6 +228,9 @@ class Context(object):
                                 "there is no CPU fallback" % (device, msg))
         self.device = device
         self._keep = []  # arrays referenced by descriptors during a call
+        _live_contexts.add(self)
+        for name, value in _knob_defaults.items():
+            self.set_knob(name, value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -205,7 +254,19 @@ class Context(object):
             raise WayneError(status, self._L.wayne_last_error(self._h).decode())
 
     def synchronize(self):
+        """Wait for everything enqueued and settle it: afterwards every slot's reads are complete (an exposure that
+        met a bin beyond its launch sequence's reach has been run a second time; see wayne_ctx_synchronize)."""
         self.check(self._L.wayne_ctx_synchronize(self._h))
+
+    def set_knob(self, name, value):
+        """Tuning / test knob of THIS context (value None or < 0: the library's own choice).  The environment
+        (WAYNE_<NAME>) is read once, at creation."""
+        self.check(self._L.wayne_ctx_set_knob(self._h, name.encode(), -1 if value is None else int(value)))
+
+    def get_knob(self, name):
+        v = C.c_longlong(0)
+        self.check(self._L.wayne_ctx_get_knob(self._h, name.encode(), C.byref(v)))
+        return None if v.value < 0 else int(v.value)
 
     @property
     def stream(self):
@@ -288,6 +349,10 @@ class Context(object):
 
     def run(self, slot):
         self.check(self._L.wayne_exposure_run(self._h, int(slot)))
+
+    def run_checked(self, slot):
+        """run + wait for the slot + settle it: its reads in HBM are complete on return."""
+        self.check(self._L.wayne_exposure_run_checked(self._h, int(slot)))
 
     def run_front(self, slot):
         self.check(self._L.wayne_exposure_run_front(self._h, int(slot)))

@@ -51,6 +51,43 @@ __device__ __forceinline__ double poly3(const double* c, double x) {
 }
 
 #if defined(__HIPCC__)
+// ---------------------------------------------------------------------------
+// bin-local coordinates of the production throwers (k_lane, k_throw's Philox mode, k_narrow)
+// ---------------------------------------------------------------------------
+// The reference adds an electron's offset to its bin's position in fp64 and truncates (pyparallel_menu.c:91-92).  The
+// production throwers draw the offset in float32; adding it to the bin's FRAME coordinate in float32 would round the
+// sum on the frame's scale (half an ulp at x >= 512: 3e-5 px, twice: in the cast of the position and in the add).
+// Instead the position is split in fp64, once per bin, into its pixel and the fraction inside it,
+//     pos = o + f,  o = floor(pos) (an integer),  f = (float)(pos - o) in [0, 1],
+// the float32 sum is f + offset -- rounded on the scale of the electron's DISTANCE from its bin (1e-7 px within a
+// pixel, 5e-7 px at 6 px, 4e-6 px at the 48 px a wide electron can reach) -- and the electron's pixel is
+//     o + floor(f + offset).
+// floor(), not the reference's truncation toward zero: the two differ only for sums in (-1, 0) of the frame coordinate,
+// which truncation sends to pixel 0 and floor to pixel -1 -- both outside the reference's strict bounds 0 < pos < n
+// (:93), so the kept electrons are the same.  A position that is not finite or beyond +-1e6 is not split (o = 0,
+// f = (float)pos): with any PSF of the instrument its electrons miss the frame either way.
+// oracle/split_oracle.c (so_bin_local) and oracle/psf_oracle.c are the same statement on the CPU.
+struct BinLocal { float fx, fy; int ox, oy; bool sane; };
+__device__ __forceinline__ BinLocal bin_local(double xd, double yd) {
+  BinLocal b;
+  const bool sane = fabs(xd) < 1e6 && fabs(yd) < 1e6;
+  b.sane = sane;
+  const double flx = sane ? floor(xd) : 0., fly = sane ? floor(yd) : 0.;
+  b.fx = (float)(xd - flx); b.fy = (float)(yd - fly);
+  b.ox = (int)flx; b.oy = (int)fly;
+  return b;
+}
+// (int)floorf(v) as ONE instruction (v_cvt_flr_i32_f32: floor, convert, saturate; NaN gives 0) -- the compiler's own
+// choice for the expression is v_floor_f32 + v_cvt_i32_f32
+__device__ __forceinline__ int floor_to_int(float v) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// o + floor(v) where nothing is known about v: no signed overflow when the conversion saturates (a dead lane's
+// -1e30f), and a NaN (a sigma that is not finite) goes off the frame like the reference's (int) of a NaN, not to o
+__device__ __forceinline__ int local_cell(int o, float v) { return (int)((unsigned)o + (unsigned)floor_to_int(fmaxf(v, -3e9f))); }
+
 // Reductions over the 16 lanes of a DPP row (butterfly of row rotations): every lane of the row gets the result.
 // All 64 lanes must be active.
 template <int CTRL> __device__ __forceinline__ int dpp_row(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }

@@ -3,6 +3,9 @@
 #include "common.h"
 #include "k_throw.h"
 
+#ifndef WAYNE_LANE_VARIANT
+#define WAYNE_LANE_VARIANT 1
+#endif
 namespace wayne {
 
 // ---------------------------------------------------------------------------
@@ -101,17 +104,15 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
     sgd = a.sigl[w];
   }
   if (!__syncthreads_or(n0 > 0)) return;
-  const bool act = n0 > 0;
-
-  float x = 0.f, y = 0.f, sg = 1.f;
-  int ic0 = 0, jc0 = 0;
-  if (act) {
-    x = (float)xd;
-    y = (float)yd;
-    sg = (float)sgd;
-    ic0 = (int)floorf(x);
-    jc0 = (int)floorf(y);
-  }
+  // the bin's position as pixel (ic0, jc0) + fraction (fx, fy) of it, split in fp64 (common.h, bin_local).  A bin whose
+  // position is not sane keeps its place in the group's count (so_group_pools) and draws nothing: within the window of
+  // +-6 px none of its electrons can reach the frame
+  const bool split = n0 > 0;
+  BinLocal bl{};
+  if (split) bl = bin_local(xd, yd);
+  const bool act = split && bl.sane;
+  const float sg = split ? (float)sgd : 1.f;
+  const int ic0 = bl.ox, jc0 = bl.oy;
   s_pool[tid] = 0;
   // workgroup tile = bounding box of its bins' windows, clipped to [1, N)
   if (tid == 0) { s_box[0] = 0x7FFFFFFF; s_box[1] = -0x7FFFFFFF; s_box[2] = 0x7FFFFFFF; s_box[3] = -0x7FFFFFFF; }
@@ -146,29 +147,30 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
   const int grp = tid & ~15, gl = tid & 15;
   bool pool = false;
   int X0 = 0, J0 = 0, res = 0;
-  float Z = 1.f, Rb = 0.f;
+  float Z = 1.f, Rb = 0.f, yl = 0.f;
   if (any_multi) {
     // does the lane's group pool its rows?  (so_group_pools)
-    const bool sane = act && fabsf(x) < 1e6f && fabsf(y) < 1e6f;
-    const int cnt = row16_sum(act ? 1 : 0), cnt_sane = row16_sum(sane ? 1 : 0), tot = row16_sum(act ? n0 : 0);
-    const int icmin = row16_mini(sane ? ic0 : 0x7FFFFFFF), icmax = row16_maxi(sane ? ic0 : -0x7FFFFFFF);
-    const int jcmin = row16_mini(sane ? jc0 : 0x7FFFFFFF);
-    const float ymin = row16_min(sane ? y : 3e38f), ymax = row16_max(sane ? y : -3e38f);
-    const float smin = row16_min(act ? sg : 3e38f), smax = row16_max(act ? sg : 0.f);
-    pool = cnt >= 2 && cnt_sane == cnt && icmax - icmin <= 2 && (ymax - ymin) <= 0.25f * smin && smax <= 1.1f * smin &&
-           tot <= 16777216;
+    const int cnt = row16_sum(split ? 1 : 0), cnt_sane = row16_sum(act ? 1 : 0), tot = row16_sum(split ? n0 : 0);
+    const int icmin = row16_mini(act ? ic0 : 0x7FFFFFFF), icmax = row16_maxi(act ? ic0 : -0x7FFFFFFF);
+    const int jcmin = row16_mini(act ? jc0 : 0x7FFFFFFF);
     X0 = icmin - kNarrowR;
     J0 = jcmin - kNarrowR;
+    // the bin's height above the bottom row of the group's window (6 .. 8 px when the group pools): one rounding of fp64
+    yl = act ? (float)(yd - (double)J0) : 0.f;
+    const float ymin = row16_min(act ? yl : 3e38f), ymax = row16_max(act ? yl : -3e38f);
+    const float smin = row16_min(split ? sg : 3e38f), smax = row16_max(split ? sg : 0.f);
+    pool = cnt >= 2 && cnt_sane == cnt && icmax - icmin <= 2 && (ymax - ymin) <= 0.25f * smin && smax <= 1.1f * smin &&
+           tot <= 16777216;
 
     float qh[kPoolRows];
 #pragma unroll
     for (int t = 0; t < kPoolRows; ++t) qh[t] = 3e38f;
     if (act && pool) {
       // the bin's masses on the rows [J0 + t, J0 + t + 1): differences of two tails on the same side of y
-      float Ep = (float)J0 - y, Ap = upper_tail<M>(fabsf(Ep) * inv_s), S = 0.f;
+      float Ep = -yl, Ap = upper_tail<M>(fabsf(Ep) * inv_s), S = 0.f;
 #pragma unroll
       for (int t = 0; t < kPoolRows; ++t) {
-        const float E = (float)(J0 + t + 1) - y, A = upper_tail<M>(fabsf(E) * inv_s);
+        const float E = (float)(t + 1) - yl, A = upper_tail<M>(fabsf(E) * inv_s);
         const float m = (Ep >= 0.f) ? Ap - A : ((E <= 0.f) ? A - Ap : 1.f - Ap - A);
         qh[t] = fmaxf(m, 0.f);
         S += qh[t];
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       // the same for every column of the bin (x and y are independent), so it is computed once, here, with the
       // not-yet-visited mass taken as the sum of the two remaining tails (a running 1 - sum would lose the far rows
       // to cancellation)
-      const float f = y - (float)jc0;
+      const float f = bl.fy;
       float up = upper_tail<M>((1.f - f) * inv_s), lo = upper_tail<M>(f * inv_s);   // mass above / below the centre row
       s_q[0][tid] = 1.f - up - lo;
       for (int c = 1; c < kNarrowCells; ++c) {
@@ -232,9 +234,9 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
 
   if (any_multi) {
     SeededStream rng(a.seed, STAGE_NARROW, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
-    const float fx = x - (float)ic0;
+    const float fx = bl.fx;
     float up = upper_tail<M>((1.f - fx) * inv_s), lo = upper_tail<M>(fx * inv_s);
-    float n_rem = (float)max(n0, 0);
+    float n_rem = act ? (float)n0 : 0.f;
     // c = -1: a pooling bin thins its electrons (common ~ Binomial(n, Z)); c >= 0: the column chain
     for (int c = __any(pool) ? -1 : 0; c < kNarrowCells; ++c) {
       if (!__any(n_rem > 0.f)) break;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
           rng.next2(wa, wb);
           rng.next2(va, vb);
           const float Rs = __builtin_amdgcn_sqrtf(cs * __builtin_amdgcn_logf(u01f(wb)));
-          const int col = min(max((int)floorf(fmaf(__builtin_amdgcn_cosf(rev12(wa)), Rs, x)), ic0 - kNarrowR), ic0 + kNarrowR);
+          const int col = ic0 + min(max(floor_to_int(fmaf(__builtin_amdgcn_cosf(rev12(wa)), Rs, fx)), -kNarrowR), kNarrowR);
           const float u = u01f(va) * Rb;
           int row = 0;
 #pragma unroll
@@ -400,7 +402,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   // again in the throw loop: four memory latencies in a row per workgroup of a kernel whose launch-independent cost
   // was 30 us (scripts/thrower_vs_electrons.py)
   int n_one = 0, nw_one = 0;
-  float x_one = 0.f, y_one = 0.f;
+  BinLocal bl_one{};                      // the bin's position as pixel + fraction (common.h, bin_local)
   float ch = 0.f, cl = 0.f, sh = 0.f, sl = 0.f;
   if (inw) {
     double sh_d = a.sigh[w], sl_d = a.sigl[w];
@@ -409,7 +411,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
       n_one = a.nlane[kw0];
       const double xd = a.xpos[kw0], yd = a.ypos[kw0];
       nw_one = a.nwide[kw0];
-      x_one = (float)xd; y_one = (float)yd;
+      bl_one = bin_local(xd, yd);
       nw_one = min(max(nw_one, 0), n_one);
     }
     sh = (float)sh_d; sl = (float)sl_d;
@@ -438,27 +440,36 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   for (int k = k0; k < k1; ++k) {
     const size_t kw = (size_t)k * a.W + (inw ? w : 0);
     int n = 0, nw = 0;
-    float x = 0.f, y = 0.f;
+    int ic = 0, jc = 0;
+    bool sane = false;
     if (FUSED) {
       // every bin of the chunk, populated or not, and both sigmas (the counts are not drawn twice for a box); the
       // positions without their division, good to 1e-10 px, and the box a pixel larger all round
       if (inw) {
+        float x = 0.f, y = 0.f;
         bin_position_bound(p, f_wl, p.tr + kTrStride * (size_t)k, p.x_ref[k], p.y_ref[k], &x, &y);
+        sane = fabsf(x) < 1e6f && fabsf(y) < 1e6f;
+        ic = (int)floorf(x); jc = (int)floorf(y);
         n = 2; nw = 1;
       }
     } else if (!BATCH) {
       n = n_one;
-      if (n > 0) { x = x_one; y = y_one; nw = nw_one; }
+      if (n > 0) { sane = bl_one.sane; ic = bl_one.ox; jc = bl_one.oy; nw = nw_one; }
     } else if (inw) {
       n = a.nlane[kw];
-      if (n > 0) { x = (float)a.xpos[kw]; y = (float)a.ypos[kw]; nw = min(max(a.nwide[kw], 0), n); }
+      if (n > 0) {
+        const BinLocal b = bin_local(a.xpos[kw], a.ypos[kw]);
+        sane = b.sane; ic = b.ox; jc = b.oy;
+        nw = min(max(a.nwide[kw], 0), n);
+      }
     }
     if (n > 0) {
       any = true;
+      // (each sigma the bin uses on its own: fmaxf would step over a NaN)
+      const bool sig_ok = (nw > 0 ? (sh >= 0.f && sh < 1e6f) : true) && (n > nw ? (sl >= 0.f && sl < 1e6f) : true);
       const float smax = fmaxf(nw > 0 ? sh : 0.f, n > nw ? sl : 0.f);
-      float r = (smax >= 0.f && smax < 1e6f) ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
-      if (fabsf(x) < 1e6f && fabsf(y) < 1e6f) {
-        const int ic = (int)floorf(x), jc = (int)floorf(y);
+      float r = sig_ok ? 6.9f * smax + 1.f : __int_as_float(0x7F800000);
+      if (sane) {
         constexpr int spare = FUSED ? 1 : 0;
         x_lo = min(x_lo, ic - spare); x_hi = max(x_hi, ic + spare); y_lo = min(y_lo, jc - spare); y_hi = max(y_hi, jc + spare);
       } else {
@@ -515,7 +526,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   for (int k = k0; k < k1; ++k) {
   const size_t kw = (size_t)k * a.W + (inw ? w : 0);
   int n = 0, nw = 0;
-  float x = -1e30f, y = -1e30f;
+  BinLocal bl{};
   if (FUSED) {
     if (inw) {
       const BinPlan b = plan_bin(p, k, w, f_wl, f_flux, f_sens, f_dlam, f_ratio, f_sigl, p.tr + kTrStride * (size_t)k, p.x_ref[k],
@@ -525,7 +536,7 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
       if (b.narrow > 0u || b.rest > 0u) atomicOr(p.status, 2);   // a bin for k_narrow / k_throw after all: the host runs the exposure again
       n = (int)b.lane;
       f_electrons += b.lane;
-      if (n > 0) { x = (float)b.xs; y = (float)b.ys; nw = min(max(b.nwide, 0), n); }
+      if (n > 0) { bl = bin_local(b.xs, b.ys); nw = min(max(b.nwide, 0), n); }
     }
   } else if (!BATCH) {
     n = n_one;
@@ -535,12 +546,15 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   if (!__syncthreads_or(n > 0)) continue;                    // (also: the tile is clean and this round's list counter is 0)
   const SubInfo si = FUSED ? s_sub[k - k0] : a.sub[__builtin_amdgcn_readfirstlane(k)];     // (a scalar load: k is the workgroup's)
   if (!FUSED && !BATCH) {
-    if (n > 0) { x = x_one; y = y_one; nw = nw_one; }
+    if (n > 0) { bl = bl_one; nw = nw_one; }
   } else if (!FUSED && n > 0) {
-    x = (float)a.xpos[kw];
-    y = (float)a.ypos[kw];
+    bl = bin_local(a.xpos[kw], a.ypos[kw]);
     nw = min(max(a.nwide[kw], 0), n);
   }
+  // the electron's pixel is (ox, oy) + floor((fx, fy) + its offset): see bin_local.  A lane without electrons in this
+  // sub-sample throws at -1e30 (its stream still advances with the wave's)
+  const float x = n > 0 ? bl.fx : -1e30f, y = n > 0 ? bl.fy : -1e30f;
+  const int ox = bl.ox, oy = bl.oy;
 
   // Electron j of the bin takes WORD j of the bin's stream (a pair of the stream serves two electrons); the first nw
   // take sigma_h.  One 32-bit word per electron:
@@ -558,10 +572,11 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
   // hold nearly the same number of electrons), then the tail, where the stream still advances in every lane and only
   // the deposit is suppressed for the lanes that are done.  A wave with thin, unsplit bins selects sigma per electron.
   const int tw4 = tw * 4;
-  const int origin = -(ty0 * tw4 + tx0 * 4);                 // tile[(yi - ty0) * tw + (xi - tx0)] as a byte offset from yi, xi
+  // tile[(oy + j - ty0) * tw + (ox + i - tx0)] as a byte offset from an electron's pixel offsets (i, j) from its bin's pixel
+  const int origin = (oy - ty0) * tw4 + (ox - tx0) * 4;
   // (c = -2 ln2 sigma^2, c16 = -16 c: (R sigma)^2 = c log2 u = c (log2(h + 1/2) - 16) as one fma)
   uint32_t refine = 0u;
-  auto draw = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py, int& xi, int& yi) {
+  auto draw = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py, float& vx, float& vy) {
     // angle in [1, 2) revolutions = the word's high 23 bits as a mantissa (one v_alignbit_b32).  Its 7 lowest bits
     // are the radius half-word's 7 highest: given the radius, the angle still runs over 65536 equally spaced
     // directions -- offset by a fraction of their spacing that depends on the radius
@@ -573,22 +588,39 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
       r2 = fmaf(c, __builtin_amdgcn_logf((float)(refine >> 15) + 0.5f), -33.f * c);
     }
     const float Rs = __builtin_amdgcn_sqrtf(r2);
-    xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, px);      // C truncation toward zero (:91-92)
-    yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
+    vx = fmaf(__builtin_amdgcn_cosf(rev), Rs, px);            // offset + the bin's fraction of a pixel (:91-92; bin_local)
+    vy = fmaf(__builtin_amdgcn_sinf(rev), Rs, py);
   };
   // (test-free tile) every live electron is inside the tile and on the frame
   auto throw_sure = [&](SeededStream& rng, uint32_t wd, float c, float c16, bool live) {
-    int xi, yi;
-    draw(rng, wd, c, c16, x, y, xi, yi);
-    // byte address = yi * tw4 + (xi * 4 + origin): v_lshl_add_u32, v_mad_u32_u24 (the compiler's own choice is a multiply,
-    // a shift and a three-operand add)
-    int addr;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(tw4), "v"((xi << 2) + origin));
+    float vx, vy;
+    draw(rng, wd, c, c16, x, y, vx, vy);
+    // byte address = j * tw4 + (i * 4 + origin), (i, j) = floor(vx, vy) within +-kLaneReachMax: v_cvt_flr_i32_f32 twice,
+    // v_lshl_add_u32, v_mad_i32_i24 (the compiler's own choice is a floor, a convert, a multiply, a shift and a
+    // three-operand add)
+    // (one block: left to itself the compiler takes `origin` apart again and adds its two halves per electron)
+    int addr, j;
+#if WAYNE_LANE_VARIANT == 3
+    // separate statements, origin opaque
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(vx));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(j) : "v"(vy));
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(i) : "v"(i), "v"(origin));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr) : "v"(j), "s"(tw4), "v"(i));
+#elif WAYNE_LANE_VARIANT == 4
+    // truncating converts (WRONG cells for negative offsets: a timing build) to price v_cvt_flr against v_cvt_i32
+    asm("v_cvt_i32_f32 %0, %2\n\tv_cvt_i32_f32 %1, %3\n\tv_lshl_add_u32 %0, %0, 2, %4\n\tv_mad_i32_i24 %0, %1, %5, %0"
+        : "=&v"(addr), "=&v"(j) : "v"(vx), "v"(vy), "v"(origin), "s"(tw4));
+#else
+    asm("v_cvt_flr_i32_f32 %0, %2\n\tv_cvt_flr_i32_f32 %1, %3\n\tv_lshl_add_u32 %0, %0, 2, %4\n\tv_mad_i32_i24 %0, %1, %5, %0"
+        : "=&v"(addr), "=&v"(j) : "v"(vx), "v"(vy), "v"(origin), "s"(tw4));
+#endif
     if (live) tile_add(addr);
   };
   auto throw_one = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py) {
-    int xi, yi;
-    draw(rng, wd, c, c16, px, py, xi, yi);
+    float vx, vy;
+    draw(rng, wd, c, c16, px, py, vx, vy);
+    const int xi = local_cell(ox, vx), yi = local_cell(oy, vy);
     const int lx = xi - tx0, ly = yi - ty0;
     if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
       tile_add(__umul24(ly, tw4) + (lx << 2));

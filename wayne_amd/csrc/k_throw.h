@@ -112,17 +112,18 @@ __device__ __forceinline__ double flat_value(const ThrowArgs& a, const SubInfo& 
 
 // What the per-electron loop needs of a bin, as one 32-byte record (two LDS reads)
 struct ThrowBin {
-  float x, y;             // trace position (frame coordinates)
+  float x, y;             // trace position: the fraction of its pixel (common.h, bin_local) ...
   float ch, cl;           // -2 ln2 sigma_h^2, -2 ln2 sigma_l^2
   uint32_t bin_end;       // first electron (sub-sample numbering) after this bin
   uint32_t wide_end;      // first electron of the bin that takes sigma_l
-  uint32_t pad_[2];
+  int ox, oy;             // ... and that pixel (frame coordinates)
 };
 
 __device__ __forceinline__ ThrowBin load_throw_bin(const uint32_t* P, const int32_t* NW, const double* XP, const double* YP,
                                                    const double* sigl, const double* sigh, int b) {
   ThrowBin r;
-  r.x = (float)XP[b]; r.y = (float)YP[b];
+  const BinLocal bl = bin_local(XP[b], YP[b]);
+  r.x = bl.fx; r.y = bl.fy; r.ox = bl.ox; r.oy = bl.oy;
   const float sh = (float)sigh[b], sl = (float)sigl[b];
   r.ch = (-1.3862943611198906f * sh) * sh;
   r.cl = (-1.3862943611198906f * sl) * sl;
@@ -130,7 +131,6 @@ __device__ __forceinline__ ThrowBin load_throw_bin(const uint32_t* P, const int3
   r.bin_end = P[b + 1];
   // N = (int)(counts * ratio) may exceed the bin's count (ratio > 1: every electron wide, pyparallel_menu.c:89-98)
   r.wide_end = start + min((uint32_t)max(NW[b], 0), r.bin_end - start);
-  r.pad_[0] = r.pad_[1] = 0;
   return r;
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
       // compare.  The body of the event branch runs when some lane of the wave needs it (~1 in 6 iterations
       // at ~350 wide electrons per bin) and is two LDS reads.
       ThrowBin cur;
-      cur.x = cur.y = -1e30f; cur.ch = cur.cl = 0.f; cur.bin_end = bin_start; cur.wide_end = bin_start;
+      cur.x = cur.y = -1e30f; cur.ox = cur.oy = 0; cur.ch = cur.cl = 0.f; cur.bin_end = bin_start; cur.wide_end = bin_start;
       int bi = b - 1;                       // bin index of `cur`: the first event loads bin b
       for (uint64_t u = ub; u < ue; ++u) {
         const uint32_t e0 = (uint32_t)(u * kThrowBlock);
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
         SeededStream rng(a.seed, STAGE_THROW, (uint32_t)u, (uint32_t)k + a.subsample0, a.exposure);
         uint32_t stop = 0;                  // force the event branch at j = 0
         float c = 0.f, x = -1e30f, y = -1e30f;
+        uint32_t oxl = 0u, oyl = 0u;        // the bin's pixel relative to the tile's corner
         for (uint32_t j = 0; j < kThrowBlock; ++j) {
           if (j >= stop) {
             const uint32_t e = e0 + j;
@@ -324,7 +325,10 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
               // the first n_wide electrons of a bin take the wide gaussian (pyparallel_menu.c:89-98)
               const bool wide = e < cur.wide_end;
               c = wide ? cur.ch : cur.cl;
-              x = cur.x; y = cur.y;
+              x = cur.x; y = cur.y; oxl = (uint32_t)cur.ox - (uint32_t)tx0; oyl = (uint32_t)cur.oy - (uint32_t)ty0;
+              // a sigma that is not finite (or whose square is not): the reference's (int) of a non-finite position
+              // keeps none of these electrons (:91-93) -- settled here, once per segment, so that the sums below are finite
+              if (!(c > -3e38f)) { x = y = -1e30f; c = 0.f; }
               const uint32_t seg_end = wide ? cur.wide_end : cur.bin_end;
               stop = min(seg_end - e0, limit);
               if (e >= cur.bin_end) { x = y = -1e30f; c = 0.f; stop = 0xFFFFFFFFu; }   // inconsistent prefix: nothing to throw
@@ -336,15 +340,20 @@ __global__ __launch_bounds__(kThrowThreads) void k_throw(ThrowArgs a) {
           // sin / cos take revolutions, and any window of length 1 will do: [1, 2) straight from the bits
           const float rev = rev12(wa);
           const float Rs = __builtin_amdgcn_sqrtf(c * __builtin_amdgcn_logf(u01f(wb)));
-          const int xi = (int)fmaf(__builtin_amdgcn_cosf(rev), Rs, x);   // C truncation toward zero (:91-92)
-          const int yi = (int)fmaf(__builtin_amdgcn_sinf(rev), Rs, y);
-          const int lx = xi - tx0, ly = yi - ty0;
+          // the bin's pixel + floor(offset + the bin's fraction of it) (:91-92; common.h, bin_local), counted from the
+          // tile's corner (unsigned: a dead lane's -1e30 saturates the conversion and wraps to a cell off every frame)
+          uint32_t lx, ly;
+          asm("v_cvt_flr_i32_f32 %0, %2\n\tv_cvt_flr_i32_f32 %1, %3\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5"
+              : "=&v"(lx), "=&v"(ly)
+              : "v"(fmaf(__builtin_amdgcn_cosf(rev), Rs, x)), "v"(fmaf(__builtin_amdgcn_sinf(rev), Rs, y)), "v"(oxl), "v"(oyl));
           // the tile lies inside [1, N) x [1, N), so this one test implies the
           // reference's 0 < pos < n bounds (:93) on the fast path
-          if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+          if (lx < (uint32_t)tw && ly < (uint32_t)th) {
             atomicAdd(&tile[__umul24(ly, tw) + lx], 1);   // tile area < 2^14: 24-bit multiply-add
-          else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)
-            deposit_global<FLUSH>(a, si, xi, yi, 1);
+          } else {
+            const int xi = (int)(lx + (uint32_t)tx0), yi = (int)(ly + (uint32_t)ty0);
+            if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) deposit_global<FLUSH>(a, si, xi, yi, 1);
+          }
         }
       }
     } else {

@@ -66,6 +66,7 @@ struct Slot {
   PrepArgs last_prep{};       // ... and k_prep_sub's arguments of that run
   int last_chunks = 0;
   bool force_throw = false;   // the last run met a bin beyond a lane's reach: run with k_throw (set by check_status)
+  bool ran = false;           // a whole run was enqueued whose status word nobody has looked at yet (settle)
   wayne_exposure_desc d{};  // host copy (pointers are NOT valid after upload)
   int W = 0, K = 0, R = 0;
   bool has_depth = false, has_replay_seed = false, has_lc = false, has_lc_hidden = false;
@@ -145,6 +146,35 @@ constexpr int kSlots = 256;
 
 constexpr int kStreams = 2;   // exposures in even / odd slots run on different HIP streams
 
+// Tuning and test knobs of a context.  Each is read ONCE from the environment (WAYNE_<NAME>) when the context is
+// created; afterwards only wayne_ctx_set_knob changes it -- no entry point looks at the environment of a live context,
+// so a thread that edits the environment cannot change what another thread's context launches (and getenv never races
+// a setenv).  -1 = not set: the library's own choice.
+struct Knobs {
+  long long tile_ints = -1;      // LDS ints of a k_throw tile (thrower_lds_ints)
+  long long batch = -1;          // sub-samples a k_lane workgroup takes (plan::lane_batches)
+  long long thin = -1;           // k_lane's first-touch flush list on (1) / off (0)
+  long long no_acc_box = -1;     // 1: k_ramp loads every accumulator (no boxes)
+  long long lane_reach = -1;     // electrons a lane takes in an exposure launched without k_throw (lowers kLaneReach: exercises the re-run)
+  long long throw_wgs = -1;      // k_throw workgroups per launch
+  long long keep_narrow = -1;    // 1: k_narrow is launched even when no bin is expected to qualify
+  long long no_fuse = -1;        // 1: never k_lane_fused
+  long long fork_narrow = -1;    // 1: k_narrow on a side stream beside k_lane
+  long long streams = -1;        // 1: every slot on one stream
+  long long upload_timing = -1;  // 1: wayne_ctx_destroy prints the host time of wayne_exposure_upload by part
+  long long ramp_reads = -1;     // TIMING BUILDS (-DWAYNE_TIMING_KNOBS) only: k_ramp works through the first n reads
+};
+struct KnobName { const char* name; const char* env; long long Knobs::*field; };
+const KnobName kKnobNames[] = {
+    {"tile_ints", "WAYNE_TILE_INTS", &Knobs::tile_ints},       {"batch", "WAYNE_BATCH", &Knobs::batch},
+    {"thin", "WAYNE_THIN", &Knobs::thin},                      {"no_acc_box", "WAYNE_NO_ACC_BOX", &Knobs::no_acc_box},
+    {"lane_reach", "WAYNE_LANE_REACH", &Knobs::lane_reach},    {"throw_wgs", "WAYNE_THROW_WGS", &Knobs::throw_wgs},
+    {"keep_narrow", "WAYNE_KEEP_NARROW", &Knobs::keep_narrow}, {"no_fuse", "WAYNE_NO_FUSE", &Knobs::no_fuse},
+    {"fork_narrow", "WAYNE_FORK_NARROW", &Knobs::fork_narrow}, {"streams", "WAYNE_STREAMS", &Knobs::streams},
+    {"upload_timing", "WAYNE_UPLOAD_TIMING", &Knobs::upload_timing}, {"ramp_reads", "WAYNE_RAMP_READS", &Knobs::ramp_reads},
+};
+constexpr size_t kMiscBytes = 64;   // status block of a slot: [0] electrons (u64), [8] status (int); k_prep_wl clears all of it
+
 constexpr size_t kCounterBytes = (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long);
 
 struct wayne_ctx {
@@ -161,7 +191,10 @@ struct wayne_ctx {
   // then both copy and share the PCIe link: 640 exposures/s -- instead of one copying while the other computes (810).
   hipEvent_t ev_kdone[kStreams] = {nullptr, nullptr};
   bool kdone_valid[kStreams] = {false, false};
-  int n_streams = kStreams;              // WAYNE_STREAMS=1 serialises all exposures on one stream
+  int n_streams = kStreams;              // knob `streams` = 1 serialises all exposures on one stream
+  Knobs knobs;                           // frozen at creation (see Knobs)
+  DevBuf status_all;                     // kSlots status blocks of kMiscBytes (Slot::misc views into it): ONE copy brings all of them back
+  char* status_host = nullptr;           // its pinned host mirror (settle)
   std::string err;
   // grism
   bool have_grism = false;
@@ -353,9 +386,9 @@ std::vector<float> embed(const float* src, int N, int S, float fill) {
 
 // LDS ints of a thrower workgroup's tile.  A workgroup covers 1/splits of a sub-sample's electrons,
 // i.e. a slice of the trace (first-order spectra are < ~260 px long) plus the PSF margin on each
-// side, by (margin on each side + the trace's small tilt) rows.  WAYNE_TILE_INTS overrides.
-int thrower_lds_ints(const wayne_ctx*, int splits, int margin) {
-  if (const char* e = std::getenv("WAYNE_TILE_INTS")) return std::min(std::max(std::atoi(e), 256), 40000);
+// side, by (margin on each side + the trace's small tilt) rows.  Knob `tile_ints` overrides.
+int thrower_lds_ints(const wayne_ctx* c, int splits, int margin) {
+  if (c->knobs.tile_ints >= 0) return (int)std::min<long long>(std::max<long long>(c->knobs.tile_ints, 256), 40000);
   const long long w = 260 / std::max(splits, 1) + 2 * margin + 4, h = 2 * margin + 12;
   return (int)std::min<long long>(std::max<long long>(w * h, 1024), 12288);   // <= 48 KiB
 }
@@ -499,12 +532,17 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
   // k_narrow beside k_lane on a side stream: worth 10 % when the thrower still had idle issue slots
   // (round 1); now each of the two fills the VALU by itself and running them one after the other is as fast
   // (1860 vs 1846 exposures/s on one stream, 2212 vs 2224 on two) -- off unless WAYNE_FORK_NARROW=1
-  {
-    const char* e = std::getenv("WAYNE_FORK_NARROW");
-    c->fork_narrow = c->fork_narrow && e && std::atoi(e) != 0;
-  }
-  if (const char* e = std::getenv("WAYNE_STREAMS")) c->n_streams = std::min(std::max(std::atoi(e), 1), kStreams);
-  if (c->counters.reserve(kCounterBytes) != hipSuccess || hipMemset(c->counters.p, 0, kCounterBytes) != hipSuccess) {
+  // the one place the environment is read (see Knobs)
+  for (const KnobName& k : kKnobNames)
+    if (const char* e = std::getenv(k.env)) c->knobs.*(k.field) = std::max(std::atoll(e), -1LL);
+  c->fork_narrow = c->fork_narrow && c->knobs.fork_narrow > 0;
+  if (c->knobs.streams >= 0) c->n_streams = (int)std::min<long long>(std::max<long long>(c->knobs.streams, 1), kStreams);
+  if (c->counters.reserve(kCounterBytes) != hipSuccess || hipMemset(c->counters.p, 0, kCounterBytes) != hipSuccess ||
+      c->status_all.reserve(kSlots * kMiscBytes) != hipSuccess || hipMemset(c->status_all.p, 0, kSlots * kMiscBytes) != hipSuccess ||
+      hipHostMalloc((void**)&c->status_host, kSlots * kMiscBytes, hipHostMallocDefault) != hipSuccess) {
+    c->counters.release();
+    c->status_all.release();
+    if (c->status_host) (void)hipHostFree(c->status_host);
     for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(c->streams[i]);
     delete c;
     set(WAYNE_E_NOMEM);
@@ -516,7 +554,7 @@ wayne_ctx* wayne_ctx_create(int device, int* status) {
 
 void wayne_ctx_destroy(wayne_ctx* c) {
   if (!c) return;
-  if (std::getenv("WAYNE_UPLOAD_TIMING") && c->up_calls > 0)
+  if (c->knobs.upload_timing > 0 && c->up_calls > 0)
     std::fprintf(stderr, "wayne_exposure_upload: %ld calls; us per call: staging + copies %.1f, electron estimate %.1f, "
                  "accumulator boxes %.1f, sky tables %.1f\n", c->up_calls, c->up_us[0] / c->up_calls,
                  c->up_us[1] / c->up_calls, c->up_us[2] / c->up_calls, c->up_us[3] / c->up_calls);
@@ -525,7 +563,8 @@ void wayne_ctx_destroy(wayne_ctx* c) {
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& s : c->slots) s.release();
-  for (DevBuf* b : {&c->counters, &c->sens_wl, &c->sens_val, &c->pfl, &c->sky, &c->dark_sci, &c->dark_err, &c->zero_read,
+  if (c->status_host) (void)hipHostFree(c->status_host);
+  for (DevBuf* b : {&c->counters, &c->status_all, &c->sens_wl, &c->sens_val, &c->pfl, &c->sky, &c->dark_sci, &c->dark_err, &c->zero_read,
                     &c->pa_prefix, &c->pa_nwide, &c->pa_nsplit, &c->pa_nlane, &c->pa_x, &c->pa_y, &c->pa_sl, &c->pa_sh, &c->pa_sub,
                     &c->pa_frame, &c->pa_in})
     b->release();
@@ -543,9 +582,104 @@ void wayne_ctx_destroy(wayne_ctx* c) {
 
 const char* wayne_last_error(const wayne_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// Every slot whose last whole run nobody has looked at yet: read its status word (all of them in ONE copy) and run a
+// slot that met a bin beyond its launch sequence's reach a second time, with the general sequence.  Called with all
+// streams idle; leaves them idle.  An overflow (bit 0) is reported after the other slots have been settled.
+static int settle(wayne_ctx* c) {
+  int err = WAYNE_OK;
+  for (int pass = 0; pass < 2; ++pass) {
+    int hi = -1;
+    for (int i = 0; i < kSlots; ++i)
+      if (c->slots[i].ran && c->slots[i].uploaded) hi = i;
+    if (hi < 0) break;
+    HIP_TRY(c, hipMemcpy(c->status_host, c->status_all.p, (size_t)(hi + 1) * kMiscBytes, hipMemcpyDeviceToHost));
+    bool again = false;
+    for (int i = 0; i <= hi; ++i) {
+      Slot& s = c->slots[i];
+      if (!s.ran || !s.uploaded) continue;
+      s.ran = false;
+      const int status = ((const Slot::Misc*)(c->status_host + (size_t)i * kMiscBytes))->status;
+      if (status & 1) {
+        err = fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
+      } else if ((status & 2) && pass == 0) {
+        s.force_throw = true;
+        c->reruns += 1;
+        int rc = wayne_exposure_run(c, i);
+        if (rc) return rc;
+        again = true;
+      }
+    }
+    if (!again) break;
+    int rc = sync_all(c);
+    if (rc) return rc;
+  }
+  return err;
+}
+
 int wayne_ctx_synchronize(wayne_ctx* c) {
   if (!c) return WAYNE_E_INVALID;
-  return sync_all(c);
+  (void)hipSetDevice(c->device);
+  int rc = sync_all(c);
+  if (rc) return rc;
+  return settle(c);
+}
+
+int wayne_ctx_set_knob(wayne_ctx* c, const char* name, long long value) {
+  if (!c || !name) return WAYNE_E_INVALID;
+  for (const KnobName& k : kKnobNames)
+    if (std::strcmp(name, k.name) == 0) {
+      if (k.field == &Knobs::streams || k.field == &Knobs::fork_narrow) {
+        // (these two shape the context itself: no exposure may be in flight while they change)
+        int rc = sync_all(c);
+        if (rc) return rc;
+      }
+      c->knobs.*(k.field) = std::max(value, -1LL);
+      if (k.field == &Knobs::streams)
+        c->n_streams = value < 0 ? kStreams : (int)std::min<long long>(std::max<long long>(value, 1), kStreams);
+      if (k.field == &Knobs::fork_narrow) c->fork_narrow = value > 0 && c->side[0] && c->side[1] && c->ev_fork[0] && c->ev_fork[1] && c->ev_join[0] && c->ev_join[1];
+      return WAYNE_OK;
+    }
+  return fail(c, WAYNE_E_INVALID, std::string("set_knob: no knob named ") + name);
+}
+
+int wayne_ctx_get_knob(const wayne_ctx* c, const char* name, long long* value) {
+  if (!c || !name || !value) return WAYNE_E_INVALID;
+  for (const KnobName& k : kKnobNames)
+    if (std::strcmp(name, k.name) == 0) { *value = c->knobs.*(k.field); return WAYNE_OK; }
+  return WAYNE_E_INVALID;
+}
+
+const char* wayne_build_flags(void) {
+  // every compile-time switch that changes what the library computes or launches; the shipped build has none
+  return ""
+#ifdef WAYNE_NEGCTL_SKY_RUNAWAY
+         " WAYNE_NEGCTL_SKY_RUNAWAY"
+#endif
+#ifdef WAYNE_NEGCTL_ADDITIVE_KEY
+         " WAYNE_NEGCTL_ADDITIVE_KEY"
+#endif
+#ifdef WAYNE_TIMING_KNOBS
+         " WAYNE_TIMING_KNOBS"
+#endif
+#ifdef WAYNE_TIMING_COLPOOL
+         " WAYNE_TIMING_COLPOOL"
+#endif
+#ifdef WAYNE_TIMING_RAMP_NO_DARK
+         " WAYNE_TIMING_RAMP_NO_DARK"
+#endif
+#ifdef WAYNE_TIMING_RAMP_NO_ONCE
+         " WAYNE_TIMING_RAMP_NO_ONCE"
+#endif
+#if WAYNE_PREP_THREADS != 512
+         " WAYNE_PREP_THREADS"
+#endif
+#if WAYNE_RAMP_THREADS != 1024
+         " WAYNE_RAMP_THREADS"
+#endif
+#if WAYNE_RAMP_PF != 2
+         " WAYNE_RAMP_PF"
+#endif
+      ;
 }
 
 void* wayne_ctx_stream(wayne_ctx* c) { return c ? (void*)c->streams[0] : nullptr; }
@@ -877,7 +1011,8 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     HIP_TRY(c, s.chunk_total.reserve((size_t)K * n_chunks * sizeof(uint32_t)));
     HIP_TRY(c, s.chunk_box.reserve((size_t)K * n_chunks * 4 * sizeof(double)));
   }
-  HIP_TRY(c, s.misc.reserve(64));
+  s.misc.view((char*)c->status_all.p + (size_t)slot * kMiscBytes);
+  s.ran = false;
   const size_t SS = (size_t)c->S * c->S;
   const size_t acc_bytes = (size_t)R * SS * sizeof(long long);
   if (s.acc.cap < acc_bytes) s.acc_init = false;
@@ -909,12 +1044,12 @@ int wayne_exposure_upload(wayne_ctx* c, int slot, const wayne_exposure_desc* d) 
     // k_lane's batches and its first-touch flush list (plan::lane_batches)
     int kb = 1;
     plan::lane_batches(K, W, s.max_chunk_electrons, &kb, &s.thin);
-    if (const char* e = std::getenv("WAYNE_BATCH")) kb = std::min(std::max(std::atoi(e), 1), kLaneBatchMax);
+    if (c->knobs.batch >= 0) kb = (int)std::min<long long>(std::max<long long>(c->knobs.batch, 1), kLaneBatchMax);
     s.kb = kb;
-    if (const char* e = std::getenv("WAYNE_THIN")) s.thin = std::atoi(e) != 0;
+    if (c->knobs.thin >= 0) s.thin = c->knobs.thin != 0;
   }
   s.use_box = plan::accumulator_boxes(c->est, W, d->wl_um, d->flux, K, R, c->S, d->sub_scale, d->x_ref, d->y_ref,
-                                      d->sample_read, s.acc_box) && !std::getenv("WAYNE_NO_ACC_BOX");
+                                      d->sample_read, s.acc_box) && !(c->knobs.no_acc_box > 0);
   lap(2, t_lap);
   {
     const size_t seg_bytes = ((SS + 63) / 64) * sizeof(uint32_t);
@@ -1019,11 +1154,11 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     // all -- an empty launch still costs ~8 us of the exposure's critical path -- and the lanes take what they
     // find up to kLaneReach electrons; a bin beyond that (the estimate carries no Poisson noise) sets status bit 1
     // and the exposure is run again with k_throw when its status is read (check_status)
-    // (WAYNE_LANE_REACH: a test knob that lowers the lanes' reach so that the re-run path can be exercised)
+    // (knob `lane_reach`: a test knob that lowers the lanes' reach so that the re-run path can be exercised)
     int reach = kLaneReach;
-    if (const char* e = std::getenv("WAYNE_LANE_REACH")) reach = std::min(std::max(std::atoi(e), 1), kLaneReach);
+    if (c->knobs.lane_reach >= 0) reach = (int)std::min<long long>(std::max<long long>(c->knobs.lane_reach, 1), kLaneReach);
     lane_unlimited = d.rng_mode == WAYNE_RNG_SPLIT && s.est_thrown <= 0. && d.thrower_splits <= 0 && !s.force_throw &&
-                     !std::getenv("WAYNE_THROW_WGS");
+                     c->knobs.throw_wgs < 0;
     a.lane_max = lane_unlimited ? reach : kLaneMax;
     a.prefix = s.prefix.as<uint32_t>(); a.xpos = s.xpos.as<double>(); a.ypos = s.ypos.as<double>();
     a.sub = s.sub.as<SubInfo>();
@@ -1037,7 +1172,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     // multinomial's threshold (mean <= 6 against kSplitMin = 32: 1e-13 per draw), k_narrow's launch would only find
     // that out workgroup by workgroup (0.04 ms at K = 2233) -- it is left out, and a bin that qualifies after all
     // flags the run, which is then repeated with every kernel (check_status)
-    skip_narrow = lane_unlimited && s.max_narrow <= 6. && !std::getenv("WAYNE_KEEP_NARROW");
+    skip_narrow = lane_unlimited && s.max_narrow <= 6. && !(c->knobs.keep_narrow > 0);
     a.no_narrow = skip_narrow ? 1 : 0;
     CosmicArgs& ca = cosmic_args;
     ca.R = R; ca.N = N; ca.S = S; ca.seed = d.seed; ca.exposure = d.exposure_index;
@@ -1045,7 +1180,7 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     ca.read_dt = s.read_dt.as<double>(); ca.acc = s.acc.as<long long>();
     ca.seg = s.seg.as<uint32_t>();
     // thin exposure, nothing for k_throw or k_narrow expected: the lanes plan their bins themselves (k_lane, FUSED)
-    fused = lane_unlimited && skip_narrow && s.thin && !std::getenv("WAYNE_NO_FUSE");
+    fused = lane_unlimited && skip_narrow && s.thin && !(c->knobs.no_fuse > 0);
     s.fused_last = fused;
     s.last_prep = a;
     s.last_chunks = n_chunks;
@@ -1065,12 +1200,12 @@ int wayne_exposure_run_front(wayne_ctx* c, int slot) {
     a.kb = s.kb;
     // grid: one unit (128 electrons; 1 in replay mode) per lane of the workgroups of a sub-sample, from
     // the host's estimate of the electrons + 8 %, but at least ~4 workgroups per CU over the launch
-    // (WAYNE_THROW_WGS / desc.thrower_splits override); k_throw shares out what it actually finds
+    // (knob `throw_wgs` / desc.thrower_splits override); k_throw shares out what it actually finds
     const int min_wgs = 1024;
     int splits = d.thrower_splits;
     if (splits <= 0) {
-      if (const char* e = std::getenv("WAYNE_THROW_WGS")) {
-        splits = std::max(1, (std::max(std::atoi(e), 1) + K - 1) / K);
+      if (c->knobs.throw_wgs >= 0) {
+        splits = (int)std::max<long long>(1, (std::max<long long>(c->knobs.throw_wgs, 1) + K - 1) / K);
       } else {
         const double unit = (d.rng_mode == WAYNE_RNG_REPLAY) ? 1. : (double)kThrowBlock;
         const double lanes = 1.08 * s.est_thrown / unit;
@@ -1165,9 +1300,9 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
 #ifdef WAYNE_TIMING_KNOBS
   // measurement knob of TIMING BUILDS only (scripts/ramp_vs_reads.py builds its own library with -DWAYNE_TIMING_KNOBS):
   // the kernel works through the first n reads only -- the slot's other accumulators stay uncleared and the later
-  // reads' planes stale, so the shipped library does not look at the variable at all
+  // reads' planes stale, so the shipped library does not look at the knob at all
   bool ramp_reads_cut = false;
-  if (const char* e_ = std::getenv("WAYNE_RAMP_READS")) { a.R = std::max(1, std::min(s.R, std::atoi(e_))); ramp_reads_cut = a.R < s.R; }
+  if (c->knobs.ramp_reads >= 0) { a.R = (int)std::max<long long>(1, std::min<long long>(s.R, c->knobs.ramp_reads)); ramp_reads_cut = a.R < s.R; }
 #endif
   a.seed = d.seed; a.exposure = d.exposure_index; a.flags = d.flags;
   a.sky_ct_s = d.sky_ct_s; a.noise_mean = d.noise_mean; a.noise_std = d.noise_std;
@@ -1206,6 +1341,7 @@ int wayne_exposure_run_back(wayne_ctx* c, int slot) {
   if (ramp_reads_cut) s.acc_dirty = true;     // the next front half starts from cleared accumulators
 #endif
   s.front_done = false;
+  s.ran = true;
   return WAYNE_OK;
 }
 
@@ -1248,9 +1384,22 @@ static int check_status(wayne_ctx* c, Slot& s, bool* rerun = nullptr) {
   struct { unsigned long long electrons; int status; int pad; } m{};
   HIP_TRY(c, hipMemcpyAsync(&m, s.misc.p, sizeof m, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.ran = false;                           // looked at
   if (m.status & 1) return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
   if (rerun) *rerun = (m.status & 2) != 0;
   return WAYNE_OK;
+}
+
+int wayne_exposure_run_checked(wayne_ctx* c, int slot) {
+  int rc = wayne_exposure_run(c, slot);
+  if (rc) return rc;
+  Slot& s = c->slots[slot];
+  bool rerun = false;
+  if ((rc = check_status(c, s, &rerun)) || !rerun) return rc;
+  s.force_throw = true;
+  c->reruns += 1;
+  if ((rc = wayne_exposure_run(c, slot))) return rc;
+  return check_status(c, s);
 }
 
 int wayne_exposure_download(wayne_ctx* c, int slot, void* out_reads) {
@@ -1313,6 +1462,7 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
   use_slot_stream(c, slot);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *host_reads = s.pinned;
+  s.ran = false;                             // looked at (the status word came with the reads)
   if (s.pinned_misc->status & 1)
     return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
   if (s.pinned_misc->status & 2) {           // a bin beyond the lanes' reach: once more, with k_throw
@@ -1322,6 +1472,7 @@ int wayne_exposure_wait(wayne_ctx* c, int slot, void** host_reads) {
     if (rc == WAYNE_OK) rc = wayne_exposure_fetch_async(c, slot);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    s.ran = false;
     if (s.pinned_misc->status & 1)
       return fail(c, WAYNE_E_OVERFLOW, "exposure: a sub-sample holds >= 2^32 electrons (or a bin >= 2^31)");
   }

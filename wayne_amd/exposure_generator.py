@@ -117,7 +117,7 @@ class ExposureGenerator(object):
                        scale_factor=None, add_gain_variations=True, add_non_linear=True,
                        clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                        add_initial_bias=True, progress_bar=None, threads=2,
-                       rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, reference_quirks=False,
+                       rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
                        record=None, exact_samplers=False):
         """Generate a spatially scanned exposure (exposure_generator.py:178-405).
 
@@ -125,10 +125,14 @@ class ExposureGenerator(object):
         Philox-keyed streams, wide PSF component thrown per electron, narrow
         component drawn as one multinomial per bin), RNG_PHILOX (every electron
         thrown), or RNG_REPLAY (the reference's rand_r streams in the thrower,
-        with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` -- float64 reads (the
-        default: what the reference's Exposure.reads hold, exposure.py:47,106-120) or float32 reads (the production
-        path of bench.py, VisitRunner and the CLI: half the bytes to write and to carry over PCIe, <= 3 ulp of a
-        float32 from the float64 result); `reference_quirks` keeps the reference's -5 px frame
+        with `threads` selecting its OpenMP partition: bit-exact scatter); `out_dtype` -- float32 reads (the
+        default HERE and in Observation, VisitRunner, the CLI and bench.py's `value`: ONE arithmetic for every entry
+        point -- exact integer electron sums, then a float32 per-read chain; half the bytes to write and to carry
+        over PCIe, <= 3 ulp of a float32 from the float64 result, no measurable effect on a recovered transit depth:
+        profiles/r06/visit_science.json) or float64 reads (out_dtype=np.float64, CLI --float64-reads: what the
+        reference's Exposure.reads hold, exposure.py:47,106-120 -- a DEVIATION of the default from the reference,
+        chosen so that the benchmarked kernel is the one an API user gets; FITS files carry float64 SCI images
+        either way); `reference_quirks` keeps the reference's -5 px frame
         offset at SUBARRAY=1024 (exposure_generator.py:630) and flat-fields G102 exposures with the
         G141 cube as the reference does (grism.py:428,453-454); `record`, if a dict,
         receives the device's intermediate products (counts, x, y per bin and
@@ -226,7 +230,7 @@ class ExposureGenerator(object):
                          scale_factor=None, add_gain_variations=True, add_non_linear=True,
                          clip_values_det_limits=True, add_read_noise=True, add_stellar_noise=True,
                          add_initial_bias=True, progress_bar=None, threads=2,
-                         rng_mode=_lib.RNG_SPLIT, out_dtype=np.float64, reference_quirks=False,
+                         rng_mode=_lib.RNG_SPLIT, out_dtype=np.float32, reference_quirks=False,
                          exact_samplers=False):
         """The host half of scanning_frame: sample timing, scan positions, SSV,
         jitter / seed draws, spectrum crop (exposure_generator.py:247-334) ->
