@@ -257,6 +257,7 @@ int wayne_oracle_psf_philox(const int32_t *counts, int size,
       const float ang = 6.283185307179586f * (wayne_oracle_rev12(ra) - 1.0f);
       const float sig = (j < n_wide) ? psf_sigmah[b] : psf_sigmal[b];
       const float c = (-1.3862943611198906f * sig) * sig;
+      if (!(c > -3e38f)) continue;          /* a sigma that is not finite: none of its electrons is kept (:91-93) */
       const float Rs = sqrtf(c * log2f(wo_u01(rb)));
       const int xp = wo_cell(ox, fmaf(cosf(ang), Rs, fx));
       const int yp = wo_cell(oy, fmaf(sinf(ang), Rs, fy));

@@ -233,6 +233,7 @@ static void so_throw_one(uint32_t g[4], const so_local *L, float sig, int n, int
   wayne_oracle_xo_next2(g, w);            /* one pair per electron: angle, radius */
   const float ang = 6.283185307179586f * (wayne_oracle_rev12(w[0]) - 1.0f);
   const float c = (-1.3862943611198906f * sig) * sig;
+  if (!(c > -3e38f)) return;                /* a sigma that is not finite: the reference keeps none of its electrons (:91-93) */
   const float Rs = sqrtf(c * log2f(so_u01(w[1])));
   const int xp = so_cell(L->ox, fmaf(cosf(ang), Rs, L->fx));
   const int yp = so_cell(L->oy, fmaf(sinf(ang), Rs, L->fy));
@@ -250,11 +251,10 @@ static void so_throw_word(uint32_t wd, uint32_t *refine, const so_local *L, floa
   const float ang = 6.283185307179586f * (rev - 1.0f);
   const float c = (-1.3862943611198906f * sig) * sig;
   const uint32_t h = wd & 0xFFFFu;
+  if (h == 0u) *refine = *refine * 1664525u + 1013904223u;    /* (the side stream advances whether or not the electron is kept) */
+  if (!(c > -3e38f)) return;                /* a sigma that is not finite: the reference keeps none of its electrons (:91-93) */
   float r2 = fmaf(c, log2f((float)h + 0.5f), -16.0f * c);
-  if (h == 0u) {
-    *refine = *refine * 1664525u + 1013904223u;
-    r2 = fmaf(c, log2f((float)(*refine >> 15) + 0.5f), -33.0f * c);
-  }
+  if (h == 0u) r2 = fmaf(c, log2f((float)(*refine >> 15) + 0.5f), -33.0f * c);
   const float Rs = sqrtf(r2);
   const int xp = so_cell(L->ox, fmaf(cosf(ang), Rs, L->fx));
   const int yp = so_cell(L->oy, fmaf(sinf(ang), Rs, L->fy));

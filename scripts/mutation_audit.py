@@ -22,7 +22,7 @@ two sets of tests, in this order:
 A mutant is a list of (file under wayne_amd/csrc, exact text, replacement); the text must occur exactly once.  The
 shipped sources are never touched: each mutant is built from a copy under tests/native/_build/mutants/ and loaded
 through WAYNE_HIP_LIB (wayne_amd/_lib.py), like the negative-control libraries.  Test infrastructure; results of round 5:
-profiles/r05/mutation_audit.txt, DESIGN.md section 6.
+profiles/r05/mutation_audit.txt, HISTORY.md section 6.
 """
 import os
 import shutil

@@ -10,7 +10,7 @@ uncleared accumulators, so the shipped library ignores the variable)
 
 A straight line is the healthy picture.  Round 4 found t(3) = 20 us, t(4) = 49 us, flat to t(12): ONE wave per launch
 walking a 512-step search (a sky draw whose uniform fell into the rounding residue of its float32 cdf) while every
-other wave had finished -- see DESIGN.md section 9.
+other wave had finished -- see HISTORY.md section 9.
 """
 import os
 import sys

@@ -49,7 +49,7 @@ def main():
         moved = int(np.abs(got.astype(np.int64) - want).sum()) // 2
         frac = moved / max(total, 1)
         worst = max(worst, frac)
-        # (tests/helpers.py split_moved_bound: a rate term + room for ONE flipped chain)
+        # (tests/helpers.py split_moved_bound: a rate term + room for ONE flipped chain; HISTORY.md section 6)
         ok = (np.array_equal(got, again) and abs(int(got.sum()) - total) <= 2 + total // 100000 and
               moved <= 2 + 1e-4 * total + 3 * np.sqrt(16.0 * counts.max()))
         print("case %2d W=%4d N=%3d electrons=%9d moved=%6d (%.1e) %s" % (i, counts.size, N, total, moved, frac,

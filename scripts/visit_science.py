@@ -68,7 +68,7 @@ def main():
                 float(np.mean(r["residual_rms_over_photon_noise"]))))
         for pair, m in rep["paired"].items():
             r = m["ramp"]
-            print("  %-28s n=%4d  white %+7.3f +- %.3f ppm   channels chi2 %.1f / %d (sigma %.1f ppm)   x-phase chi2 %.1f  y-phase chi2 %.1f / 7" % (
+            print("  %-28s n=%4d  white %+7.3f +- %.3f ppm   channels chi2 %.1f / %d (sigma %.1f ppm)   x-phase chi2 %.1f  y-phase chi2 %.1f / 2" % (
                 pair, m["n"], r["white_depth_difference_ppm"], r["white_sigma_ppm"], r["chi2"], r["dof"],
                 float(np.mean(r["sigma_ppm"])), r["flux_ratio_vs_x_phase_ppm"]["chi2"], r["flux_ratio_vs_y_phase_ppm"]["chi2"]))
 

@@ -6,7 +6,7 @@ compiled C (`oracle/_ref`, wayne/pyparallel_menu.c:87-108, different `test` seed
 distribution when the two throwers draw from the same law; each test states its band in standard errors of that
 distribution (5 sigma unless said otherwise), so a band is not a fitted number.
 
-What each figure would catch ("ensemble parity"):
+What each figure would catch (HISTORY.md section 6, "ensemble parity"):
   z_mean / z_std        a shift of any pixel's expected count (wrong cell masses, a biased sampler, a lost tail) and
                         over- or under-dispersion of the pixel counts against the reference
   log_var_ratio / fano  the variance law itself: with `N = (int)(counts*ratio)` fixed (pyparallel_menu.c:89) a pixel's

@@ -53,7 +53,7 @@ def oracle_kwargs(kw, seed=0, exposure=0):
 
 def split_moved_bound(counts, total, exact=False):
     """Most electrons the device's split thrower may place in another pixel than oracle/split_oracle.c on the same
-    counters.  A binomial draw of a chain comes out differently when its uniform lands within
+    counters (HISTORY.md section 6).  A binomial draw of a chain comes out differently when its uniform lands within
     the last bits of a step of the cdf / of a rejection test -- glibc against ocml with exact samplers, hardware
     rcp / exp / log in production math -- and the rest of THAT chain is then drawn afresh: a few sqrt(n) electrons
     of one bin or, where a group of 16 bins pools its rows, of one pooled column (n up to the group's electrons),

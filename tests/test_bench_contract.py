@@ -61,6 +61,45 @@ def test_bench_line_has_the_contract_keys():
     for key in ("delivered", "end_to_end"):
         assert d[key]["ranks_reported"] == 1 and list(d[key]["per_rank_exposures_s"]) == ["0"]
     assert len(d["two_streams"]["repetitions"]) == 3
+    # one arithmetic per default, and the line says which: the workload names the reads' type and the stream count,
+    # two_streams says whose number it is, the library names itself
+    import bench
+    assert bench.READS_LABEL[False] in d["config"]["workload"] and "one HIP stream" in d["config"]["workload"]
+    assert "f32 reads (the default of ExposureGenerator, Observation, VisitRunner and the CLI)" == bench.READS_LABEL[False]
+    assert d["two_streams"]["note"].startswith("what VisitRunner (Observation, the CLI) delivers device-side")
+    assert d["library"] == {"path": os.path.join("wayne_amd", "libwayne_hip.so"), "build_flags": "", "abi": 7}
+    assert rep["incomplete_exposures"] == 0 and rep["second_runs_in_timed_region"] == 0
+
+
+def test_every_ramp_instantiation_gets_the_arithmetic_it_runs():
+    # `dtype` names the arithmetic of the timed kernels from the instantiation the library reports
+    # (wayne_exposure_ramp_variant); over every name select_ramp can emit (wayne_hip.hip): the all-float32 per-read
+    # chain exists only for float reads, production math, the table-driven sky in ONE piece and no gaussian-noise stage
+    # (k_ramp.h, ramp_body: SKY == 1 && !NOISE)
+    sys.path.insert(0, ROOT)
+    import bench
+    names = []
+    for t in ("float", "double"):
+        for fast in ("true", "false"):
+            for sky in (0, 1, 2):
+                for noise in ("false", "true"):
+                    pinned = fast == "true" and sky != 0 and noise == "false"
+                    if pinned:
+                        for allon in (["false", "true"] if (t == "float" and sky == 1) else ["false"]):
+                            names.append("k_ramp<%s, %s, %d, %s, %s>" % (t, fast, sky, noise, allon))
+                    else:
+                        names.append("k_ramp_wide<%s, %s, %d, %s>" % (t, fast, sky, noise))
+    assert len(names) == 25
+    f32_chain = [n for n in names if "all-f32 per-read chain" in bench.dtype_label(n, n.split("<")[1].startswith("double"))]
+    assert sorted(f32_chain) == ["k_ramp<float, true, 1, false, false>", "k_ramp<float, true, 1, false, true>"]
+    for n in names:
+        label = bench.dtype_label(n, "<double" in n)
+        assert label.startswith(n) and label.endswith("f64 reads" if "<double" in n else "f32 reads")
+        if n not in f32_chain:
+            assert "f64 cumulative sum" in label, n
+    # the source says the same: the production chain is taken when SKY == 1 && !NOISE, for float reads, in fast math
+    src = open(os.path.join(ROOT, "wayne_amd", "csrc", "k_ramp.h")).read()
+    assert "SKY == 1 && !NOISE" in src
 
 
 def test_launcher_refuses_a_rank_count_mismatch():

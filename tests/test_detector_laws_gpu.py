@@ -169,7 +169,7 @@ def test_bin_positions_are_the_references_trace_scan_and_frame_offset(name):
     # exposure_generator.py:258, 517-529, 591-594, 630-632, as written: at sub-sample i the star sits at
     # (x_ref + jitter, y_ref + mid_point_i x scan_speed), a bin of wavelength wl at trace.wl_to_x / wl_to_y of that star, and
     # on the frame at that position minus 507 - SUBARRAY / 2 (0 at the full array here: the reference's -5 there shifts
-    # the spectrum off its own flat, DESIGN.md section 1, kept only with reference_quirks).  The trace is the product's
+    # the spectrum off its own flat, HISTORY.md section 1, kept only with reference_quirks).  The trace is the product's
     # PYTHON `_SpectrumTrace` -- whose coefficients and wavelength map are held to the reference's own test values in
     # tests/test_reference_goldens.py -- evaluated here; the positions are the DEVICE's (k_prep_wl / k_prep_sub).  No oracle:
     # the audit's mutants "scan speed 1 % high" and "offset 512 - SUBARRAY / 2" were stopped only by tests that restate the host loop.

@@ -2,7 +2,7 @@
 FAIL on the defects they exist for (negative controls) -- before tests/test_extremes_gpu.py trusts them with the device.
 
 The injected defect is the historical one: ~500 spurious electrons in ONE pixel of a 10^6-pixel frame (VERDICT r04;
-DESIGN.md "A search must be able to stop").  The moment statistic that missed it for three rounds is evaluated beside
+HISTORY.md "A search must be able to stop").  The moment statistic that missed it for three rounds is evaluated beside
 the checker, on the same data, to show the difference.
 """
 import numpy as np

@@ -134,7 +134,7 @@ def compare(name, tag, got, rec, want, orec, moved_frac, bad_frac, med_dn, med_r
     # (a moved electron is off in two pixels of every later read: on a 256 x 256 frame of 15 reads that term leads)
     assert bad <= bad_frac * d.size + 2 * (got.shape[0] - 1) * moved, "%d of %d pixel-reads off the oracle" % (bad, d.size)
     # ... and no single pixel is far off: the largest event the tolerance model knows is ONE re-drawn chain of a pooled
-    # column (16 bins' electrons, DESIGN.md section 6 "the flipped draw"): a few sqrt(16 max count) electrons
+    # column (16 bins' electrons, HISTORY.md section 6 "the flipped draw"): a few sqrt(16 max count) electrons
     worst = 3.0 * np.sqrt(16.0 * float(orec["counts"].max())) / 2.35 + 1.0 + slack / 2.35
     assert float(d.max()) <= worst, "largest pixel deviation %.1f DN (bound %.1f)" % (float(d.max()), worst)
     # (med_rel: float32 reads round to 6e-8 of their value -- 2.4e-4 DN at the few thousand DN of a 256 x 256 scan)

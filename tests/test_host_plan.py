@@ -16,7 +16,7 @@ from scipy import stats
 import plan_harness as ph
 from oracle import wayne_oracle as wo
 
-REACH = 6.9          # sigma: what every thrower mode provably stays within (k_ramp)
+REACH = 6.9          # sigma: what every thrower mode provably stays within (HISTORY.md section 4, k_ramp)
 MODES = [("SPARS10", 2.932, 10.0), ("RAPID", 0.278, 0.278), ("STEP25", 2.9, 25.0)]
 
 

@@ -39,7 +39,7 @@ def test_flat_field_of_the_oracle_is_the_references_cubic(name, size):
     # grism.py:349-385: flat[pixel] = f0 + f1 t + f2 t^2 + f3 t^3, t = (wl(pixel) - WMIN) / (WMAX - WMIN), wl(pixel) the
     # wavelength get_pixel_wl gives that pixel for a source at (x_ref, y_ref) (:137-163; pinned by the reference's test
     # values); on a sub-array the frame pixel (y, x) takes the flat of (y + off, x + off), off = (1014 - size) / 2 (:362-363; 0
-    # at the full array here)
+    # at the full array here, HISTORY.md section 1)
     v = helpers.make_visit(name)
     eo = helpers.oracle_generator(v)
     gr = eo.grism

@@ -156,7 +156,7 @@ def test_pooled_row_groups_against_oracle_same_counters(gpu_ctx):
 def test_soak_cases_against_oracle(gpu_ctx):
     # a fixed-seed stretch of scripts/soak_split.py (random numbers of bins, trace-like and scattered positions, thin
     # and dense bins, sigma ranges that pool, fall back or mix inside a wave) -- and the case that once exceeded the
-    # old "5e-4 of the total" bound: case 217 of seed 23, 17 bins, ONE flipped draw
+    # old "5e-4 of the total" bound: case 217 of seed 23, 17 bins, ONE flipped draw (HISTORY.md section 6)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import soak_split

@@ -339,6 +339,36 @@ def test_cli_runs_a_small_visit_and_writes_fits(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_resume_on_the_device(tmp_path):
+    # `--resume` with the real context (tests/test_resume.py has the rank-failure scenario on the CPU): a visit with one
+    # file missing and one truncated is completed by regenerating exactly those two, and what is regenerated equals,
+    # read for read and bit for bit, what the first run wrote -- every random stream is keyed by (visit seed, exposure
+    # index), never by what ran before (the reference's exposures share one global numpy stream: no restart there)
+    import shutil
+    work = str(tmp_path / "visit")
+    shutil.copytree(MINI, work)
+    yml = os.path.join(work, "params.yml")
+    obs = run_visit.run(["-p", yml, "--max-exposures", "4"])
+    names = ["%04d_raw.fits" % n for n in (1, 2, 3, 4)]
+    first = {n: [h.data for h in fitsio.read(os.path.join(obs.outdir, n))] for n in names}
+    stamp = {n: os.stat(os.path.join(obs.outdir, n)).st_mtime_ns for n in names}
+    os.remove(os.path.join(obs.outdir, names[1]))
+    with open(os.path.join(obs.outdir, names[2]), "r+b") as f:
+        f.truncate(100000)
+    obs2 = run_visit.run(["-p", yml, "--max-exposures", "4", "--resume"])
+    assert obs2.skipped == [0, 3]
+    assert sorted(n for n in os.listdir(obs2.outdir) if n.endswith((".fits", ".part"))) == ["0000_flt.fits"] + names
+    for n in names:
+        again = [h.data for h in fitsio.read(os.path.join(obs2.outdir, n))]
+        assert len(again) == len(first[n]) == 1 + 5 * 4
+        for a, b in zip(again, first[n]):
+            assert (a is None and b is None) or np.array_equal(a, b)
+        assert (os.stat(os.path.join(obs2.outdir, n)).st_mtime_ns == stamp[n]) == (n in (names[0], names[3]))
+    from wayne_amd import engine
+    engine.close_all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("how", ["gpus_2_sharing_device_0", "ranks_per_gpu_2"])
 def test_cli_starts_its_own_ranks(tmp_path, how):
     # `python -m wayne_amd.run_visit --gpus 2`: the parent starts two rank processes before anything touches a GPU

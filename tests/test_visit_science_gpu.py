@@ -1,0 +1,118 @@
+"""GPU: visit-level (science-level) parity -- transit depths recovered from whole simulated visits, in ppm.
+
+The reference exists to produce visits from which transit depths are recovered (observation.py:293-357: the
+per-wavelength light curves; exposure_generator.py:344-348, 625-628: flux x (1 - depth) -> electrons).  Here a depth
+spectrum is injected (0.0146 + 2e-4 sin(2 pi (lambda - 1.1) / 0.3)), visits are generated through the HIP
+path in the production mode (split thrower, float32 reads: what `value`, the CLI and the API default run), with float64
+reads, per electron with float64 reads (the reference's arithmetic shape) and -- a subset -- in the bit-exact replay
+mode, 20 spectral light curves are extracted the way an observer would (tests/visit_science.py) and fitted.
+
+Asserted, every bound a multiple of the fit's own error (from its residuals), none tuned to the measured value:
+  (a) recovered - injected within k sigma in every channel, both extractions, every mode -- and the residual scatter is
+      the photon noise (x 1.0 ... 1.3 in the median channel): the simulator puts in the light curve it was given and adds no noise of its own;
+  (b) production - per-electron, PAIRED (same stellar counts, sky, dark, read-noise draws: the counters do not depend on
+      the thrower): every channel within k sigma of zero, the white light curve within k sigma of zero at a sigma of
+      under 2 ppm -- the measured replacement of the argued "aggregate approximation budget" of the production thrower;
+  (c) float32 against float64 reads: below 0.5 ppm in every channel -- which settles the float32 default;
+  (d) replay - per-electron on the subset: the same, at its sigma;
+  (e) no dependence of the paired flux ratio on the star's sub-pixel phase in x or y (a first harmonic is what a
+      position-rounding defect of the thrower would leave).
+scripts/visit_science.py runs the same at twice the length and writes profiles/r06/visit_science.json.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import visit_science as vs
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "visit_science_test.json")
+K_PULL = 4.5          # per channel: 20 channels x 2 extractions x 3 modes x 2 visits = 240 pulls, P(|z| > 4.5) = 7e-6 each
+CHI2_20 = 20.0 + 5.0 * np.sqrt(40.0)      # chi2 of 20 channels: mean 20, sigma sqrt(40); 5 sigma = 51.6 (P ~ 1e-4)
+CHI2_2 = 18.4         # chi2 of 2 dof at P = 1e-4
+
+
+def keep(name, rep):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        d = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        d[name] = rep
+        json.dump(d, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module", params=[("cfg3", 512, 8), ("cfg4", 64, 8)], ids=["cfg3", "cfg4"])
+def visit(request):
+    name, n, every = request.param
+    sv = vs.ScienceVisit(name, n)
+    tables = {m: vs.generate(sv, m) for m in ("production", "split_f64", "per_electron")}
+    idx = np.arange(0, n, every)
+    tables["replay"] = vs.generate(sv, "replay", idx)
+    rep = vs.analyse(sv, tables, {"replay": idx})
+    keep(name, rep)
+    from wayne_amd import engine
+    engine.close_all()
+    return sv, rep
+
+
+def test_recovered_depths_are_the_injected_ones(visit):
+    sv, rep = visit
+    assert 0.40 < sv.G.mean() < 0.65 and sv.G.min() == 0.0 and sv.G.max() == 1.0            # the visit covers the transit
+    assert np.ptp(sv.expected) > 3e-4                                                      # ... and the spectrum has its feature
+    for mode in ("production", "split_f64", "per_electron"):
+        for how in ("ramp", "last_read"):
+            r = rep["modes"][mode][how]
+            pull = np.array(r["pull"])
+            assert np.abs(pull).max() < K_PULL, (mode, how, pull)
+            assert r["chi2"] < CHI2_20, (mode, how, r["chi2"])
+            assert abs(r["white_recovered_minus_injected_ppm"]) < 4.0 * r["white_sigma_ppm"], (mode, how, r)
+            # the scatter about the fitted light curve is the photon noise of the channel (+ sky, read noise, edge pixels)
+            # (the end channels sit on the steep flanks of the sensitivity curve, where the two fractional edge columns
+            # of a star-fixed channel add their own noise at random sub-pixel phases: the observer's, not the simulator's)
+            rms = np.array(r["residual_rms_over_photon_noise"])
+            assert 0.85 < rms.min() and np.median(rms) < (1.3 if how == "ramp" else 1.6) and rms.max() < 2.5, (mode, how, rms)
+
+
+def test_production_mode_against_every_electron_float64_in_ppm(visit):
+    sv, rep = visit
+    n = rep["n_exposures"]
+    for how in ("ramp", "last_read"):
+        r = rep["paired"]["production_minus_per_electron"][how]
+        d, s = np.array(r["depth_difference_ppm"]), np.array(r["sigma_ppm"])
+        assert np.abs(d / s).max() < K_PULL and r["chi2"] < CHI2_20, (how, d, s)
+        # what a pair buys: the common noise is gone -- the paired scatter is the partition noise of electrons near a
+        # channel's edge, well under the channel's photon noise
+        phot = np.array(rep["photon_noise_ppm_per_exposure"])
+        assert np.all(np.array(r["paired_flux_rms_ppm"]) < 1.2 * phot)
+        # white light: no edges inside, so the pair is nearly noise-free -> the bias bound in ppm
+        assert abs(r["white_depth_difference_ppm"]) < 4.0 * r["white_sigma_ppm"], (how, r)
+        assert r["white_sigma_ppm"] < 2.0 * np.sqrt(512.0 / n) * (1.0 if sv.v.name == "cfg3" else 0.5), (how, r["white_sigma_ppm"])
+        assert abs(r["white_flux_offset_ppm"]) < 4.0 * r["white_flux_offset_sigma_ppm"] + 0.5, (how, r)
+        for axis in ("x", "y"):
+            ph = r["flux_ratio_vs_%s_phase_ppm" % axis]
+            assert ph["chi2"] < CHI2_2, (how, axis, ph)
+
+
+def test_float32_reads_change_no_depth(visit):
+    sv, rep = visit
+    for how in ("ramp", "last_read"):
+        a = np.array(rep["paired"]["production_minus_per_electron"][how]["depth_difference_ppm"])
+        b = np.array(rep["paired"]["split_f64_minus_per_electron"][how]["depth_difference_ppm"])
+        assert np.abs(a - b).max() < 0.5, (how, np.abs(a - b).max())
+        wa = rep["paired"]["production_minus_per_electron"][how]["white_depth_difference_ppm"]
+        wb = rep["paired"]["split_f64_minus_per_electron"][how]["white_depth_difference_ppm"]
+        assert abs(wa - wb) < 0.05, (how, wa, wb)
+
+
+def test_replay_mode_subset_agrees_too(visit):
+    sv, rep = visit
+    for how in ("ramp", "last_read"):
+        r = rep["paired"]["replay_minus_per_electron"][how]
+        d, s = np.array(r["depth_difference_ppm"]), np.array(r["sigma_ppm"])
+        assert np.abs(d / s).max() < K_PULL and r["chi2"] < CHI2_20, (how, d, s)
+        assert abs(r["white_depth_difference_ppm"]) < 4.0 * r["white_sigma_ppm"], (how, r)

@@ -65,7 +65,9 @@ __device__ __forceinline__ double poly3(const double* c, double x) {
 // floor(), not the reference's truncation toward zero: the two differ only for sums in (-1, 0) of the frame coordinate,
 // which truncation sends to pixel 0 and floor to pixel -1 -- both outside the reference's strict bounds 0 < pos < n
 // (:93), so the kept electrons are the same.  A position that is not finite or beyond +-1e6 is not split (o = 0,
-// f = (float)pos): with any PSF of the instrument its electrons miss the frame either way.
+// f = (float)pos): with any PSF of the instrument its electrons miss the frame either way.  A sigma that is not finite
+// (or whose square overflows a float) is settled where the bin is loaded: its electrons are thrown at -1e30, off every
+// frame like the reference's (int) of a non-finite double -- so the sums in the electron loops are finite.
 // oracle/split_oracle.c (so_bin_local) and oracle/psf_oracle.c are the same statement on the CPU.
 struct BinLocal { float fx, fy; int ox, oy; bool sane; };
 __device__ __forceinline__ BinLocal bin_local(double xd, double yd) {
@@ -84,9 +86,7 @@ __device__ __forceinline__ int floor_to_int(float v) {
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
   return r;
 }
-// o + floor(v) where nothing is known about v: no signed overflow when the conversion saturates (a dead lane's
-// -1e30f), and a NaN (a sigma that is not finite) goes off the frame like the reference's (int) of a NaN, not to o
-__device__ __forceinline__ int local_cell(int o, float v) { return (int)((unsigned)o + (unsigned)floor_to_int(fmaxf(v, -3e9f))); }
+
 
 // Reductions over the 16 lanes of a DPP row (butterfly of row rotations): every lane of the row gets the result.
 // All 64 lanes must be active.

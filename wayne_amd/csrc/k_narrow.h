@@ -3,9 +3,6 @@
 #include "common.h"
 #include "k_throw.h"
 
-#ifndef WAYNE_LANE_VARIANT
-#define WAYNE_LANE_VARIANT 1
-#endif
 namespace wayne {
 
 // ---------------------------------------------------------------------------
@@ -252,7 +249,7 @@ __global__ __launch_bounds__(kNarrowThreads) void k_narrow(ThrowArgs a) {
       if (n_rem > 0.f && (c >= 0 || pool)) {
         const float pc = (c < 0) ? P : fminf(fmaxf(M::div_(P, rem), 0.f), 1.f);
 #ifdef WAYNE_TIMING_COLPOOL
-        // TIMING BUILD (wrong frames; DESIGN.md section 9, "column chains pooled over 4 bins"): what the kernel would cost
+        // TIMING BUILD (wrong frames; HISTORY.md section 9, "column chains pooled over 4 bins"): what the kernel would cost
         // if three of four column chains did not exist -- the chains of waves 2..7 are replaced by a rounding (whole
         // waves, so the issue slots really go), their thinning draw and everything downstream stays
         if (c >= 0 && (tid >> 6) >= 2) n_col = fminf(floorf(fmaf(n_rem, pc, 0.5f)), n_rem);
@@ -418,6 +415,12 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
     ch = (-1.3862943611198906f * sh) * sh;
     cl = (-1.3862943611198906f * sl) * sl;
   }
+  // A sigma that is not finite (or whose square is not): the reference's (int) of a non-finite position keeps none of
+  // the electrons that take it (pyparallel_menu.c:91-93).  Settled here, once per bin -- such electrons are thrown at
+  // -1e30 -- so that every sum in the electron loop is finite and its floor needs no guard.
+  const bool bad_h = !(ch > -3e38f), bad_l = !(cl > -3e38f);
+  if (bad_h) ch = 0.f;
+  if (bad_l) cl = 0.f;
   // FUSED: the bin's per-wavelength inputs of the counts chain, the batch's SubInfo records, and the cosmic-ray hits
   // that k_prep_sub's workgroups add on their way in
   double f_wl = 0., f_flux = 0., f_sens = 0., f_dlam = 0., f_ratio = 0., f_sigl = 0.;
@@ -600,32 +603,26 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
     // three-operand add)
     // (one block: left to itself the compiler takes `origin` apart again and adds its two halves per electron)
     int addr, j;
-#if WAYNE_LANE_VARIANT == 3
-    // separate statements, origin opaque
-    int i;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(vx));
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(j) : "v"(vy));
-    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(i) : "v"(i), "v"(origin));
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr) : "v"(j), "s"(tw4), "v"(i));
-#elif WAYNE_LANE_VARIANT == 4
-    // truncating converts (WRONG cells for negative offsets: a timing build) to price v_cvt_flr against v_cvt_i32
-    asm("v_cvt_i32_f32 %0, %2\n\tv_cvt_i32_f32 %1, %3\n\tv_lshl_add_u32 %0, %0, 2, %4\n\tv_mad_i32_i24 %0, %1, %5, %0"
-        : "=&v"(addr), "=&v"(j) : "v"(vx), "v"(vy), "v"(origin), "s"(tw4));
-#else
     asm("v_cvt_flr_i32_f32 %0, %2\n\tv_cvt_flr_i32_f32 %1, %3\n\tv_lshl_add_u32 %0, %0, 2, %4\n\tv_mad_i32_i24 %0, %1, %5, %0"
         : "=&v"(addr), "=&v"(j) : "v"(vx), "v"(vy), "v"(origin), "s"(tw4));
-#endif
     if (live) tile_add(addr);
   };
+  // (tile with the bounds test) the electron's cell counted from the tile's corner: floor of the sum + the bin's pixel
+  // relative to that corner, in unsigned arithmetic -- a dead lane's -1e30 saturates the conversion and wraps to a cell
+  // off every frame.  As many instructions as the truncating convert and the subtraction of the corner they replace.
+  const uint32_t oxl = (uint32_t)ox - (uint32_t)tx0, oyl = (uint32_t)oy - (uint32_t)ty0;
   auto throw_one = [&](SeededStream& rng, uint32_t wd, float c, float c16, float px, float py) {
     float vx, vy;
     draw(rng, wd, c, c16, px, py, vx, vy);
-    const int xi = local_cell(ox, vx), yi = local_cell(oy, vy);
-    const int lx = xi - tx0, ly = yi - ty0;
-    if ((unsigned)lx < (unsigned)tw && (unsigned)ly < (unsigned)th)
+    uint32_t lx, ly;
+    asm("v_cvt_flr_i32_f32 %0, %2\n\tv_cvt_flr_i32_f32 %1, %3\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5"
+        : "=&v"(lx), "=&v"(ly) : "v"(vx), "v"(vy), "v"(oxl), "v"(oyl));
+    if (lx < (uint32_t)tw && ly < (uint32_t)th) {
       tile_add(__umul24(ly, tw4) + (lx << 2));
-    else if (xi > 0 && xi < a.N && yi > 0 && yi < a.N)               // (:93)
-      deposit_global<FLUSH>(a, si, xi, yi, 1);
+    } else {
+      const int xi = (int)(lx + (uint32_t)tx0), yi = (int)(ly + (uint32_t)ty0);
+      if (xi > 0 && xi < a.N && yi > 0 && yi < a.N) deposit_global<FLUSH>(a, si, xi, yi, 1);               // (:93)
+    }
   };
   int cmin = n, cmax = n;
   for (int off = 32; off > 0; off >>= 1) {
@@ -638,10 +635,23 @@ __device__ __forceinline__ void lane_body(const ThrowArgs& a, const PrepArgs& p,
     SeededStream rng(a.seed, STAGE_LANE, (uint32_t)w, (uint32_t)k + a.subsample0, a.exposure);
     refine = (rng.s1 * 0x9E3779B9u) ^ rng.s3;
     const bool one_sigma = !__any(n > nw);
+    // electrons [lo, hi) of the lane are thrown; the others of its n take a sigma that is not finite (see bad_h):
+    // lo = 0, hi = n in every wave of every exposure this instrument can produce
+    const int lo = bad_h ? nw : 0, hi = bad_l ? min(nw, n) : n;
+    const bool odd_wave = __any(n > 0 && (bad_h || bad_l));
     const int cmin2 = cmin & ~1;                             // electrons 2i and 2i + 1 share pair i
     const float ch16 = -16.f * ch, cl16 = -16.f * cl;
     uint32_t wa, wb;
-    if (sure) {
+    if (odd_wave) {
+      // (a wave with such a lane -- its workgroup's tile is never test-free: the reach of a sigma that is not finite is
+      // not -- takes ONE general loop; the loops below keep their single test per electron)
+      for (int j = 0; j < cmax; j += 2) {
+        const bool la = j < hi && j >= lo, lb = j + 1 < hi && j + 1 >= lo;
+        rng.next2(wa, wb);
+        throw_one(rng, wa, (j < nw) ? ch : cl, (j < nw) ? ch16 : cl16, la ? x : -1e30f, la ? y : -1e30f);
+        throw_one(rng, wb, (j + 1 < nw) ? ch : cl, (j + 1 < nw) ? ch16 : cl16, lb ? x : -1e30f, lb ? y : -1e30f);
+      }
+    } else if (sure) {
       if (one_sigma) {
         for (int j = 0; j < cmin2; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, true); throw_sure(rng, wb, ch, ch16, true); }
         for (int j = cmin2; j < cmax; j += 2) { rng.next2(wa, wb); throw_sure(rng, wa, ch, ch16, j < n); throw_sure(rng, wb, ch, ch16, j + 1 < n); }

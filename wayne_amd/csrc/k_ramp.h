@@ -349,7 +349,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   };
   auto ld_f32 = [&](const __amdgpu_buffer_rsrc_t& rs, int r) -> float {
 #ifdef WAYNE_TIMING_RAMP_NO_DARK
-    // TIMING BUILD (wrong frames; DESIGN.md section 9, "two exposures per launch"): the dark planes for free -- what the
+    // TIMING BUILD (wrong frames; HISTORY.md section 9, "two exposures per launch"): the dark planes for free -- what the
     // second exposure of a pair that shared its partner's dark loads would cost
     return 0.02f + 1e-9f * (float)(r + (int)off4);
 #endif
@@ -374,7 +374,7 @@ __device__ __forceinline__ void ramp_body(const RampArgs& a) {
   const int lane_r = min(tid & 63, kMaxReads);
   const int p0 = __builtin_amdgcn_readfirstlane(p_raw) & ~63;
 #ifdef WAYNE_TIMING_RAMP_NO_ONCE
-  // TIMING BUILD (wrong frames): the once-per-pixel planes for free -- what a second exposure in
+  // TIMING BUILD (wrong frames; HISTORY.md section 9): the once-per-pixel planes for free -- what a second exposure in
   // the same launch would save on them
   const float t_sky = (interior && do_sky) ? 1.0f + 1e-4f * (float)(p & 255) : 0.f;
   const float t_pfl = 1.0f + 1e-5f * (float)(p & 127);

@@ -185,6 +185,40 @@ def read(path):
     return hdus
 
 
+def scan(path):
+    """The structure of a FITS file without its data: [(header, data bytes), ...] by reading the header blocks and
+    seeking over the payloads, or None when the file is not a complete FITS file (a header that does not end, a payload
+    the file is too short for, trailing bytes).  Cheap -- a few kilobytes read per HDU -- which is what a restarted
+    visit needs to decide whether an exposure's file is whole (wayne_amd/observation.py, `resume`)."""
+    import os
+    try:
+        total = os.path.getsize(path)
+        out, pos = [], 0
+        with open(path, "rb") as f:
+            while pos < total:
+                buf = b""
+                while True:                                  # a header: blocks up to the one that holds END
+                    block = f.read(BLOCK)
+                    if len(block) < BLOCK:
+                        return None
+                    buf += block
+                    if any(block[i:i + 8] == b"END     " for i in range(0, BLOCK, 80)):
+                        break
+                    if len(buf) > 64 * BLOCK:
+                        return None
+                h, used = _read_header(buf, 0)
+                size = _data_size(h)
+                padded = (size + BLOCK - 1) // BLOCK * BLOCK
+                pos += used + padded
+                if pos > total:
+                    return None
+                out.append((h, size))
+                f.seek(pos)
+        return out if pos == total and out else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _fmt_value(v):
     if isinstance(v, bool):
         return "%20s" % ("T" if v else "F")
@@ -289,15 +323,22 @@ def _write_all(fd, pieces):
             bufs.pop(0)
 
 
+PART_SUFFIX = ".part"
+
+
 def write_pieces(path, pieces):
-    """Write pre-rendered pieces (header blocks, big-endian payloads, padding) as one file; an existing file is
-    replaced (truncated in place)."""
+    """Write pre-rendered pieces (header blocks, big-endian payloads, padding) as one file.  The bytes go to
+    `path + ".part"` and the finished file is renamed over `path` (atomic on one file system): a reader -- or a visit
+    restarted after a crash -- never sees a file under its final name that is not whole.  An existing file is replaced,
+    as the reference's remove + writeto does (exposure.py:211-213)."""
     import os
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    part = path + PART_SUFFIX
+    fd = os.open(part, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
     try:
         _write_all(fd, pieces)
     finally:
         os.close(fd)
+    os.replace(part, path)
 
 
 def write(path, hdus):

@@ -192,13 +192,52 @@ class Observation(object):
         except (TypeError, IndexError):
             return value
 
-    def run_observation(self, rank=0, world=1, write_fits=True):
+    def exposure_file_is_whole(self, number):
+        """Is `NNNN_raw.fits` of exposure `number` (1-based) in the output directory, complete, and THIS visit's file?
+        Files are written under a temporary name and renamed when finished (fitsio.write_pieces), so a file under its
+        final name is whole unless something else truncated it: checked anyway -- the HDU structure is walked header by
+        header (1 + 5 NSAMP HDUs ending exactly at the end of the file, SCI images of the mode's size) and the primary
+        header must carry this exposure's start time and mode."""
+        path = os.path.join(self.outdir, "{:04d}_raw.fits".format(number))
+        if not os.path.isfile(path):
+            return False
+        from . import fitsio
+        hdus = fitsio.scan(path)
+        if hdus is None or len(hdus) != 1 + 5 * self.NSAMP:
+            return False
+        p0 = hdus[0][0]
+        S = self.detector.frame_size(self.SUBARRAY) if hasattr(self.detector, "frame_size") else (
+            1024 if self.SUBARRAY == 1024 else self.SUBARRAY + 10)
+        try:
+            same = (int(p0["NSAMP"]) == self.NSAMP and str(p0["SAMP_SEQ"]).strip() == self.SAMPSEQ and
+                    abs(float(p0["EXPSTART"]) - (float(self.exp_start_times[number - 1]) - 2400000.5)) < 1e-7)
+        except (KeyError, TypeError, ValueError):
+            return False
+        return bool(same) and all(size == S * S * 8 for (h, size) in hdus[1::5])
+
+    def run_observation(self, rank=0, world=1, write_fits=True, resume=False):
         """Generate the direct image and every exposure (observation.py:388-413); with
-        world > 1 only the exposures i = rank, rank + world, ... (round-robin sharding)."""
+        world > 1 only the exposures i = rank, rank + world, ... (round-robin sharding).
+        `resume`: an exposure whose file is already in the output directory, whole and this visit's
+        (exposure_file_is_whole), is not generated again -- what is left of a visit after a rank died is then only the
+        files that are missing.  Every exposure's random streams are keyed by the visit seed and its own index, so the
+        files of a resumed visit are those of an uninterrupted one (the reference, whose exposures share one global
+        numpy stream, has no such restart: it deletes and rewrites, exposure.py:211-213)."""
         if write_fits and self.outdir and not os.path.exists(self.outdir):
             os.makedirs(self.outdir)
         frames = {}
-        if rank == 0:
+        if write_fits and self.outdir:
+            # a crash leaves at most half-written temporary files behind: this rank's are removed (never a final name)
+            from . import fitsio
+            for i in [-1] + list(range(rank, len(self.exp_start_times), world)):
+                if i == -1 and rank != 0:
+                    continue
+                name = "0000_flt.fits" if i == -1 else "{:04d}_raw.fits".format(i + 1)
+                part = os.path.join(self.outdir, name + fitsio.PART_SUFFIX)
+                if os.path.exists(part):
+                    os.remove(part)
+        if rank == 0 and not (resume and write_fits and os.path.isfile(os.path.join(self.outdir, "0000_flt.fits"))
+                              and self._fits_is_whole(os.path.join(self.outdir, "0000_flt.fits"))):
             frames[0] = self._generate_direct_image(write_fits)
         # files are written by background threads while the GPU works on the next exposures
         import sys
@@ -226,6 +265,11 @@ class Observation(object):
         import threading
         ahead = queue.Queue(maxsize=depth + 1)
         mine = list(range(rank, len(self.exp_start_times), world))
+        self.skipped = []
+        if resume and write_fits:
+            self.skipped = [i for i in mine if self.exposure_file_is_whole(i + 1)]
+            done = set(self.skipped)
+            mine = [i for i in mine if i not in done]
         stop = threading.Event()            # set by this thread when it leaves the loop, for whatever reason
         # The context is created HERE, on the thread that will use it (upload / launch / collect): the producer's
         # prepare() then finds the engine in the cache instead of building the context, uploading grism and calibration,
@@ -284,6 +328,11 @@ class Observation(object):
                 pool.close()
             sys.setswitchinterval(old_interval)
         return frames
+
+    @staticmethod
+    def _fits_is_whole(path):
+        from . import fitsio
+        return fitsio.scan(path) is not None
 
     def _generate_exposure(self, expstart, number, write_fits=True, submit_slot=None, prepare_only=False):
         """observation.py:415-504.  With `submit_slot` the exposure is only enqueued on that context

@@ -1,6 +1,6 @@
 """Command line: generate a visit from a YAML parameter file.
 
-    python -m wayne_amd.run_visit -p <parameter_file> [--calibration DIR] [--device N] [--max-exposures M] [--gpus G]
+    python -m wayne_amd.run_visit -p <parameter_file> [--calibration DIR] [--device N] [--max-exposures M] [--gpus G] [--resume]
 
 Accepts the reference's parameter files (wayne/run_visit.py:1-9, example
 examples/hd209458b_12181_simulation_parameters.yml): sections `general`
@@ -13,6 +13,9 @@ examples/hd209458b_12181_simulation_parameters.yml): sections `general`
     the Open Exoplanet Catalogue lookup (oec.py) is not provided;
   * a missing stellar spectrum file falls back to a black body of
     `target: star_temperature` (default 6100 K);
+  * `--resume`: exposures whose files are already in the output directory (whole, and this visit's: same start time and
+    mode) are skipped; files are written under a temporary name and renamed, so an interrupted run leaves no partial
+    file under a final name.  A resumed visit's files are those of an uninterrupted one (per-exposure Philox keys);
   * `--gpus G`: the process starts G rank processes itself (one per GPU of this node, before anything touches a
     GPU) and waits for them; under an external launcher (WORLD_SIZE / RANK set, one process per GPU) it is one
     rank.  Each rank generates its round-robin share of the exposures (observation.py:403-405 is the axis) on the
@@ -140,6 +143,9 @@ def run(argv=None):
     ap.add_argument("--gpus", type=int, default=1, help="start rank processes, one per GPU of this node")
     ap.add_argument("--ranks-per-gpu", type=int, default=1, help="... and this many to a GPU (small sub-arrays)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # ranks meet and report, no GPU work
+    ap.add_argument("--resume", action="store_true",
+                    help="skip every exposure whose NNNN_raw.fits is already in the output directory, whole and this "
+                         "visit's (restart after a failed rank: only the missing files are generated)")
     ap.add_argument("--float64-reads", action="store_true",
                     help="float64 reads from the device (the reference's arithmetic to the file) instead of float32 ones")
     args = ap.parse_args(argv)
@@ -198,8 +204,9 @@ def run(argv=None):
         shutil.copy2(args.parameter_file, os.path.join(obs.outdir, os.path.basename(args.parameter_file)))
         t, lc = obs.show_lightcurve()
         np.savetxt(os.path.join(obs.outdir, "visit_plan.txt"), np.column_stack([t, lc]), header="JD white_light_model")
-    frames = obs.run_observation(rank=rank, world=world)
-    print("rank %d/%d: wrote %d files to %s" % (rank, world, len(frames), obs.outdir))
+    frames = obs.run_observation(rank=rank, world=world, resume=args.resume)
+    print("rank %d/%d: wrote %d files to %s%s" % (rank, world, len(frames), obs.outdir,
+                                                 " (%d already there)" % len(obs.skipped) if args.resume else ""))
     return obs
 
 
