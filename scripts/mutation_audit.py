@@ -109,6 +109,13 @@ MUTANTS = [
     dict(name="bin_fraction_dropped", stage="A4 position of a bin inside its pixel (pyparallel_menu.c:91-92; common.h bin_local)",
          what="the production throwers forget the fraction of a pixel of every bin's position: electrons thrown from the pixel's corner",
          edits=[("common.h", "  b.fx = (float)(xd - flx); b.fy = (float)(yd - fly);", "  b.fx = 0.f; b.fy = 0.f;")]),
+    dict(name="lane_floor_is_trunc", stage="A4 the electron's pixel (pyparallel_menu.c:91-93; common.h bin_local: floor of fraction + offset)",
+         what="k_lane's test-free path truncates the local sum toward zero: electrons left of / below their bin's pixel land one pixel high",
+         edits=[("k_narrow.h", 'asm("v_cvt_flr_i32_f32 %0, %2\\n\\tv_cvt_flr_i32_f32 %1, %3\\n\\tv_lshl_add_u32',
+                 'asm("v_cvt_i32_f32 %0, %2\\n\\tv_cvt_i32_f32 %1, %3\\n\\tv_lshl_add_u32')]),
+    dict(name="settle_never_reruns", stage="host: wayne_ctx_synchronize settles incomplete exposures (include/wayne_hip.h)",
+         what="wayne_ctx_synchronize reads the status words and never runs a flagged exposure again",
+         edits=[("wayne_hip.hip", "} else if ((status & 2) && pass == 0) {", "} else if (false && (status & 2) && pass == 0) {")]),
     dict(name="wide_count_rounded", stage="A4 N = (int)(counts ratio) (pyparallel_menu.c:89)",
          what="the wide count rounded to nearest instead of truncated (thrower call and exposure path)",
          edits=[("host_plan.h", "                                                   : (int32_t)nw;",
@@ -251,6 +258,21 @@ PY_MUTANTS = [
 # Mutants of host code no GPU test is needed for (the FITS writer): `python scripts/mutation_audit.py cpu
 # [name ...]` runs the CPU suite in a temporary copy of the tree.
 CPU_MUTANTS = [
+    dict(name="resume_any_start_time", stage="restart: a file is this visit's (observation.py:427; wayne_amd/observation.py exposure_file_is_whole)",
+         what="--resume takes any whole file of the right name and mode for this visit's, whatever its start time",
+         edits=[("wayne_amd/observation.py", "abs(float(p0[\"EXPSTART\"]) - (float(self.exp_start_times[number - 1]) - 2400000.5)) < 1e-7)",
+                 "True)")]),
+    dict(name="resume_counts_no_hdus", stage="restart: a file is whole (exposure_file_is_whole)",
+         what="--resume accepts a file that lost trailing HDUs",
+         edits=[("wayne_amd/observation.py", "if hdus is None or len(hdus) != 1 + 5 * self.NSAMP:", "if hdus is None:")]),
+    dict(name="write_in_place", stage="f1 FITS writer: temporary name, then rename (wayne_amd/fitsio.py write_pieces)",
+         what="files are written under their final name: an interrupted write leaves a partial file there",
+         edits=[("wayne_amd/fitsio.py", "    part = path + PART_SUFFIX\n", "    part = path\n"),
+                ("wayne_amd/fitsio.py", "    os.replace(part, path)\n", "    pass\n")]),
+    dict(name="knob_read_live", stage="host: knobs frozen at context creation (include/wayne_hip.h wayne_ctx_set_knob)",
+         what="wayne_exposure_upload looks at WAYNE_BATCH in the environment of the live context again",
+         edits=[("wayne_amd/csrc/wayne_hip.hip", "    if (c->knobs.batch >= 0) kb = (int)std::min<long long>(std::max<long long>(c->knobs.batch, 1), kLaneBatchMax);",
+                 "    if (const char* e = std::getenv(\"WAYNE_BATCH\")) kb = std::min(std::max(std::atoi(e), 1), kLaneBatchMax);")]),
     dict(name="fits_read_order", stage="f1 FITS layout (exposure.py:133-214: reads in reverse time order)",
          what="the reads written first read first",
          edits=[("wayne_amd/exposure.py", "            samp = n - 1 - i\n", "            samp = i\n")]),

@@ -67,7 +67,8 @@ def test_bench_line_has_the_contract_keys():
     assert bench.READS_LABEL[False] in d["config"]["workload"] and "one HIP stream" in d["config"]["workload"]
     assert "f32 reads (the default of ExposureGenerator, Observation, VisitRunner and the CLI)" == bench.READS_LABEL[False]
     assert d["two_streams"]["note"].startswith("what VisitRunner (Observation, the CLI) delivers device-side")
-    assert d["library"] == {"path": os.path.join("wayne_amd", "libwayne_hip.so"), "build_flags": "", "abi": 7}
+    lib_path = os.environ.get("WAYNE_HIP_LIB") or os.path.join(ROOT, "wayne_amd", "libwayne_hip.so")
+    assert d["library"] == {"path": os.path.relpath(lib_path, ROOT), "build_flags": "", "abi": 7}
     assert rep["incomplete_exposures"] == 0 and rep["second_runs_in_timed_region"] == 0
 
 

@@ -149,3 +149,31 @@ def test_scan_walks_a_file_without_reading_its_data(tmp_path):
     open(q, "wb").write(raw[:len(raw) - 2880])
     assert len(fitsio.scan(q)) == 2
     assert fitsio.scan(str(tmp_path / "missing.fits")) is None
+
+
+def test_a_failed_write_leaves_no_file_under_the_final_name(tmp_path, monkeypatch):
+    # files are written under `<name>.part` and renamed when finished: a write that dies half way (a full disk, a killed
+    # process) never leaves a partial file under the name a reader -- or `--resume` -- looks for, and an older file of
+    # that name stays what it was
+    import numpy as np
+    p = str(tmp_path / "x.fits")
+    hdus = [fitsio.HDU(fitsio.Header([("NSAMP", 3, "")]), None),
+            fitsio.HDU(fitsio.Header([]), np.arange(1000, dtype=np.float64).reshape(25, 40), name="SCI")]
+    fitsio.write(p, hdus)
+    good = open(p, "rb").read()
+    real = fitsio._write_all
+
+    def dies(fd, pieces):
+        os.write(fd, bytes(pieces[0])[:1000])                 # a little of the file, then the failure
+        raise OSError(28, "No space left on device")
+    monkeypatch.setattr(fitsio, "_write_all", dies)
+    with pytest.raises(OSError):
+        fitsio.write(p, hdus)
+    assert open(p, "rb").read() == good                        # the file of that name is untouched
+    q = str(tmp_path / "y.fits")
+    with pytest.raises(OSError):
+        fitsio.write(q, hdus)
+    assert not os.path.exists(q) and os.path.exists(q + fitsio.PART_SUFFIX)
+    monkeypatch.setattr(fitsio, "_write_all", real)
+    fitsio.write(q, hdus)
+    assert open(q, "rb").read() == good and not os.path.exists(q + fitsio.PART_SUFFIX)
