@@ -48,6 +48,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg3", type=int, default=1024)
     ap.add_argument("--cfg4", type=int, default=160)
+    ap.add_argument("--cfg2", type=int, default=0, help="staring mode, full array (BASELINE configs[1]: 100 exposures)")
+    ap.add_argument("--cfg5-g102", type=int, default=0, help="the G102 grism, cfg4's shape with SSV")
     ap.add_argument("--replay-every", type=int, default=8)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "visit_science.json"))
     a = ap.parse_args()
@@ -56,6 +58,10 @@ def main():
         out["cfg3"] = run("cfg3", a.cfg3, a.replay_every)
     if a.cfg4:
         out["cfg4"] = run("cfg4", a.cfg4, a.replay_every)
+    if a.cfg2:
+        out["cfg2"] = run("cfg2", a.cfg2, a.replay_every)
+    if a.cfg5_g102:
+        out["cfg5_g102"] = run("cfg5_g102", a.cfg5_g102, a.replay_every)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -244,3 +244,28 @@ def test_inner_boundary_from_plain_c(tmp_path):
         frame = np.fromfile(str(tmp_path / "out.bin"), dtype=np.int32)
         np.testing.assert_array_equal(frame, k["frame"].ravel())
         assert ("%d electrons" % int(k["frame"].sum())) in r.stdout
+
+
+def test_a_bins_fraction_of_a_pixel_survives_at_the_far_side_of_the_frame(gpu_ctx):
+    # The reference adds an electron's offset to its bin's position in fp64 (pyparallel_menu.c:91-92).  Through round 5
+    # the production throwers cast the FRAME coordinate to float32 first: at x >= 512 that rounds to 6.1e-5 px, so a bin
+    # 2e-5 px below a pixel boundary was moved ONTO it and its electrons into the next pixel.  With a PSF far narrower
+    # than that distance the law is a certainty -- every electron in pixel (floor(y), floor(x)) -- and all three modes
+    # must give the same frame: the bit-exact replay of the reference, and the production modes from bin-local
+    # coordinates (wayne_amd/csrc/common.h, bin_local).  No oracle in between.
+    N = 1014
+    ks = np.arange(520, 1010, 7)
+    eps = 2e-5
+    x = np.concatenate([ks + 1.0 - eps, ks + eps, ks + 0.5])                 # just below, just above a boundary, mid-pixel
+    y = np.concatenate([ks[::-1] + eps, ks[::-1] + 1.0 - eps, ks[::-1] + 1.0 - eps])
+    n = x.size
+    counts = np.full(n, 300, dtype=np.int32)
+    counts[::3] = 20                                                          # thin bins too
+    ratio = np.full(n, 0.25)                                                  # a quarter of each bin takes sigma_h
+    sl, sh = np.full(n, 1e-6), np.full(n, 2e-6)
+    want = np.zeros((N, N), dtype=np.int64)
+    np.add.at(want, (np.floor(y).astype(int), np.floor(x).astype(int)), counts)
+    assert np.all(np.float32(x[:ks.size]) == ks + 1.0)                        # the cast that used to be made: ON the boundary
+    for mode in (_lib.RNG_REPLAY, _lib.RNG_PHILOX, _lib.RNG_SPLIT):
+        got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 11, threads=3, rng_mode=mode).reshape(N, N)
+        np.testing.assert_array_equal(got, want, err_msg="rng_mode %d" % mode)

@@ -15,8 +15,11 @@ Asserted, every bound a multiple of the fit's own error (from its residuals), no
       under 2 ppm -- the measured replacement of the argued "aggregate approximation budget" of the production thrower;
   (c) float32 against float64 reads: below 0.5 ppm in every channel -- which settles the float32 default;
   (d) replay - per-electron on the subset: the same, at its sigma;
-  (e) no dependence of the paired flux ratio on the star's sub-pixel phase in x or y (a first harmonic is what a
-      position-rounding defect of the thrower would leave).
+  (e) no dependence of the paired flux ratio on the star's sub-pixel phase in x or y, white light and channel by channel;
+  (f) no flux moved between channels (the static part of the pair) -- with a NEGATIVE CONTROL: a library whose
+      production throwers drop the fraction of a pixel of every bin's position fails (f) by hundreds of sigma while its
+      depths stay right, which is why both are asked for;
+  (g) the pairing estimator has unit gain: a visit generated 0.2 % deeper is found 0.2 % deeper.
 scripts/visit_science.py runs the same at twice the length and writes profiles/r06/visit_science.json.
 """
 import json
@@ -96,6 +99,81 @@ def test_production_mode_against_every_electron_float64_in_ppm(visit):
         for axis in ("x", "y"):
             ph = r["flux_ratio_vs_%s_phase_ppm" % axis]
             assert ph["chi2"] < CHI2_2, (how, axis, ph)
+
+
+def test_no_channel_depends_on_the_sub_pixel_phase(visit):
+    sv, rep = visit
+    # 20 channels x 2 extractions x 2 visits: the largest of 80 chi2 values of 2 dof stays below the 1e-5 quantile
+    for how in ("ramp", "last_read"):
+        chi2 = np.array(rep["paired"]["production_minus_per_electron"][how]["flux_ratio_vs_x_phase_by_channel_chi2"])
+        assert chi2.max() < 23.0, (how, chi2)
+
+
+def test_no_mode_moves_flux_between_channels(visit):
+    # the static part of a pair: the mean flux ratio of every channel over the visit is 1 -- the production thrower puts a
+    # channel's electrons where the per-electron thrower puts them (a transit-independent redistribution would cancel in
+    # a depth and show here; the negative control below is such a defect)
+    sv, rep = visit
+    for pair in ("production_minus_per_electron", "replay_minus_per_electron"):
+        r = rep["paired"][pair]["ramp"]
+        off, sig = np.array(r["channel_flux_offset_ppm"]), np.array(r["channel_flux_offset_sigma_ppm"])
+        assert np.abs(off / sig).max() < K_PULL, (pair, off, sig)
+        assert np.abs(off).max() < 60.0 * np.sqrt(64.0 / rep["paired"][pair]["n"]) + 15.0, (pair, off)
+
+
+def test_negative_control_a_dropped_fraction_of_a_pixel_is_seen():
+    # The measurement has teeth: a library whose production throwers forget where inside its pixel a bin sits
+    # (-DWAYNE_NEGCTL_DROP_FRACTION: the gross form of a position-rounding defect; the replay mode, fp64 positions, is not
+    # touched by it) shifts every bin's electrons by its own fraction of a pixel -- half a pixel on average, whatever the
+    # star's phase, because 26 bins share a pixel -- so channels on a rising flank of the spectrum gain flux and channels
+    # on a falling flank lose it: per-channel flux offsets of thousands of ppm, hundreds of sigma, where the shipped
+    # library shows none (above).  A transit DEPTH is blind to it (a static redistribution cancels in the ratio of in- to
+    # out-of-transit flux): that is why the pair is asked for both.  In a child process: the library is chosen at load.
+    import subprocess
+    import sys
+    from wayne_amd import build as wb
+    lib = wb.build_negctl_fraction()
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); import visit_science as vs\n"
+        "sv = vs.ScienceVisit('cfg3', 96)\n"
+        "t = {m: vs.generate(sv, m) for m in ('production', 'replay')}\n"
+        "t['per_electron'] = t.pop('replay')\n"           # (pair against the mode the defect does not touch)
+        "rep = vs.analyse(sv, t)\n"
+        "r = rep['paired']['production_minus_per_electron']['ramp']\n"
+        "print(json.dumps({'offset_ppm': r['channel_flux_offset_ppm'], 'sigma_ppm': r['channel_flux_offset_sigma_ppm'],\n"
+        "                  'depth_chi2': r['chi2'], 'white_depth_difference_ppm': r['white_depth_difference_ppm'],\n"
+        "                  'white_sigma_ppm': r['white_sigma_ppm']}))\n"
+    ) % os.path.join(ROOT, "tests")
+    env = dict(os.environ, WAYNE_HIP_LIB=lib, WAYNE_ALLOW_FLAGGED_LIB="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    keep("negative_control_dropped_fraction", got)
+    off, sig = np.array(got["offset_ppm"]), np.array(got["sigma_ppm"])
+    assert np.abs(off).max() > 2000.0 and np.abs(off / sig).max() > 100.0, (off, sig)
+    assert off.max() > 500.0 and off.min() < -500.0                      # both signs: flux moved, not lost
+    # ... and the depths do not care (which is the point of a differential measurement)
+    assert got["depth_chi2"] < CHI2_20 and abs(got["white_depth_difference_ppm"]) < 4.0 * got["white_sigma_ppm"] + 3.0
+
+
+def test_the_pairing_recovers_an_injected_depth_difference():
+    # ... and the estimator has unit gain: the per-electron visit generated with every depth 0.2 % deeper (29 ppm at a
+    # depth of 1.46 %), the paired fit must return that difference, white light and channel by channel
+    from wayne_amd import engine
+    sv = vs.ScienceVisit("cfg3", 256)
+    scale = 1.002
+    a = vs.generate(sv, "production")
+    b = vs.generate(sv, "per_electron", depth_scale=scale)
+    engine.close_all()
+    for k in (0, 1):
+        d, s_, _ = vs.fit_paired(a[k], b[k], sv.G)
+        want = -(scale - 1.0) * sv.expected
+        assert np.abs((d - want) / s_).max() < K_PULL and (((d - want) / s_) ** 2).sum() < CHI2_20
+        dw, sw, _ = vs.fit_paired(vs.white(a[k]), vs.white(b[k]), sv.G)
+        want_w = -(scale - 1.0) * sv.white_expected
+        assert abs(dw[0] - want_w) < 4.0 * sw[0] and abs(dw[0]) > 10.0 * sw[0]           # seen, and at its size
+        keep("injected_difference_%s" % ("ramp" if k == 0 else "last_read"),
+             {"injected_ppm": want_w * 1e6, "recovered_ppm": float(dw[0]) * 1e6, "sigma_ppm": float(sw[0]) * 1e6})
 
 
 def test_float32_reads_change_no_depth(visit):

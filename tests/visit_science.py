@@ -47,7 +47,7 @@ MODES = {
     "replay": (_lib.RNG_REPLAY, np.float64, True),            # the reference's own rand_r streams, bit-exact scatter
 }
 N_CHANNELS = 20
-WL_RANGE = (1.12, 1.65)       # micron: where the G141 sensitivity is high
+WL_RANGES = {"G141": (1.12, 1.65), "G102": (0.82, 1.13)}       # micron: where the grism's sensitivity is high
 ROW_MARGIN = 14
 BG_COLS = (6, 26)             # bordered columns used for the sky level (left of the first-order spectrum)
 
@@ -80,7 +80,8 @@ class ScienceVisit(object):
         tr = gr.get_trace(v.cfg["x_ref"] + 0.5, v.cfg["y_ref"] + 0.5)
         self.dx = np.asarray(tr.wl_to_x(self.wl), dtype=float) - (v.cfg["x_ref"] + 0.5)
         self.dy = np.asarray(tr.wl_to_y(self.wl), dtype=float) - (v.cfg["y_ref"] + 0.5)
-        edges_wl = np.linspace(WL_RANGE[0], WL_RANGE[1], N_CHANNELS + 1)
+        lo_wl, hi_wl = WL_RANGES[gr.name]
+        edges_wl = np.linspace(lo_wl, hi_wl, N_CHANNELS + 1)
         self.edges = np.interp(edges_wl, self.wl, self.dx)               # channel edges as offsets from the star, px
         self.channel_wl = 0.5 * (edges_wl[1:] + edges_wl[:-1])
         # transit
@@ -173,8 +174,9 @@ class ScienceVisit(object):
         return ramp, last
 
 
-def generate(sv, mode, indices=None, depth=3):
-    """Flux tables (n, N_CHANNELS) x 2 of the visit in `mode`, exposures pipelined over `depth` context slots."""
+def generate(sv, mode, indices=None, depth=3, depth_scale=1.0):
+    """Flux tables (n, N_CHANNELS) x 2 of the visit in `mode`, exposures pipelined over `depth` context slots.
+    `depth_scale`: the injected transit depths multiplied by it (the estimator's own injection-recovery check)."""
     v = sv.v
     rng_mode, out_dtype, exact = MODES[mode]
     eng = engine.get_engine(0, v.grism, v.detector, v.calibration, v.NSAMP, v.SAMPSEQ, v.SUBARRAY)
@@ -192,8 +194,11 @@ def generate(sv, mode, indices=None, depth=3):
     for n, i in enumerate(idx):
         eg = ExposureGenerator(v.detector, v.grism, v.NSAMP, v.SAMPSEQ, v.SUBARRAY, calibration=v.calibration,
                                seed=v.seed, exposure_index=i)
+        over = dict(sv.frame_overrides)
+        if depth_scale != 1.0:
+            over["planet_signal"] = v.planet_signal(i) * depth_scale
         desc = eg.build_descriptor(eng, rng_mode=rng_mode, out_dtype=out_dtype, exact_samplers=exact, threads=2,
-                                   **v.frame_kwargs(i, **sv.frame_overrides))
+                                   **v.frame_kwargs(i, **over))
         if len(in_flight) >= depth:
             finish()
         slot = n % (depth + 1)
@@ -294,6 +299,13 @@ def analyse(sv, tables, subset=None):
             r_chan = (fa / fb - 1.0).mean(axis=1)
             px = phase_trend(r_chan, sv.phase_x[idx])
             py = phase_trend(r_chan, sv.phase_y[idx])
+            # ... and channel by channel in x, where a shift of the spectrum against the star-fixed channels shows first (the
+            # steep flanks of the sensitivity curve): the largest chi2 (2 dof each) of the 20
+            by_channel = [phase_trend((fa / fb - 1.0)[:, c], sv.phase_x[idx])[2] for c in range(N_CHANNELS)]
+            # the static part of the pair: does one mode put a channel's electrons into its neighbours?  Mean flux ratio
+            # per channel over the visit (a transit-independent redistribution cancels in a depth; it shows here)
+            rc = fa / fb - 1.0
+            off, off_s = rc.mean(axis=0), rc.std(axis=0, ddof=1) / np.sqrt(rc.shape[0])
             rep[how] = {"depth_difference_ppm": [round(float(x) * 1e6, 3) for x in d],
                         "sigma_ppm": [round(float(x) * 1e6, 3) for x in s],
                         "chi2": float(((d / s) ** 2).sum()), "dof": N_CHANNELS,
@@ -301,6 +313,9 @@ def analyse(sv, tables, subset=None):
                         "white_depth_difference_ppm": round(float(dw[0]) * 1e6, 4), "white_sigma_ppm": round(float(sw[0]) * 1e6, 4),
                         "white_flux_offset_ppm": round(float(r_white.mean()) * 1e6, 4),
                         "white_flux_offset_sigma_ppm": round(float(r_white.std(ddof=1) / np.sqrt(len(r_white))) * 1e6, 4),
+                        "flux_ratio_vs_x_phase_by_channel_chi2": [round(float(x), 2) for x in by_channel],
+                        "channel_flux_offset_ppm": [round(float(x) * 1e6, 2) for x in off],
+                        "channel_flux_offset_sigma_ppm": [round(float(x) * 1e6, 2) for x in off_s],
                         "flux_ratio_vs_x_phase_ppm": {"cos_sin": [round(float(x) * 1e6, 3) for x in px[0]],
                                                       "err": [round(float(x) * 1e6, 3) for x in px[1]], "chi2": px[2], "dof": 2},
                         "flux_ratio_vs_y_phase_ppm": {"cos_sin": [round(float(x) * 1e6, 3) for x in py[0]],

@@ -78,6 +78,16 @@ def build_negctl_key(force=False, verbose=False):
     return build_variant(["-DWAYNE_NEGCTL_ADDITIVE_KEY"], NEGCTL_KEY_LIB, force, verbose)
 
 
+# Negative-control library of tests/test_visit_science_gpu.py: the production throwers drop the fraction of a pixel of
+# every bin's position (common.h, bin_local) -- the gross form of the position-rounding defect that the visit-level
+# measurement is there to exclude.
+NEGCTL_FRACTION_LIB = os.path.join(ROOT, "tests", "native", "_build", "libwayne_hip_negctl_fraction.so")
+
+
+def build_negctl_fraction(force=False, verbose=False):
+    return build_variant(["-DWAYNE_NEGCTL_DROP_FRACTION"], NEGCTL_FRACTION_LIB, force, verbose)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

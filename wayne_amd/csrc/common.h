@@ -77,6 +77,11 @@ __device__ __forceinline__ BinLocal bin_local(double xd, double yd) {
   const double flx = sane ? floor(xd) : 0., fly = sane ? floor(yd) : 0.;
   b.fx = (float)(xd - flx); b.fy = (float)(yd - fly);
   b.ox = (int)flx; b.oy = (int)fly;
+#ifdef WAYNE_NEGCTL_DROP_FRACTION
+  // NEGATIVE-CONTROL BUILD (wrong frames; tests/test_visit_science_gpu.py): the production throwers forget where inside
+  // its pixel a bin sits -- the gross form of a position-rounding defect, to show that the visit-level measurement sees one
+  b.fx = 0.f; b.fy = 0.f;
+#endif
   return b;
 }
 // (int)floorf(v) as ONE instruction (v_cvt_flr_i32_f32: floor, convert, saturate; NaN gives 0) -- the compiler's own

@@ -658,6 +658,9 @@ const char* wayne_build_flags(void) {
 #ifdef WAYNE_NEGCTL_ADDITIVE_KEY
          " WAYNE_NEGCTL_ADDITIVE_KEY"
 #endif
+#ifdef WAYNE_NEGCTL_DROP_FRACTION
+         " WAYNE_NEGCTL_DROP_FRACTION"
+#endif
 #ifdef WAYNE_TIMING_KNOBS
          " WAYNE_TIMING_KNOBS"
 #endif
