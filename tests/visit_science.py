@@ -115,10 +115,16 @@ class ScienceVisit(object):
         d = v.depth0[i0:i1]
         out = np.empty(N_CHANNELS)
         self.channel_electrons = np.empty(N_CHANNELS)
+        # the wavelength solution is field dependent (grism.py:779-803): along a 700-row scan a wavelength's column moves
+        # by a fraction of a pixel against the star, so the PSF's mass on a channel is averaged over the scan
+        # (9 positions; the channel EDGES stay those of the scan's start: they are the observer's choice)
+        tr0 = (v.cfg["x_ref"] + 0.5, v.cfg["y_ref"] + 0.5)
+        dxs = [np.asarray(gr.get_trace(tr0[0], tr0[1] + v.scan_speed * t).wl_to_x(self.wl), dtype=float) - tr0[0]
+               for t in np.linspace(0.0, self.read_times[-1], 9)] if v.scan_speed else [self.dx]
         for c in range(N_CHANNELS):
             a, b = self.edges[c], self.edges[c + 1]
-            mass = (ratio * (ndtr((b - self.dx) / sh) - ndtr((a - self.dx) / sh)) +
-                    (1 - ratio) * (ndtr((b - self.dx) / sl) - ndtr((a - self.dx) / sl)))
+            mass = np.mean([ratio * (ndtr((b - dx) / sh) - ndtr((a - dx) / sh)) +
+                            (1 - ratio) * (ndtr((b - dx) / sl) - ndtr((a - dx) / sl)) for dx in dxs], axis=0)
             w = weight * mass
             out[c] = (w * d).sum() / w.sum()
             self.channel_electrons[c] = w.sum() * self.read_times[-1] * 1e4 * 1e-3 * 1e3   # (flux x sens x dlam[um] 1e4 x s)
