@@ -42,7 +42,6 @@ import hashlib
 import json
 import os
 import re
-import subprocess
 import sys
 import time
 

@@ -23,7 +23,6 @@ import numpy as np
 import pytest
 import yaml
 
-import helpers
 from oracle import clib, visit_oracle as vo, wayne_oracle as wo
 from wayne_amd import _lib, fitsio, run_visit
 from wayne_amd.exposure_generator import ExposureGenerator

@@ -402,6 +402,20 @@ def test_cli_starts_its_own_ranks(tmp_path, how):
         for ha, hb in zip(a, b):
             if ha.data is not None:
                 np.testing.assert_array_equal(ha.data, hb.data)
+    # ... and the two ranks restarted with --resume after rank 1 lost a file: only that file is written again
+    stamp = {n: os.stat(os.path.join(outdir2, n)).st_mtime_ns for n in names}
+    os.remove(os.path.join(outdir2, names[1]))                  # exposure index 1: rank 1's
+    out = subprocess.run([sys.executable, "-m", "wayne_amd.run_visit", "-p", os.path.join(two, "params.yml"),
+                          "--max-exposures", "4", "--resume"] + ranks, capture_output=True, text=True, timeout=900, env=env,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "(2 already there)" in out.stdout and "(1 already there)" in out.stdout
+    for n in names:
+        assert (os.stat(os.path.join(outdir2, n)).st_mtime_ns == stamp[n]) == (n != names[1]), n
+    a, b = fitsio.read(os.path.join(obs.outdir, names[1])), fitsio.read(os.path.join(outdir2, names[1]))
+    for ha, hb in zip(a, b):
+        if ha.data is not None:
+            np.testing.assert_array_equal(ha.data, hb.data)
 
 
 def test_cli_launcher_fails_loudly_without_gpus(tmp_path):
