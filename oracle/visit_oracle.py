@@ -158,15 +158,16 @@ class ObservationOracle(object):
             self.scale_factors = hook_and_long_term_ramp(self.exp_start_times, self.orbit_start_index,
                                                          *visit_trend_coeffs)
 
-    def exposure_inputs(self, number):
+    def exposure_inputs(self, number, with_depths=True):
         """What _generate_exposure hands to scanning_frame / staring_frame for file number `number`
-        (observation.py:415-462)."""
+        (observation.py:415-462).  `with_depths=False` leaves the K x W light-curve matrix out (None): this oracle's
+        model is a 2-D integration per sample and wavelength, minutes for an in-transit exposure of 2233 sub-samples."""
         index_number = number - 1
         expstart = self.exp_start_times[index_number]
         sample_rate = self.sample_rate if self.spatial_scan else 365.25 * 86400. * 1000.   # :433-434 (1 yr, in ms)
         _, mids, durs, read_index = self.eo._gen_scanning_sample_times(sample_rate)          # :436
         time_array = expstart + mids / (86400. * 1000.)                                        # :439
-        depths = planet_depths(self.orbit, self.ldcoeffs, self.planet_spectrum, time_array, self.rp_white)
+        depths = planet_depths(self.orbit, self.ldcoeffs, self.planet_spectrum, time_array, self.rp_white) if with_depths else None
         x_ref = try_index(self.x_ref, index_number) + self.x_shifts * index_number            # :449-455
         y_ref = try_index(self.y_ref, index_number) + self.y_shifts * index_number
         sky = try_index(self.sky_background, index_number)
@@ -176,15 +177,15 @@ class ObservationOracle(object):
 
     def generate_exposure(self, number, draws, **oracle_kw):
         """The reads of exposure `number` (observation.py:464-500) through ExposureOracle."""
-        inp = self.exposure_inputs(number)
+        # `planet_signal`: a K x W depth matrix to use instead of this oracle's own light curves (a test hands in the
+        # device's, after comparing the two, so that np.round / Poisson of the counts see the same means to the last bit)
+        override = oracle_kw.pop("planet_signal", None)
+        inp = self.exposure_inputs(number, with_depths=override is None)
         kw = dict(self.frame_kwargs)
         kw.update(sky_background=inp["sky_background"], scale_factor=inp["scale_factor"])
         kw.update(oracle_kw)
-        # `planet_signal`: a K x W depth matrix to use instead of this oracle's own light curves (a test hands in the
-        # device's, after comparing the two, so that np.round / Poisson of the counts see the same means to the last bit)
-        override = kw.pop("planet_signal", None)
         if override is not None:
-            assert np.shape(override) == np.shape(inp["planet_signal"])
+            assert np.shape(override) == (len(inp["sample_mid_points"]), len(self.wl))
             inp["planet_signal"] = np.asarray(override, dtype=float)
         if self.spatial_scan:
             return self.eo.scanning_frame(inp["x_ref"], inp["y_ref"], self.x_jitter, self.y_jitter, self.wl,
