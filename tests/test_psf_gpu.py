@@ -196,6 +196,13 @@ def test_hostile_inputs_all_modes(gpu_ctx):
     sl[30], sh[31] = -0.7, -3.0
     sl[40] = 0.0
     ratio[50] = np.nan
+    # sigmas that are not finite: the reference's (int) of a non-finite position keeps none of the electrons that take
+    # them (pyparallel_menu.c:91-93) -- the wide ones of bin 60 / 62, the narrow ones of bin 61 / 63, everything of 64 --
+    # while the bin's other electrons land as usual (the production throwers settle this once per bin: k_narrow.h bad_h / bad_l)
+    for b in (60, 61, 62, 63, 64):
+        x[b], y[b], ratio[b], counts[b] = 40.0 + b, 50.5, 0.5, 300
+    sh[60], sl[61], sh[62], sl[63] = np.nan, np.nan, np.inf, -np.inf
+    sl[64] = sh[64] = np.nan
     want = clib.psf_oracle(counts, x, y, ratio, sl, sh, N, N, 77, 3)
     got = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 77, threads=3, rng_mode=_lib.RNG_REPLAY)
     np.testing.assert_array_equal(got, want)
@@ -213,6 +220,13 @@ def test_hostile_inputs_all_modes(gpu_ctx):
     a = gpu_ctx.psf_apply(counts, x, y, ratio, sl, sh, N, N, 5, rng_mode=_lib.RNG_SPLIT)
     moved = int(np.abs(a.astype(np.int64) - w2).sum()) // 2
     assert moved <= 5 + 1e-3 * w2.sum(), "%d of %d electrons moved" % (moved, w2.sum())
+    # the five bins alone: exactly the electrons with a finite sigma arrive (150 of 300 each, none of bin 64's), in all modes
+    sel = np.zeros(W, dtype=bool)
+    sel[60:65] = True
+    c5 = np.where(sel, counts, 0).astype(np.int32)
+    for mode in (_lib.RNG_REPLAY, _lib.RNG_PHILOX, _lib.RNG_SPLIT):
+        f5 = gpu_ctx.psf_apply(c5, x, y, ratio, sl, sh, N, N, 9, threads=2, rng_mode=mode)
+        assert int(f5.sum()) == 4 * 150, (mode, int(f5.sum()))
 
 
 def test_inner_boundary_from_plain_c(tmp_path):
