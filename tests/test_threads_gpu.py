@@ -142,15 +142,18 @@ def test_a_thread_editing_the_environment_does_not_change_a_live_context():
         knobs_before = {k: eng.ctx.get_knob(k) for k in _lib.KNOBS}
         reruns_before = eng.ctx.reruns
         stop = threading.Event()
+        # every variable is given a value ONCE here, while nothing of this process is inside the library: the meddler
+        # below then only replaces values of names that exist (a pointer swap in libc's table), never adds or removes one
+        # -- growing or shrinking the table under a concurrent reader elsewhere in the process (the HIP runtime reads its
+        # own variables with getenv) would be a hazard of this TEST, not of the product
+        for k, val in names.items():
+            os.environ[k] = val
 
         def meddle():
             flip = 0
             while not stop.is_set():
                 for k, val in names.items():
-                    if flip & 1:
-                        os.environ[k] = val
-                    else:
-                        os.environ.pop(k, None)
+                    os.environ[k] = val if flip & 1 else "2"
                 flip += 1
         t = threading.Thread(target=meddle)
         t.start()
